@@ -1,0 +1,60 @@
+"""In-tree build of the HIP library (hipcc, gfx950 only).
+
+`python apd-mvs_amd/build.py` or `build_library()` compiles csrc/*.hip into
+apd-mvs_amd/_build/libapd_mi355x.so.  -ffp-contract=off and no fast-math are part of the
+arithmetic contract: the kernels must round exactly like the CPU oracle.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "_build")
+LIB_PATH = os.path.join(OUT_DIR, "libapd_mi355x.so")
+SOURCES = ["apd_kernels.hip", "apd_kernels_weak.hip", "apd_capi.hip"]
+HEADERS = ["apd_device.h", "apd_sweep.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False, extra_flags=()):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([HIPCC] + FLAGS + list(extra_flags) + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout)
+        return r.stdout
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=3) as ex:
+            for out in ex.map(run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    if jobs or not os.path.exists(LIB_PATH):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

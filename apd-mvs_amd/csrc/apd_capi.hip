@@ -1,0 +1,695 @@
+// apd_capi.hip -- host side of the C ABI (include/apd_mi355x.h): one apd_context == one reference
+// `APD` object (APD.h:67-145).  Owns every device allocation, the stream and the per-kernel timers.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "apd_device.h"
+
+namespace apd {
+hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
+hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
+hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s);
+}  // namespace apd
+
+using apd::FrameArgs;
+using apd::ViewConst;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            return fail(APD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                    \
+    } while (0)
+
+struct apd_context {
+    int device = 0;
+    int W = 0, H = 0;
+    apd_params params{};
+    int num_images = 0;
+    bool views_uploaded = false;
+    bool prior_uploaded = false;
+    int weak_count = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device memory
+    std::vector<float *> images;
+    std::vector<float *> depths;
+    ViewConst *views_dev = nullptr;
+    float4 *planes = nullptr, *fit_planes = nullptr;
+    float *costs = nullptr;
+    uint32_t *rng = nullptr, *selected_views = nullptr;
+    uint8_t *view_weight = nullptr, *weak_info = nullptr, *weak_reliable = nullptr;
+    short2 *nearest_strong = nullptr, *neighbours = nullptr;
+    int *neighbours_map = nullptr;
+    size_t neighbours_cap = 0;
+    FrameArgs fa{};
+    // profiling
+    bool profiling = false;
+    double prof_ms[APD_KERNEL_COUNT] = {0};
+    int prof_launches[APD_KERNEL_COUNT] = {0};
+    struct PendingEvent {
+        int kernel;
+        hipEvent_t start, stop;
+    };
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+// ---------------------------------------------------------------------------------------------
+// contract C2/C3 on the host: plane-independent part of ComputeHomography (APD.cu:305-331).
+// Built with -ffp-contract=off; fmaf exactly where the oracle has it.
+// ---------------------------------------------------------------------------------------------
+static inline float dot3_fma(float a0, float b0, float a1, float b1, float a2, float b2)
+{
+    return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
+}
+
+static void relative_pose(const apd_camera &ref, const apd_camera &src, float Rr[9], float tr[3])
+{
+    float refC[3], srcC[3], Cr[3];
+    for (int j = 0; j < 3; ++j) {
+        refC[j] = -dot3_fma(ref.R[0 + j], ref.t[0], ref.R[3 + j], ref.t[1], ref.R[6 + j], ref.t[2]);
+        srcC[j] = -dot3_fma(src.R[0 + j], src.t[0], src.R[3 + j], src.t[1], src.R[6 + j], src.t[2]);
+    }
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+            Rr[3 * r + c] = dot3_fma(src.R[3 * r + 0], ref.R[3 * c + 0], src.R[3 * r + 1], ref.R[3 * c + 1], src.R[3 * r + 2],
+                                     ref.R[3 * c + 2]);
+        }
+    }
+    for (int j = 0; j < 3; ++j) {
+        Cr[j] = refC[j] - srcC[j];
+    }
+    for (int r = 0; r < 3; ++r) {
+        tr[r] = dot3_fma(src.R[3 * r + 0], Cr[0], src.R[3 * r + 1], Cr[1], src.R[3 * r + 2], Cr[2]);
+    }
+}
+
+static void refresh_frame_args(apd_context *c)
+{
+    FrameArgs &fa = c->fa;
+    const apd_params &p = c->params;
+    fa.W = c->W;
+    fa.H = c->H;
+    fa.num_src = c->num_images > 0 ? c->num_images - 1 : 0;
+    fa.half_rows = 2 * (((c->H / 2) + 15) / 16) * 16;
+    fa.top_k = p.top_k;
+    fa.depth_min = p.depth_min;
+    fa.depth_max = p.depth_max;
+    fa.geom_consistency = p.geom_consistency;
+    fa.weak_peak_radius = p.weak_peak_radius;
+    fa.rotate_time = p.rotate_time;
+    fa.ransac_threshold = p.ransac_threshold;
+    fa.geom_factor = p.geom_factor;
+    fa.state = p.state;
+    fa.seed = p.seed;
+    // constants of GenNeighbours evaluated in double on the host (APD.cu:1791-1795)
+    const float angle = 45.0f / (float)(p.rotate_time > 0 ? p.rotate_time : 1);
+    fa.k3_cos_angle = (float)cos((double)angle * M_PI / (double)180.f);
+    fa.k3_sin_angle = (float)sin((double)angle * M_PI / (double)180.f);
+    fa.k3_cone = (float)cos((double)(angle / 2.0f) * M_PI / (double)180.0f);
+    int shift = (int)(tan((double)(angle / 2.0f) * M_PI / (double)180.0f) * 20);
+    fa.k3_shift_range = shift < 1 ? 1 : shift;
+    fa.ref_img = c->images.empty() ? nullptr : c->images[0];
+    fa.views = c->views_dev;
+    fa.planes = c->planes;
+    fa.fit_planes = c->fit_planes;
+    fa.costs = c->costs;
+    fa.rng = c->rng;
+    fa.selected_views = c->selected_views;
+    fa.view_weight = c->view_weight;
+    fa.weak_info = c->weak_info;
+    fa.weak_reliable = c->weak_reliable;
+    fa.nearest_strong = c->nearest_strong;
+    fa.neighbours_map = c->neighbours_map;
+    fa.neighbours = c->neighbours;
+}
+
+extern "C" {
+
+void apd_default_params(apd_params *p)
+{
+    if (!p) {
+        return;
+    }
+    memset(p, 0, sizeof(*p));
+    p->max_iterations = 3;
+    p->num_images = 5;
+    p->sigma_spatial = 5.0f;
+    p->sigma_color = 3.0f;
+    p->top_k = 4;
+    p->depth_min = 0.0f;
+    p->depth_max = 1.0f;
+    p->geom_consistency = 0;
+    p->strong_radius = 5;
+    p->strong_increment = 2;
+    p->weak_radius = 5;
+    p->weak_increment = 5;
+    p->use_APD = 1;
+    p->weak_peak_radius = 2;
+    p->rotate_time = 4;
+    p->ransac_threshold = 0.005f;
+    p->geom_factor = 0.2f;
+    p->state = APD_FIRST_INIT;
+    p->seed = 12345ull;
+}
+
+const char *apd_last_error(void) { return g_last_error.c_str(); }
+int apd_version(void) { return 100; }
+
+int apd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+int apd_create(apd_handle *out, int device, int width, int height, const apd_params *params)
+{
+    if (!out || !params || width <= 0 || height <= 0) {
+        return fail(APD_ERR_INVALID, "apd_create: bad argument");
+    }
+    if (width > 16384 || height > 16384) {
+        return fail(APD_ERR_UNSUPPORTED, "apd_create: image larger than 16384 px per side");
+    }
+    if (params->strong_radius != 5 || params->strong_increment != 2 || params->weak_radius != 5 || params->weak_increment != 5) {
+        // the reference never changes these (main.h:84-87); the kernels are specialised for them
+        return fail(APD_ERR_UNSUPPORTED, "apd_create: only strong 5/2 and weak 5/5 patch geometry is built");
+    }
+    if (device >= 0) {
+        HIP_TRY(hipSetDevice(device));
+    }
+    apd_context *c = new apd_context();
+    HIP_TRY(hipGetDevice(&c->device));
+    c->W = width;
+    c->H = height;
+    c->params = *params;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    const size_t n = (size_t)width * height;
+    // allocations of CudaSpaceInitialization (APD.cpp:636-666)
+    HIP_TRY(hipMalloc(&c->costs, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->rng, n * 6 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->selected_views, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->view_weight, n * APD_MAX_IMAGES));
+    HIP_TRY(hipMalloc(&c->planes, n * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->fit_planes, n * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->weak_info, n));
+    HIP_TRY(hipMalloc(&c->weak_reliable, n));
+    HIP_TRY(hipMalloc(&c->nearest_strong, n * sizeof(short2)));
+    HIP_TRY(hipMalloc(&c->neighbours_map, n * sizeof(int)));
+    HIP_TRY(hipMalloc(&c->views_dev, APD_MAX_IMAGES * sizeof(ViewConst)));
+    HIP_TRY(hipMemsetAsync(c->costs, 0, n * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->rng, 0, n * 6 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->selected_views, 0, n * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->view_weight, 0, n * APD_MAX_IMAGES, c->stream));  // uninitialised in the reference
+    HIP_TRY(hipMemsetAsync(c->planes, 0, n * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->fit_planes, 0, n * sizeof(float4), c->stream));    // APD.cpp:651
+    HIP_TRY(hipMemsetAsync(c->weak_info, APD_STRONG, n, c->stream));             // APD.cpp:541-547
+    HIP_TRY(hipMemsetAsync(c->weak_reliable, 0, n, c->stream));
+    HIP_TRY(hipMemsetAsync(c->nearest_strong, 0, n * sizeof(short2), c->stream));
+    HIP_TRY(hipMemsetAsync(c->neighbours_map, 0, n * sizeof(int), c->stream));
+    HIP_TRY(hipMalloc(&c->neighbours, APD_NEIGHBOUR_NUM * sizeof(short2)));
+    c->neighbours_cap = 1;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    refresh_frame_args(c);
+    *out = c;
+    return APD_OK;
+}
+
+int apd_destroy(apd_handle c)
+{
+    if (!c) {
+        return APD_OK;
+    }
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (float *p : c->images) {
+        hipFree(p);
+    }
+    for (float *p : c->depths) {
+        hipFree(p);
+    }
+    hipFree(c->views_dev);
+    hipFree(c->planes);
+    hipFree(c->fit_planes);
+    hipFree(c->costs);
+    hipFree(c->rng);
+    hipFree(c->selected_views);
+    hipFree(c->view_weight);
+    hipFree(c->weak_info);
+    hipFree(c->weak_reliable);
+    hipFree(c->nearest_strong);
+    hipFree(c->neighbours_map);
+    hipFree(c->neighbours);
+    for (auto &pe : c->pending) {
+        hipEventDestroy(pe.start);
+        hipEventDestroy(pe.stop);
+    }
+    for (hipEvent_t e : c->event_pool) {
+        hipEventDestroy(e);
+    }
+    if (c->own_stream) {
+        hipStreamDestroy(c->stream);
+    }
+    delete c;
+    return APD_OK;
+}
+
+int apd_set_stream(apd_handle c, void *hip_stream)
+{
+    if (!c) {
+        return fail(APD_ERR_INVALID, "apd_set_stream: null handle");
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream) {
+        hipStreamDestroy(c->stream);
+    }
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return APD_OK;
+}
+
+int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, const float *const *images, const float *const *depths)
+{
+    if (!c || !cameras || !images || num_images < 2) {
+        return fail(APD_ERR_INVALID, "apd_upload_views: bad argument");
+    }
+    if (num_images > APD_MAX_IMAGES) {
+        return fail(APD_ERR_TOO_MANY, "Can't process so much images: %d", num_images);  // APD.cpp:428-431
+    }
+    if (c->params.geom_consistency && !depths) {
+        return fail(APD_ERR_INVALID, "apd_upload_views: geom_consistency needs depth maps");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->W * c->H;
+    for (float *p : c->images) {
+        hipFree(p);
+    }
+    for (float *p : c->depths) {
+        hipFree(p);
+    }
+    c->images.assign(num_images, nullptr);
+    c->depths.assign(num_images, nullptr);
+    for (int i = 0; i < num_images; ++i) {
+        if (cameras[i].width != c->W || cameras[i].height != c->H) {
+            return fail(APD_ERR_INVALID, "apd_upload_views: camera %d is %dx%d, handle is %dx%d", i, cameras[i].width, cameras[i].height,
+                        c->W, c->H);
+        }
+        HIP_TRY(hipMalloc(&c->images[i], n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(c->images[i], images[i], n * sizeof(float), hipMemcpyDefault, c->stream));
+        if (depths) {
+            HIP_TRY(hipMalloc(&c->depths[i], n * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(c->depths[i], depths[i], n * sizeof(float), hipMemcpyDefault, c->stream));
+        }
+    }
+    c->num_images = num_images;
+    c->params.num_images = num_images;
+    const apd_camera &ref = cameras[0];
+    FrameArgs &fa = c->fa;
+    memcpy(fa.K, ref.K, sizeof(fa.K));
+    memcpy(fa.R, ref.R, sizeof(fa.R));
+    memcpy(fa.t, ref.t, sizeof(fa.t));
+    memcpy(fa.c, ref.c, sizeof(fa.c));
+    fa.ifx = 1.0f / ref.K[0];
+    fa.ify = 1.0f / ref.K[4];
+    std::vector<ViewConst> vcs(num_images - 1);
+    for (int v = 0; v < num_images - 1; ++v) {
+        const apd_camera &src = cameras[v + 1];
+        ViewConst &vc = vcs[v];
+        memset(&vc, 0, sizeof(vc));
+        relative_pose(ref, src, vc.Rr, vc.tr);
+        vc.k0 = src.K[0];
+        vc.k2 = src.K[2];
+        vc.k4 = src.K[4];
+        vc.k5 = src.K[5];
+        vc.k8 = src.K[8];
+        vc.wf = (float)src.width;
+        vc.hf = (float)src.height;
+        memcpy(vc.K, src.K, sizeof(vc.K));
+        memcpy(vc.R, src.R, sizeof(vc.R));
+        memcpy(vc.t, src.t, sizeof(vc.t));
+        memcpy(vc.c, src.c, sizeof(vc.c));
+        vc.img = c->images[v + 1];
+        vc.depth = c->depths[v + 1];
+    }
+    HIP_TRY(hipMemcpyAsync(c->views_dev, vcs.data(), vcs.size() * sizeof(ViewConst), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->views_uploaded = true;
+    refresh_frame_args(c);
+    return APD_OK;
+}
+
+int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selected_views, const uint8_t *weak_info)
+{
+    if (!c) {
+        return fail(APD_ERR_INVALID, "apd_upload_prior: null handle");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->W * c->H;
+    if (planes4) {
+        HIP_TRY(hipMemcpyAsync(c->planes, planes4, n * sizeof(float4), hipMemcpyDefault, c->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->planes, 0, n * sizeof(float4), c->stream));
+    }
+    if (selected_views) {
+        HIP_TRY(hipMemcpyAsync(c->selected_views, selected_views, n * sizeof(uint32_t), hipMemcpyDefault, c->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->selected_views, 0, n * sizeof(uint32_t), c->stream));
+    }
+    c->weak_count = 0;
+    if (weak_info) {
+        // weak index map of APD.cpp:526-537 (row-major running count of WEAK pixels)
+        std::vector<uint8_t> wi(n);
+        HIP_TRY(hipMemcpy(wi.data(), weak_info, n, hipMemcpyDefault));
+        std::vector<int> map(n, 0);
+        int count = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (wi[i] == APD_WEAK) {
+                map[i] = count++;
+            }
+        }
+        c->weak_count = count;
+        HIP_TRY(hipMemcpyAsync(c->weak_info, wi.data(), n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->neighbours_map, map.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->weak_info, APD_STRONG, n, c->stream));
+        HIP_TRY(hipMemsetAsync(c->neighbours_map, 0, n * sizeof(int), c->stream));
+    }
+    const size_t need = (size_t)(c->weak_count > 0 ? c->weak_count : 1);
+    if (need > c->neighbours_cap) {
+        hipFree(c->neighbours);
+        HIP_TRY(hipMalloc(&c->neighbours, need * APD_NEIGHBOUR_NUM * sizeof(short2)));
+        c->neighbours_cap = need;
+    }
+    HIP_TRY(hipMemsetAsync(c->fit_planes, 0, n * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->view_weight, 0, n * APD_MAX_IMAGES, c->stream));
+    HIP_TRY(hipMemsetAsync(c->weak_reliable, 0, n, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->prior_uploaded = true;
+    refresh_frame_args(c);
+    return APD_OK;
+}
+
+static hipEvent_t take_event(apd_context *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+static void drain_profile(apd_context *c)
+{
+    for (auto &pe : c->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+            c->prof_ms[pe.kernel] += (double)ms;
+            c->prof_launches[pe.kernel] += 1;
+        }
+        c->event_pool.push_back(pe.start);
+        c->event_pool.push_back(pe.stop);
+    }
+    c->pending.clear();
+}
+
+static int launch_one(apd_context *c, int kernel_id, int iter)
+{
+    apd_context::PendingEvent pe{kernel_id, nullptr, nullptr};
+    if (c->profiling) {
+        pe.start = take_event(c);
+        pe.stop = take_event(c);
+        HIP_TRY(hipEventRecord(pe.start, c->stream));
+    }
+    hipError_t e;
+    switch (kernel_id) {
+    case APD_K2_FIND_NEAREST_STRONG:
+    case APD_K3_GEN_NEIGHBOURS:
+    case APD_K4_NEIGHBOUR_UPDATE:
+    case APD_K8_RANSAC_FIT_PLANE:
+    case APD_K9_BLACK_UPDATE_WEAK:
+    case APD_K10_RED_UPDATE_WEAK:
+        e = apd::launch_weak_kernel(c->fa, kernel_id, iter, c->stream);
+        break;
+    default:
+        e = apd::launch_kernel(c->fa, kernel_id, iter, c->stream);
+        break;
+    }
+    if (e != hipSuccess) {
+        return fail(APD_ERR_HIP, "launch of kernel %d failed: %s", kernel_id, hipGetErrorString(e));
+    }
+    if (c->profiling) {
+        HIP_TRY(hipEventRecord(pe.stop, c->stream));
+        c->pending.push_back(pe);
+    }
+    return APD_OK;
+}
+
+static int check_ready(apd_context *c, const char *who)
+{
+    if (!c) {
+        return fail(APD_ERR_INVALID, "%s: null handle", who);
+    }
+    if (!c->views_uploaded) {
+        return fail(APD_ERR_STATE, "%s: apd_upload_views has not been called", who);
+    }
+    if (c->params.state != APD_FIRST_INIT && !c->prior_uploaded) {
+        return fail(APD_ERR_STATE, "%s: state != FIRST_INIT needs apd_upload_prior", who);
+    }
+    if (hipSetDevice(c->device) != hipSuccess) {
+        return fail(APD_ERR_HIP, "%s: hipSetDevice failed", who);
+    }
+    return APD_OK;
+}
+
+int apd_run_kernel(apd_handle c, int kernel_id, int iter)
+{
+    int rc = check_ready(c, "apd_run_kernel");
+    if (rc) {
+        return rc;
+    }
+    if (kernel_id < 1 || kernel_id >= APD_KERNEL_COUNT) {
+        return fail(APD_ERR_INVALID, "apd_run_kernel: unknown kernel %d", kernel_id);
+    }
+    return launch_one(c, kernel_id, iter);
+}
+
+int apd_run_sweeps(apd_handle c, int first_iter, int iters)
+{
+    int rc = check_ready(c, "apd_run_sweeps");
+    if (rc) {
+        return rc;
+    }
+    for (int i = first_iter; i < first_iter + iters; ++i) {  // APD.cu:2443-2457
+        if ((rc = launch_one(c, APD_K6_BLACK_UPDATE_STRONG, i))) return rc;
+        if ((rc = launch_one(c, APD_K7_RED_UPDATE_STRONG, i))) return rc;
+        if ((rc = launch_one(c, APD_K8_RANSAC_FIT_PLANE, i))) return rc;
+        if (c->weak_count > 0) {  // no WEAK pixel -> K9/K10 would retire every lane at once
+            if ((rc = launch_one(c, APD_K9_BLACK_UPDATE_WEAK, i))) return rc;
+            if ((rc = launch_one(c, APD_K10_RED_UPDATE_WEAK, i))) return rc;
+        }
+    }
+    return APD_OK;
+}
+
+int apd_run(apd_handle c)
+{
+    int rc = check_ready(c, "apd_run");
+    if (rc) {
+        return rc;
+    }
+    // schedule of APD::RunPatchMatch, APD.cu:2409-2471
+    if ((rc = launch_one(c, APD_K1_INIT_RANDOM_STATES, 0))) return rc;
+    if ((rc = launch_one(c, APD_K2_FIND_NEAREST_STRONG, 0))) return rc;
+    if (c->weak_count > 0) {
+        if ((rc = launch_one(c, APD_K3_GEN_NEIGHBOURS, 0))) return rc;
+        if ((rc = launch_one(c, APD_K4_NEIGHBOUR_UPDATE, 0))) return rc;
+    }
+    if ((rc = launch_one(c, APD_K5_RANDOM_INITIALIZATION, 0))) return rc;
+    if ((rc = apd_run_sweeps(c, 0, c->params.max_iterations))) return rc;
+    if ((rc = launch_one(c, APD_K11_GET_DEPTH_NORMAL, 0))) return rc;
+    if ((rc = launch_one(c, APD_K12_BLACK_FILTER, 0))) return rc;
+    if ((rc = launch_one(c, APD_K13_RED_FILTER, 0))) return rc;
+    if ((rc = launch_one(c, APD_K14_DEPTH_TO_WEAK, 0))) return rc;
+    if ((rc = launch_one(c, APD_K15_LOCAL_REFINE, 0))) return rc;
+    return APD_OK;
+}
+
+int apd_synchronize(apd_handle c)
+{
+    if (!c) {
+        return fail(APD_ERR_INVALID, "apd_synchronize: null handle");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drain_profile(c);
+    return APD_OK;
+}
+
+int apd_download(apd_handle c, float *planes4, uint8_t *weak_info, uint32_t *selected_views)
+{
+    if (!c) {
+        return fail(APD_ERR_INVALID, "apd_download: null handle");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->W * c->H;
+    // APD.cu:2490-2492
+    if (planes4) {
+        HIP_TRY(hipMemcpyAsync(planes4, c->planes, n * sizeof(float4), hipMemcpyDefault, c->stream));
+    }
+    if (weak_info) {
+        HIP_TRY(hipMemcpyAsync(weak_info, c->weak_info, n, hipMemcpyDefault, c->stream));
+    }
+    if (selected_views) {
+        HIP_TRY(hipMemcpyAsync(selected_views, c->selected_views, n * sizeof(uint32_t), hipMemcpyDefault, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drain_profile(c);
+    return APD_OK;
+}
+
+static void *state_ptr(apd_context *c, int which, size_t *bytes)
+{
+    const size_t n = (size_t)c->W * c->H;
+    switch (which) {
+    case APD_STATE_PLANES: *bytes = n * 16; return c->planes;
+    case APD_STATE_FIT_PLANES: *bytes = n * 16; return c->fit_planes;
+    case APD_STATE_COSTS: *bytes = n * 4; return c->costs;
+    case APD_STATE_RNG: *bytes = n * 24; return c->rng;
+    case APD_STATE_SELECTED_VIEWS: *bytes = n * 4; return c->selected_views;
+    case APD_STATE_VIEW_WEIGHT: *bytes = n * 32; return c->view_weight;
+    case APD_STATE_WEAK_INFO: *bytes = n; return c->weak_info;
+    case APD_STATE_WEAK_RELIABLE: *bytes = n; return c->weak_reliable;
+    case APD_STATE_NEAREST_STRONG: *bytes = n * 4; return c->nearest_strong;
+    case APD_STATE_NEIGHBOURS_MAP: *bytes = n * 4; return c->neighbours_map;
+    case APD_STATE_NEIGHBOURS: *bytes = (size_t)(c->weak_count > 0 ? c->weak_count : 1) * APD_NEIGHBOUR_NUM * 4; return c->neighbours;
+    default: *bytes = 0; return nullptr;
+    }
+}
+
+size_t apd_state_bytes(apd_handle c, int which)
+{
+    size_t b = 0;
+    if (c) {
+        state_ptr(c, which, &b);
+    }
+    return b;
+}
+
+int apd_download_state(apd_handle c, int which, void *dst, size_t bytes)
+{
+    if (!c || !dst) {
+        return fail(APD_ERR_INVALID, "apd_download_state: bad argument");
+    }
+    size_t cap = 0;
+    void *src = state_ptr(c, which, &cap);
+    if (!src || bytes > cap) {
+        return fail(APD_ERR_INVALID, "apd_download_state: state %d has %zu bytes, asked for %zu", which, cap, bytes);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drain_profile(c);
+    return APD_OK;
+}
+
+int apd_upload_state(apd_handle c, int which, const void *src, size_t bytes)
+{
+    if (!c || !src) {
+        return fail(APD_ERR_INVALID, "apd_upload_state: bad argument");
+    }
+    size_t cap = 0;
+    void *dst = state_ptr(c, which, &cap);
+    if (!dst || bytes > cap) {
+        return fail(APD_ERR_INVALID, "apd_upload_state: state %d has %zu bytes, got %zu", which, cap, bytes);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return APD_OK;
+}
+
+int apd_export_depth_normal_device(apd_handle c, float *depth_dev, float *normal_dev)
+{
+    if (!c || !depth_dev) {
+        return fail(APD_ERR_INVALID, "apd_export_depth_normal_device: bad argument");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = apd::launch_export_depth_normal(c->fa, depth_dev, normal_dev, c->stream);
+    if (e != hipSuccess) {
+        return fail(APD_ERR_HIP, "export kernel failed: %s", hipGetErrorString(e));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return APD_OK;
+}
+
+int apd_width(apd_handle c) { return c ? c->W : 0; }
+int apd_height(apd_handle c) { return c ? c->H : 0; }
+float apd_depth_min(apd_handle c) { return c ? c->params.depth_min : 0.0f; }
+float apd_depth_max(apd_handle c) { return c ? c->params.depth_max : 0.0f; }
+int apd_weak_count(apd_handle c) { return c ? c->weak_count : 0; }
+
+int apd_profile_enable(apd_handle c, int on)
+{
+    if (!c) {
+        return fail(APD_ERR_INVALID, "apd_profile_enable: null handle");
+    }
+    c->profiling = on != 0;
+    return APD_OK;
+}
+
+int apd_profile_reset(apd_handle c)
+{
+    if (!c) {
+        return fail(APD_ERR_INVALID, "apd_profile_reset: null handle");
+    }
+    hipStreamSynchronize(c->stream);
+    drain_profile(c);
+    memset(c->prof_ms, 0, sizeof(c->prof_ms));
+    memset(c->prof_launches, 0, sizeof(c->prof_launches));
+    return APD_OK;
+}
+
+int apd_profile_get(apd_handle c, int kernel_id, double *total_ms, int *launches)
+{
+    if (!c || kernel_id < 0 || kernel_id >= APD_KERNEL_COUNT) {
+        return fail(APD_ERR_INVALID, "apd_profile_get: bad argument");
+    }
+    if (total_ms) {
+        *total_ms = c->prof_ms[kernel_id];
+    }
+    if (launches) {
+        *launches = c->prof_launches[kernel_id];
+    }
+    return APD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,604 @@
+// apd_device.h -- device-side data model and arithmetic of the MI355X PatchMatch path.
+//
+// Written for gfx950 only (wave64, no texture unit: bilinear sampling is explicit global loads).
+// Build flags that are part of the contract: -ffp-contract=off, no fast-math (the algorithm relies
+// on NaN comparisons being false, APD.cu:149 / SURVEY Appendix A #9).  fmaf() appears exactly where
+// DESIGN.md's arithmetic contract says; everything else is literal IEEE binary32.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/apd_mi355x.h"
+
+namespace apd {
+
+// ------------------------------------------------------------------------------------------------
+// data model
+// ------------------------------------------------------------------------------------------------
+
+// Per source view constants.  Rr/tr are the plane-independent part of ComputeHomography
+// (APD.cu:305-331) hoisted to the host once per (reference, source) pair; the kernels read them
+// through wave-uniform (scalar) loads.
+struct ViewConst {
+    float Rr[9];       // R_src * R_ref^T
+    float tr[3];       // R_src * (C_ref - C_src)
+    float k0, k2, k4, k5, k8;  // source intrinsics used by :354-362
+    float wf, hf;      // (float)width, (float)height of the source camera (centre test :546)
+    float K[9];        // full source camera for the geometric term (:740-750)
+    float R[9];
+    float t[3];
+    float c[3];
+    const float *img;    // W*H floats
+    const float *depth;  // W*H floats or nullptr
+};
+
+struct FrameArgs {
+    int W, H;
+    int num_src;       // num_images - 1
+    int half_rows;     // rows reachable by the reference HALF launch: 2*ceil((H/2)/16)*16 (APD.cu:2402)
+    // params (main.h:75-94)
+    int top_k;
+    float depth_min, depth_max;
+    int geom_consistency;
+    int weak_peak_radius;
+    int rotate_time;
+    float ransac_threshold;
+    float geom_factor;
+    int state;
+    unsigned long long seed;
+    // K3 constants evaluated on the host in double (APD.cu:1791-1795)
+    float k3_cos_angle, k3_sin_angle, k3_cone;
+    int k3_shift_range;
+    // reference camera
+    float K[9], R[9], t[3], c[3];
+    float ifx, ify;    // correctly rounded 1/K[0], 1/K[4]
+    // state
+    const float *ref_img;
+    const ViewConst *views;  // [num_src], view v == source image v+1
+    float4 *planes;
+    float4 *fit_planes;
+    float *costs;
+    uint32_t *rng;           // 6 words per pixel
+    uint32_t *selected_views;
+    uint8_t *view_weight;    // 32 per pixel
+    uint8_t *weak_info;
+    uint8_t *weak_reliable;
+    short2 *nearest_strong;
+    const int *neighbours_map;
+    short2 *neighbours;      // 9 per weak pixel
+};
+
+// ------------------------------------------------------------------------------------------------
+// polynomial kernels (contract C5) -- same coefficients and operation order as the oracle
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float sin_poly(float x)
+{
+    const float z = x * x;
+    float p = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    p = fmaf(p, z, -1.6666654611e-1f);
+    return fmaf(p * z, x, x);
+}
+
+__device__ __forceinline__ float cos_poly(float x)
+{
+    const float z = x * x;
+    float p = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    p = fmaf(p, z, 4.166664568298827e-2f);
+    return fmaf(p * z, z, fmaf(-0.5f, z, 1.0f));
+}
+
+__device__ __forceinline__ float exp_poly(float x)
+{
+    if (!(x > -87.0f)) {
+        return (x != x) ? x : 0.0f;
+    }
+    if (x > 88.0f) {
+        return __builtin_inff();
+    }
+    const float n = floorf(fmaf(x, 1.44269504088896341f, 0.5f));
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    p = fmaf(p, r * r, r) + 1.0f;
+    return p * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+
+__device__ __forceinline__ float rsqrt_c4(float x) { return 1.0f / sqrtf(x); }
+
+// ------------------------------------------------------------------------------------------------
+// XORWOW (contract C8): state kept in six registers; AoS of 6 words per pixel in HBM
+// ------------------------------------------------------------------------------------------------
+
+struct Rng {
+    uint32_t x0, x1, x2, x3, x4, d;
+};
+
+__device__ __forceinline__ Rng rng_load(const uint32_t *base, int center)
+{
+    const uint2 *p = reinterpret_cast<const uint2 *>(base + 6 * (size_t)center);
+    const uint2 a = p[0], b = p[1], c = p[2];
+    return Rng{a.x, a.y, b.x, b.y, c.x, c.y};
+}
+
+__device__ __forceinline__ void rng_store(uint32_t *base, int center, const Rng &r)
+{
+    uint2 *p = reinterpret_cast<uint2 *>(base + 6 * (size_t)center);
+    p[0] = make_uint2(r.x0, r.x1);
+    p[1] = make_uint2(r.x2, r.x3);
+    p[2] = make_uint2(r.x4, r.d);
+}
+
+__device__ __forceinline__ uint32_t rng_next(Rng &r)
+{
+    const uint32_t t = r.x0 ^ (r.x0 >> 2);
+    r.x0 = r.x1;
+    r.x1 = r.x2;
+    r.x2 = r.x3;
+    r.x3 = r.x4;
+    r.x4 = (r.x4 ^ (r.x4 << 4)) ^ (t ^ (t << 1));
+    r.d += 362437u;
+    return r.d + r.x4;
+}
+
+__device__ __forceinline__ float rng_uniform(Rng &r)
+{
+    const float v = (float)rng_next(r);
+    return 2.3283064e-10f + (v * 2.3283064e-10f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int bit_test(uint32_t v, unsigned n) { return (int)((v >> n) & 1u); }
+// APD.cu:47-50: clears bit n and every lower bit (reference behaviour, kept).
+__device__ __forceinline__ uint32_t bit_unset_quirk(uint32_t v, unsigned n) { return v & (uint32_t)(0xFFFFFFFEu << n); }
+
+__device__ __forceinline__ bool inside(const FrameArgs &fa, int x, int y)
+{
+    return x >= 0 && y >= 0 && x < fa.W && y < fa.H;
+}
+
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z)
+{
+    const float n2 = x * x + y * y + z * z;
+    const float inv = rsqrt_c4(n2);
+    x *= inv;
+    y *= inv;
+    z *= inv;
+}
+
+__device__ __forceinline__ void normalize2(float &x, float &y)
+{
+    const float n2 = x * x + y * y;
+    const float inv = rsqrt_c4(n2);
+    x *= inv;
+    y *= inv;
+}
+
+// Get3DPoint (APD.cu:159-171) in the reference camera
+__device__ __forceinline__ void point3d(const FrameArgs &fa, int px, int py, float depth, float &X, float &Y, float &Z)
+{
+    X = depth * ((float)px - fa.K[2]) / fa.K[0];
+    Y = depth * ((float)py - fa.K[5]) / fa.K[4];
+    Z = depth;
+}
+
+// GetViewDirection (APD.cu:173-185)
+__device__ __forceinline__ void view_direction(const FrameArgs &fa, int px, int py, float depth, float &vx, float &vy, float &vz)
+{
+    float X, Y, Z;
+    point3d(fa, px, py, depth, X, Y, Z);
+    const float norm = sqrtf(X * X + Y * Y + Z * Z);
+    vx = X / norm;
+    vy = Y / norm;
+    vz = Z / norm;
+}
+
+// GetDistance2Origin (APD.cu:187-192)
+__device__ __forceinline__ float distance_to_origin(const FrameArgs &fa, int px, int py, float depth, float nx, float ny, float nz)
+{
+    float X, Y, Z;
+    point3d(fa, px, py, depth, X, Y, Z);
+    return -(nx * X + ny * Y + nz * Z);
+}
+
+// ComputeDepthfromPlaneHypothesis (APD.cu:206-209)
+__device__ __forceinline__ float depth_from_plane(const FrameArgs &fa, const float4 pl, int px, int py)
+{
+    return -pl.w * fa.K[0] /
+           (((float)px - fa.K[2]) * pl.x + (fa.K[0] / fa.K[4]) * ((float)py - fa.K[5]) * pl.y + fa.K[0] * pl.z);
+}
+
+// TransformNormal (APD.cu:374-382): camera -> world
+__device__ __forceinline__ float4 normal_cam_to_world(const FrameArgs &fa, const float4 p)
+{
+    float4 o;
+    o.x = fa.R[0] * p.x + fa.R[3] * p.y + fa.R[6] * p.z;
+    o.y = fa.R[1] * p.x + fa.R[4] * p.y + fa.R[7] * p.z;
+    o.z = fa.R[2] * p.x + fa.R[5] * p.y + fa.R[8] * p.z;
+    o.w = p.w;
+    return o;
+}
+
+// TransformNormal2RefCam (APD.cu:384-392): world -> camera
+__device__ __forceinline__ float4 normal_world_to_cam(const FrameArgs &fa, const float4 p)
+{
+    float4 o;
+    o.x = fa.R[0] * p.x + fa.R[1] * p.y + fa.R[2] * p.z;
+    o.y = fa.R[3] * p.x + fa.R[4] * p.y + fa.R[5] * p.z;
+    o.z = fa.R[6] * p.x + fa.R[7] * p.y + fa.R[8] * p.z;
+    o.w = p.w;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hypothesis generation (APD.cu:211-282)
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float4 random_normal(const FrameArgs &fa, int px, int py, Rng &rng, float depth)
+{
+    float q1 = 1.0f, q2 = 1.0f, s = 2.0f;
+    while (s >= 1.0f) {
+        q1 = 2.0f * rng_uniform(rng) - 1.0f;
+        q2 = 2.0f * rng_uniform(rng) - 1.0f;
+        s = q1 * q1 + q2 * q2;
+    }
+    const float sq = sqrtf(1.0f - s);
+    float nx = 2.0f * q1 * sq;
+    float ny = 2.0f * q2 * sq;
+    float nz = 1.0f - 2.0f * s;
+    float vx, vy, vz;
+    view_direction(fa, px, py, depth, vx, vy, vz);
+    const float dot = nx * vx + ny * vy + nz * vz;
+    if (dot > 0.0f) {
+        nx = -nx;
+        ny = -ny;
+        nz = -nz;
+    }
+    normalize3(nx, ny, nz);
+    return make_float4(nx, ny, nz, 0.0f);
+}
+
+__device__ __forceinline__ float4 perturbed_normal(const FrameArgs &fa, int px, int py, const float4 normal, Rng &rng, float perturbation)
+{
+    float vx, vy, vz;
+    view_direction(fa, px, py, 1.0f, vx, vy, vz);
+    const float a1 = (rng_uniform(rng) - 0.5f) * perturbation;
+    const float a2 = (rng_uniform(rng) - 0.5f) * perturbation;
+    const float a3 = (rng_uniform(rng) - 0.5f) * perturbation;
+    const float s1 = sin_poly(a1), s2 = sin_poly(a2), s3 = sin_poly(a3);
+    const float c1 = cos_poly(a1), c2 = cos_poly(a2), c3 = cos_poly(a3);
+    const float R0 = c2 * c3;
+    const float R1 = c3 * s1 * s2 - c1 * s3;
+    const float R2 = s1 * s3 + c1 * c3 * s2;
+    const float R3 = c2 * s3;
+    const float R4 = c1 * c3 + s1 * s2 * s3;
+    const float R5 = c1 * s2 * s3 - c3 * s1;
+    const float R6 = -s2;
+    const float R7 = c2 * s1;
+    const float R8 = c1 * c2;
+    float4 p;
+    p.x = R0 * normal.x + R1 * normal.y + R2 * normal.z;
+    p.y = R3 * normal.x + R4 * normal.y + R5 * normal.z;
+    p.z = R6 * normal.x + R7 * normal.y + R8 * normal.z;
+    p.w = 0.0f;
+    if (p.x * vx + p.y * vy + p.z * vz >= 0.0f) {
+        p = normal;
+    }
+    normalize3(p.x, p.y, p.z);
+    return p;
+}
+
+__device__ __forceinline__ float4 random_plane(const FrameArgs &fa, int px, int py, Rng &rng)
+{
+    const float depth = rng_uniform(rng) * (fa.depth_max - fa.depth_min) + fa.depth_min;
+    float4 pl = random_normal(fa, px, py, rng, depth);
+    pl.w = distance_to_origin(fa, px, py, depth, pl.x, pl.y, pl.z);
+    return pl;
+}
+
+// ------------------------------------------------------------------------------------------------
+// homography (APD.cu:333-362 on top of the hoisted relative pose), contract C2/C3
+// ------------------------------------------------------------------------------------------------
+
+struct Homography {
+    float h[9];
+};
+
+// q = n / d of the plane hypothesis (three multiplies by a correctly rounded 1/d)
+__device__ __forceinline__ void plane_q(const float4 pl, float &qx, float &qy, float &qz)
+{
+    const float inv_w = 1.0f / pl.w;
+    qx = pl.x * inv_w;
+    qy = pl.y * inv_w;
+    qz = pl.z * inv_w;
+}
+
+__device__ __forceinline__ Homography make_homography(const FrameArgs &fa, const ViewConst &vc, float qx, float qy, float qz)
+{
+    Homography o;
+    float T[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float m0 = fmaf(-vc.tr[r], qx, vc.Rr[3 * r + 0]);
+        const float m1 = fmaf(-vc.tr[r], qy, vc.Rr[3 * r + 1]);
+        const float m2 = fmaf(-vc.tr[r], qz, vc.Rr[3 * r + 2]);
+        T[3 * r + 0] = m0 * fa.ifx;
+        T[3 * r + 1] = m1 * fa.ify;
+        T[3 * r + 2] = fmaf(-T[3 * r + 1], fa.K[5], fmaf(-T[3 * r + 0], fa.K[2], m2));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o.h[0 + c] = fmaf(vc.k2, T[6 + c], vc.k0 * T[0 + c]);
+        o.h[3 + c] = fmaf(vc.k5, T[6 + c], vc.k4 * T[3 + c]);
+        o.h[6 + c] = vc.k8 * T[6 + c];
+    }
+    return o;
+}
+
+// ComputeCorrespondingPoint (APD.cu:365-372)
+__device__ __forceinline__ void correspond(const Homography &H, float xf, float yf, float &ox, float &oy)
+{
+    const float X = fmaf(H.h[1], yf, fmaf(H.h[0], xf, H.h[2]));
+    const float Y = fmaf(H.h[4], yf, fmaf(H.h[3], xf, H.h[5]));
+    const float Z = fmaf(H.h[7], yf, fmaf(H.h[6], xf, H.h[8]));
+    const float inv = 1.0f / Z;
+    ox = X * inv;
+    oy = Y * inv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler (contract C7): software replacement of tex2D(linear, clamp); gfx950 has no texture path
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+__device__ __forceinline__ float fetch_texel(const float *__restrict__ img, int W, int H, int x, int y)
+{
+    return img[(unsigned)(clampi(y, 0, H - 1) * W + clampi(x, 0, W - 1))];
+}
+
+__device__ __forceinline__ float sample_bilinear(const float *__restrict__ img, int W, int H, float sx, float sy)
+{
+    const float fx = floorf(sx), fy = floorf(sy);
+    const float a = sx - fx, b = sy - fy;
+    const int x0 = (int)fminf(fmaxf(fx, -1.0f), (float)W);
+    const int y0 = (int)fminf(fmaxf(fy, -1.0f), (float)H);
+    const int xa = clampi(x0, 0, W - 1), xb = min(x0 + 1, W - 1);
+    const int ya = clampi(y0, 0, H - 1), yb = min(y0 + 1, H - 1);
+    const unsigned ra = (unsigned)__mul24(ya, W), rb = (unsigned)__mul24(yb, W);
+    const float t00 = img[ra + (unsigned)xa], t10 = img[ra + (unsigned)xb];
+    const float t01 = img[rb + (unsigned)xa], t11 = img[rb + (unsigned)xb];
+    const float top = fmaf(a, t10 - t00, t00);
+    const float bot = fmaf(a, t11 - t01, t01);
+    return fmaf(b, bot - top, top);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed 6x6 patch (strong_radius 5, strong_increment 2): the hot NCC of APD.cu:530-614
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kPatchN = 6;       // samples per axis: offsets -5,-3,-1,1,3,5
+constexpr int kPatchRadius = 5;
+constexpr int kPatchStep = 2;
+
+// Reference side of the patch: depends on the pixel only, reused by every hypothesis and view.
+struct RefPatch {
+    float v[kPatchN * kPatchN];  // v[i*6+j]: x offset index i (outer loop), y offset index j
+    float mean;                  // sum_ref / 36
+    float var;                   // sum_ref_ref/36 - mean^2
+};
+
+__device__ __forceinline__ void ref_patch_finish(RefPatch &rp)
+{
+    float sum_r = 0.0f, sum_rr = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kPatchN; ++i) {
+        float row_r = 0.0f, row_rr = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            const float r = rp.v[i * kPatchN + j];
+            row_r += r;
+            row_rr = fmaf(r, r, row_rr);
+        }
+        sum_r += row_r;
+        sum_rr += row_rr;
+    }
+    const float inv_w = 1.0f / 36.0f;
+    sum_r *= inv_w;
+    sum_rr *= inv_w;
+    rp.mean = sum_r;
+    rp.var = fmaf(-sum_r, sum_r, sum_rr);
+}
+
+__device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float *__restrict__ img, int W, int H, int px, int py)
+{
+#pragma unroll
+    for (int i = 0; i < kPatchN; ++i) {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            rp.v[i * kPatchN + j] = fetch_texel(img, W, H, px + kPatchStep * i - kPatchRadius, py + kPatchStep * j - kPatchRadius);
+        }
+    }
+    ref_patch_finish(rp);
+}
+
+// ComputeBilateralNCCOld for plane q = n/d against source view vc.
+__device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, int px, int py,
+                                           float qx, float qy, float qz)
+{
+    const Homography H = make_homography(fa, vc, qx, qy, qz);
+    float cx, cy;
+    correspond(H, (float)px, (float)py, cx, cy);
+    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
+        return 2.0f;
+    }
+    const float kMinVar = 1e-5f;
+    if (rp.var < kMinVar) {
+        return 2.0f;  // the reference tests this after sampling; the result is the same
+    }
+    const float *__restrict__ src = vc.img;
+    const int W = fa.W, Hh = fa.H;
+    float sum_s = 0.0f, sum_ss = 0.0f, sum_rs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kPatchN; ++i) {
+        const float xf = (float)(px + kPatchStep * i - kPatchRadius);
+        const float bx = fmaf(H.h[0], xf, H.h[2]);
+        const float by = fmaf(H.h[3], xf, H.h[5]);
+        const float bz = fmaf(H.h[6], xf, H.h[8]);
+        float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            const float yf = (float)(py + kPatchStep * j - kPatchRadius);
+            const float inv = 1.0f / fmaf(H.h[7], yf, bz);
+            const float sx = fmaf(H.h[1], yf, bx) * inv;
+            const float sy = fmaf(H.h[4], yf, by) * inv;
+            const float v = sample_bilinear(src, W, Hh, sx, sy);
+            row_s += v;
+            row_ss = fmaf(v, v, row_ss);
+            row_rs = fmaf(rp.v[i * kPatchN + j], v, row_rs);
+        }
+        sum_s += row_s;
+        sum_ss += row_ss;
+        sum_rs += row_rs;
+    }
+    const float inv_w = 1.0f / 36.0f;
+    sum_s *= inv_w;
+    sum_ss *= inv_w;
+    sum_rs *= inv_w;
+    const float var_s = fmaf(-sum_s, sum_s, sum_ss);
+    if (var_s < kMinVar) {
+        return 2.0f;
+    }
+    const float covar = fmaf(-rp.mean, sum_s, sum_rs);
+    const float denom = sqrtf(rp.var * var_s);
+    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+}
+
+// Generic patch (any centre / radius / increment): sub-patches of ComputeBilateralNCCNew
+// (APD.cu:461-505).  Not hot: only WEAK pixels take this path.
+__device__ __forceinline__ float patch_cost_generic(const FrameArgs &fa, const ViewConst &vc, const Homography &H, int cx, int cy,
+                                                    int radius, int increment)
+{
+    const float *__restrict__ ref = fa.ref_img;
+    const float *__restrict__ src = vc.img;
+    const int W = fa.W, Hh = fa.H;
+    float sum_r = 0.0f, sum_rr = 0.0f, sum_s = 0.0f, sum_ss = 0.0f, sum_rs = 0.0f, wsum = 0.0f;
+    for (int i = -radius; i <= radius; i += increment) {
+        float row_r = 0.0f, row_rr = 0.0f, row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f, row_w = 0.0f;
+        const float xf = (float)(cx + i);
+        const float bx = fmaf(H.h[0], xf, H.h[2]);
+        const float by = fmaf(H.h[3], xf, H.h[5]);
+        const float bz = fmaf(H.h[6], xf, H.h[8]);
+        for (int j = -radius; j <= radius; j += increment) {
+            const float r = fetch_texel(ref, W, Hh, cx + i, cy + j);
+            const float yf = (float)(cy + j);
+            const float inv = 1.0f / fmaf(H.h[7], yf, bz);
+            const float sx = fmaf(H.h[1], yf, bx) * inv;
+            const float sy = fmaf(H.h[4], yf, by) * inv;
+            const float v = sample_bilinear(src, W, Hh, sx, sy);
+            row_r += r;
+            row_rr = fmaf(r, r, row_rr);
+            row_s += v;
+            row_ss = fmaf(v, v, row_ss);
+            row_rs = fmaf(r, v, row_rs);
+            row_w += 1.0f;
+        }
+        sum_r += row_r;
+        sum_rr += row_rr;
+        sum_s += row_s;
+        sum_ss += row_ss;
+        sum_rs += row_rs;
+        wsum += row_w;
+    }
+    const float inv_w = 1.0f / wsum;
+    sum_r *= inv_w;
+    sum_rr *= inv_w;
+    sum_s *= inv_w;
+    sum_ss *= inv_w;
+    sum_rs *= inv_w;
+    const float var_r = fmaf(-sum_r, sum_r, sum_rr);
+    const float var_s = fmaf(-sum_s, sum_s, sum_ss);
+    const float kMinVar = 1e-5f;
+    if (var_r < kMinVar || var_s < kMinVar) {
+        return 2.0f;
+    }
+    const float covar = fmaf(-sum_r, sum_s, sum_rs);
+    const float denom = sqrtf(var_r * var_s);
+    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometric consistency (APD.cu:718-789)
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void backproject_world(float x, float y, float depth, const float *K, const float *R, const float *c,
+                                                  float &Px, float &Py, float &Pz)
+{
+    const float X = depth * (x - K[2]) / K[0];
+    const float Y = depth * (y - K[5]) / K[4];
+    const float Z = depth;
+    const float tx = R[0] * X + R[3] * Y + R[6] * Z;
+    const float ty = R[1] * X + R[4] * Y + R[7] * Z;
+    const float tz = R[2] * X + R[5] * Y + R[8] * Z;
+    Px = tx + c[0];
+    Py = ty + c[1];
+    Pz = tz + c[2];
+}
+
+__device__ __forceinline__ void project_camera(float Px, float Py, float Pz, const float *K, const float *R, const float *t,
+                                               float &u, float &v, float &depth)
+{
+    const float tx = R[0] * Px + R[1] * Py + R[2] * Pz + t[0];
+    const float ty = R[3] * Px + R[4] * Py + R[5] * Pz + t[1];
+    const float tz = R[6] * Px + R[7] * Py + R[8] * Pz + t[2];
+    depth = K[6] * tx + K[7] * ty + K[8] * tz;
+    u = (K[0] * tx + K[1] * ty + K[2] * tz) / depth;
+    v = (K[3] * tx + K[4] * ty + K[5] * tz) / depth;
+}
+
+__device__ __forceinline__ float geom_cost(const FrameArgs &fa, const ViewConst &vc, int px, int py, const float4 pl)
+{
+    const float max_cost = 3.0f;
+    const float depth = depth_from_plane(fa, pl, px, py);
+    float Fx, Fy, Fz;
+    backproject_world((float)px, (float)py, depth, fa.K, fa.R, fa.c, Fx, Fy, Fz);
+    float su, sv, sd;
+    project_camera(Fx, Fy, Fz, vc.K, vc.R, vc.t, su, sv, sd);
+    const int ix = (int)fminf(fmaxf(su, -1.0f), (float)fa.W);
+    const int iy = (int)fminf(fmaxf(sv, -1.0f), (float)fa.H);
+    const float src_depth = fetch_texel(vc.depth, fa.W, fa.H, ix, iy);
+    if (src_depth == 0.0f) {
+        return max_cost;
+    }
+    float Px, Py, Pz;
+    backproject_world(su, sv, src_depth, vc.K, vc.R, vc.c, Px, Py, Pz);
+    float bu, bv, bd;
+    project_camera(Px, Py, Pz, fa.K, fa.R, fa.t, bu, bv, bd);
+    const float dc = (float)px - bu;
+    const float dr = (float)py - bv;
+    return fminf(max_cost, sqrtf(dc * dc + dr * dr));
+}
+
+// ------------------------------------------------------------------------------------------------
+// misc
+// ------------------------------------------------------------------------------------------------
+
+// XCD-aware remap of a linear workgroup id: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md),
+// so give each XCD one contiguous band of tiles and its private L2 one band of every image.
+__device__ __forceinline__ int xcd_band_tile(int b, int ntiles)
+{
+    const int xcd = b & 7, slot = b >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+}  // namespace apd

@@ -1,0 +1,727 @@
+// apd_kernels_weak.hip -- adaptive-patch-deformation kernels (the "APD" of APD-MVS) for gfx950:
+// K2 FindNearestStrongPoint, K3 GenNeighbours, K4 NeigbourUpdate, K8 RANSACToGetFitPlane,
+// K9/K10 Black/RedPixelUpdateWeak, plus the depth/normal export used before the RCCL all-gather.
+#include "apd_device.h"
+#include "apd_sweep.h"
+
+#include <float.h>
+
+namespace apd {
+
+// ------------------------------------------------------------------------------------------------
+// K2  FindNearestStrongPoint (APD.cu:2234-2270)
+// ------------------------------------------------------------------------------------------------
+
+// The reference probes the 201x201 window column by column (x outer, y inner) and keeps the first
+// strictly smaller distance.  Here the 64 lanes of a wave share one WEAK pixel's window: each lane
+// scans a strided subset in the reference's order and the wave reduces (distance, visit index)
+// lexicographically, which picks exactly the probe the sequential scan would have kept.
+__global__ __launch_bounds__(256) void k2_find_nearest_strong(FrameArgs fa)
+{
+    const int W = fa.W, H = fa.H;
+    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave_global >= W * H) {
+        return;
+    }
+    const int center = wave_global;
+    const int py = center / W, px = center - py * W;
+    if (lane == 0) {
+        fa.nearest_strong[center] = make_short2(-1, -1);
+    }
+    if (fa.weak_info[center] != APD_WEAK) {
+        return;
+    }
+    const int radius = 100, side = 2 * radius + 1;
+    // sqrtf is monotone and the reference compares sqrt values: two different integer d2 can round
+    // to the same float only above 2^24, far beyond 2*100^2, so comparing d2 is equivalent.
+    int best_d2 = 0x7fffffff, best_idx = 0x7fffffff;
+    for (int idx = lane; idx < side * side; idx += 64) {
+        const int x = idx / side - radius, y = idx - (idx / side) * side - radius;
+        const int qx = px + x, qy = py + y;
+        if (qx < 0 || qy < 0 || qx >= W || qy >= H) {
+            continue;
+        }
+        if (fa.weak_info[qx + qy * W] == APD_STRONG) {
+            const int d2 = x * x + y * y;
+            if (d2 < best_d2) {  // idx only grows within a lane
+                best_d2 = d2;
+                best_idx = idx;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int od2 = __shfl_xor(best_d2, off);
+        const int oidx = __shfl_xor(best_idx, off);
+        if (od2 < best_d2 || (od2 == best_d2 && oidx < best_idx)) {
+            best_d2 = od2;
+            best_idx = oidx;
+        }
+    }
+    if (lane == 0 && best_idx != 0x7fffffff) {
+        // "dist < min_dist" with min_dist = 255.0f initially: sqrt(d2) <= sqrt(20000) < 255 always
+        const int x = best_idx / side - radius, y = best_idx - (best_idx / side) * side - radius;
+        fa.nearest_strong[center] = make_short2((short)(px + x), (short)(py + y));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  GenNeighbours (APD.cu:1750-1969)
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool point_in_triangle(short2 A, short2 B, short2 C, int px, int py)  // APD.cu:91-112
+{
+    const float ABx = (float)(B.x - A.x), ABy = (float)(B.y - A.y);
+    const float BCx = (float)(C.x - B.x), BCy = (float)(C.y - B.y);
+    const float CAx = (float)(A.x - C.x), CAy = (float)(A.y - C.y);
+    const float ab = sqrtf(ABx * ABx + ABy * ABy);
+    const float bc = sqrtf(BCx * BCx + BCy * BCy);
+    const float ca = sqrtf(CAx * CAx + CAy * CAy);
+    if (ab <= 2 || bc <= 2 || ca <= 2) {
+        return false;
+    }
+    if (!(ab + bc > ca && bc + ca > ab && ab + ca > bc)) {
+        return false;
+    }
+    const float PAx = (float)(A.x - px), PAy = (float)(A.y - py);
+    const float PBx = (float)(B.x - px), PBy = (float)(B.y - py);
+    const float PCx = (float)(C.x - px), PCy = (float)(C.y - py);
+    const float t1 = PAx * PBy - PAy * PBx;
+    const float t2 = PBx * PCy - PBy * PCx;
+    const float t3 = PCx * PAy - PCy * PAx;
+    return t1 * t2 >= 0 && t1 * t3 >= 0;
+}
+
+// (curand()%2==0 ? 1 : -1) * curand() % range in unsigned arithmetic; sign draw first (:1813-1814)
+__device__ __forceinline__ int jitter_shift(Rng &rng, int range)
+{
+    const uint32_t sign = (rng_next(rng) % 2u == 0u) ? 1u : 0xFFFFFFFFu;
+    const uint32_t mag = rng_next(rng);
+    return (int)((sign * mag) % (uint32_t)range);
+}
+
+__device__ __forceinline__ void sort_points_by_weight(short2 *pts, float *w, int n)  // APD.cu:14-27
+{
+    for (int i = 1; i < n; ++i) {
+        const short2 p = pts[i];
+        const float v = w[i];
+        int j = i;
+        while (j >= 1 && v < w[j - 1]) {
+            pts[j] = pts[j - 1];
+            w[j] = w[j - 1];
+            --j;
+        }
+        pts[j] = p;
+        w[j] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa)
+{
+    const int px = blockIdx.x * 8 + (threadIdx.x & 7);
+    const int py = blockIdx.y * 8 + (threadIdx.x >> 3);
+    const int W = fa.W, H = fa.H;
+    if (px >= W || py >= H) {
+        return;
+    }
+    const int center = px + py * W;
+    if (fa.weak_info[center] != APD_WEAK) {
+        return;
+    }
+    const int min_margin = 6;
+    const float depth_diff = fa.depth_max - fa.depth_min;
+    Rng rng = rng_load(fa.rng, center);
+    short2 *nb = &fa.neighbours[(size_t)fa.neighbours_map[center] * APD_NEIGHBOUR_NUM];
+    for (int i = 0; i < APD_NEIGHBOUR_NUM; ++i) {
+        nb[i] = make_short2(-1, -1);
+    }
+    nb[0] = make_short2((short)px, (short)py);
+    short2 strong_pts[32];
+    unsigned dir_valid = 0;
+    for (int i = 0; i < 32; ++i) {
+        strong_pts[i] = make_short2(-1, -1);
+    }
+    int dir_base = -1, found = 0;
+    const int rotate_time = fa.rotate_time;
+    const int shift_range = fa.k3_shift_range;
+    for (int ox = -1; ox <= 1; ++ox) {
+        for (int oy = -1; oy <= 1; ++oy) {
+            if (ox == 0 && oy == 0) {
+                continue;
+            }
+            float odx = (float)ox, ody = (float)oy;
+            normalize2(odx, ody);
+            dir_base++;
+            for (int rot = 0; rot < rotate_time; ++rot) {
+                const int slot = dir_base * 4 + rot;
+                for (int radius = 2; radius <= APD_MAX_SEARCH_RADIUS; radius = min(radius * 2, radius + 25)) {
+                    const float tx = (float)px + odx * (float)radius;
+                    const float ty = (float)py + ody * (float)radius;
+                    if (tx < 0 || ty < 0 || tx >= (float)W || ty >= (float)H) {
+                        break;
+                    }
+                    for (int attempt = 0; attempt < 4; ++attempt) {
+                        const int sx = jitter_shift(rng, shift_range);
+                        const int sy = jitter_shift(rng, shift_range);
+                        float dirx = odx * 20 + (float)sx, diry = ody * 20 + (float)sy;
+                        normalize2(dirx, diry);
+                        short2 q = make_short2((short)((float)px + dirx * (float)radius), (short)((float)py + diry * (float)radius));
+                        if (q.x < min_margin || q.y < min_margin || q.x >= W - min_margin || q.y >= H - min_margin) {
+                            continue;
+                        }
+                        int qc = q.x + q.y * W;
+                        if (fa.weak_info[qc] != APD_STRONG) {
+                            q = fa.nearest_strong[qc];
+                            if (q.x == -1 || q.y == -1) {
+                                continue;
+                            }
+                            qc = q.x + q.y * W;
+                        }
+                        float tdx = (float)(q.x - px), tdy = (float)(q.y - py);
+                        normalize2(tdx, tdy);
+                        const float ca = tdx * odx + tdy * ody;
+                        if (ca > fa.k3_cone) {
+                            strong_pts[slot] = q;
+                            dir_valid |= 1u << slot;
+                            found++;
+                            break;
+                        }
+                    }
+                    if (dir_valid & (1u << slot)) {
+                        break;
+                    }
+                }
+                {
+                    float rdx = odx * fa.k3_cos_angle - ody * fa.k3_sin_angle;
+                    float rdy = odx * fa.k3_sin_angle + ody * fa.k3_cos_angle;
+                    normalize2(rdx, rdy);
+                    odx = rdx;
+                    ody = rdy;
+                }
+            }
+        }
+    }
+    if (found <= 3) {
+        fa.weak_reliable[center] = 0;
+        rng_store(fa.rng, center, rng);
+        return;
+    }
+    float4 best_plane = make_float4(0, 0, 0, 0);
+    int use_a = -1, use_b = -1, use_c = -1;
+    bool has_plane = false;
+    short2 pts[32];
+    float3 pts3d[32];
+    int valid = 0;
+    float Xc, Yc, Zc;
+    point3d(fa, px, py, fa.planes[center].w, Xc, Yc, Zc);  // .w still holds the DEPTH before K5 (:1866)
+    for (int i = 0; i < 32; ++i) {
+        pts[i] = make_short2(-1, -1);
+        if (dir_valid & (1u << i)) {
+            const short2 sp = strong_pts[i];
+            pts[valid] = sp;
+            float X, Y, Z;
+            point3d(fa, sp.x, sp.y, fa.planes[sp.x + sp.y * W].w, X, Y, Z);
+            pts3d[valid] = make_float3(X, Y, Z);
+            valid++;
+        }
+    }
+    {
+        int iteration = 50;
+        float min_cost = FLT_MAX;
+        int max_count = 3;
+        while (iteration--) {
+            const int a = (int)(rng_next(rng) % (uint32_t)valid);
+            const int b = (int)(rng_next(rng) % (uint32_t)valid);
+            const int c = (int)(rng_next(rng) % (uint32_t)valid);
+            if (a == b || b == c || a == c) {
+                continue;
+            }
+            if (!point_in_triangle(pts[a], pts[b], pts[c], px, py)) {
+                continue;
+            }
+            const float3 A = pts3d[a], B = pts3d[b], C = pts3d[c];
+            const float ACx = A.x - C.x, ACy = A.y - C.y, ACz = A.z - C.z;
+            const float BCx = B.x - C.x, BCy = B.y - C.y, BCz = B.z - C.z;
+            float nx = ACy * BCz - BCy * ACz;
+            float ny = -(ACx * BCz - BCx * ACz);
+            float nz = ACx * BCy - BCx * ACy;
+            if ((nx == 0 && ny == 0 && nz == 0) || nx != nx || ny != ny || nz != nz) {
+                continue;
+            }
+            normalize3(nx, ny, nz);
+            const float nw = -(nx * A.x + ny * A.y + nz * A.z);
+            int count = 0;
+            for (int k = 0; k < valid; ++k) {
+                const float3 P = pts3d[k];
+                const float dist = fabsf(nx * P.x + ny * P.y + nz * P.z + nw);
+                if (dist / depth_diff < fa.ransac_threshold) {
+                    count++;
+                }
+            }
+            if (count < 6) {
+                continue;
+            }
+            const float cdist = fabsf(nx * Xc + ny * Yc + nz * Zc + nw);
+            if (count > max_count) {
+                max_count = count;
+                min_cost = cdist;
+                best_plane = make_float4(nx, ny, nz, nw);
+                has_plane = true;
+                use_a = a;
+                use_b = b;
+                use_c = c;
+            } else if (count == max_count) {
+                if (cdist < min_cost) {
+                    min_cost = cdist;
+                    best_plane = make_float4(nx, ny, nz, nw);
+                    use_a = a;
+                    use_b = b;
+                    use_c = c;
+                }
+            }
+        }
+    }
+    rng_store(fa.rng, center, rng);
+    if (!has_plane) {
+        fa.weak_reliable[center] = 0;
+        return;
+    }
+    float weight[32];
+    for (int i = 0; i < valid; ++i) {
+        const float3 P = pts3d[i];
+        float dist = fabsf(best_plane.x * P.x + best_plane.y * P.y + best_plane.z * P.z + best_plane.w);
+        if (dist / depth_diff >= fa.ransac_threshold) {
+            pts[i] = make_short2(-1, -1);
+            weight[i] = FLT_MAX;
+            continue;
+        }
+        if (i == use_a || i == use_b || i == use_c) {
+            dist -= 1;
+        }
+        weight[i] = dist;
+    }
+    sort_points_by_weight(pts, weight, valid);
+    for (int i = 1; i < APD_NEIGHBOUR_NUM; ++i) {
+        nb[i] = pts[i - 1];
+    }
+    fa.weak_reliable[center] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  NeigbourUpdate (APD.cu:1971-1987)
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k4_neighbour_update(FrameArgs fa)
+{
+    const int center = blockIdx.x * 256 + threadIdx.x;
+    if (center >= fa.W * fa.H) {
+        return;
+    }
+    if (fa.weak_info[center] == APD_WEAK && fa.weak_reliable[center] != 1) {
+        fa.weak_info[center] = APD_UNKNOWN;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8  RANSACToGetFitPlane (APD.cu:2272-2384)
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k8_ransac_fit_plane(FrameArgs fa)
+{
+    const int center = blockIdx.x * 256 + threadIdx.x;
+    const int W = fa.W;
+    if (center >= W * fa.H) {
+        return;
+    }
+    const float4 pl = fa.planes[center];
+    if (fa.weak_info[center] != APD_WEAK) {
+        fa.fit_planes[center] = pl;
+        return;
+    }
+    const int py = center / W, px = center - py * W;
+    Rng rng = rng_load(fa.rng, center);
+    const short2 *nb = &fa.neighbours[(size_t)fa.neighbours_map[center] * APD_NEIGHBOUR_NUM];
+    short2 pts[8];
+    float3 pts3d[8];
+    int count = 0;
+    for (int i = 1; i < APD_NEIGHBOUR_NUM; ++i) {
+        const short2 q = nb[i];
+        if (q.x == -1 || q.y == -1) {
+            continue;
+        }
+        pts[count] = q;
+        const float depth = depth_from_plane(fa, fa.planes[q.x + q.y * W], q.x, q.y);
+        float X, Y, Z;
+        point3d(fa, q.x, q.y, depth, X, Y, Z);
+        pts3d[count] = make_float3(X, Y, Z);
+        count++;
+    }
+    if (count < 3) {
+        fa.fit_planes[center] = pl;
+        return;
+    }
+    int iteration = 50;
+    float min_cost = FLT_MAX;
+    float4 best = make_float4(0, 0, 0, 0);
+    bool has_best = false;
+    while (iteration--) {
+        const int a = (int)(rng_next(rng) % (uint32_t)count);
+        const int b = (int)(rng_next(rng) % (uint32_t)count);
+        const int c = (int)(rng_next(rng) % (uint32_t)count);
+        if (a == b || b == c || a == c) {
+            continue;
+        }
+        if (!point_in_triangle(pts[a], pts[b], pts[c], px, py)) {
+            continue;
+        }
+        const float3 A = pts3d[a], B = pts3d[b], C = pts3d[c];
+        const float ACx = A.x - C.x, ACy = A.y - C.y, ACz = A.z - C.z;
+        const float BCx = B.x - C.x, BCy = B.y - C.y, BCz = B.z - C.z;
+        float nx = ACy * BCz - BCy * ACz;
+        float ny = -(ACx * BCz - BCx * ACz);
+        float nz = ACx * BCy - BCx * ACy;
+        if ((nx == 0 && ny == 0 && nz == 0) || nx != nx || ny != ny || nz != nz) {
+            continue;
+        }
+        normalize3(nx, ny, nz);
+        const float nw = -(nx * A.x + ny * A.y + nz * A.z);
+        float tc = 0.0f;
+        for (int k = 0; k < count; ++k) {
+            if (k == a || k == b || k == c) {
+                continue;
+            }
+            const float3 P = pts3d[k];
+            tc += fabsf(nx * P.x + ny * P.y + nz * P.z + nw);
+        }
+        if (tc < min_cost) {
+            min_cost = tc;
+            best = make_float4(nx, ny, nz, nw);
+            has_best = true;
+        }
+        if (min_cost == 0) {
+            break;
+        }
+    }
+    rng_store(fa.rng, center, rng);
+    if (has_best) {
+        const float depth = depth_from_plane(fa, pl, px, py);
+        float vx, vy, vz;
+        view_direction(fa, px, py, depth, vx, vy, vz);
+        const float dot = best.x * vx + best.y * vy + best.z * vz;
+        if (dot > 0) {
+            best = make_float4(-best.x, -best.y, -best.z, -best.w);
+        }
+        fa.fit_planes[center] = best;
+    } else {
+        fa.fit_planes[center] = make_float4(0, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9/K10  Black/RedPixelUpdateWeak -> CheckerboardPropagationWeak (APD.cu:1323-1508, 892-980)
+// ------------------------------------------------------------------------------------------------
+
+// ComputeBilateralNCCNew (APD.cu:400-528): centre 6x6 patch + up to eight 3x3 sub-patches around the
+// reliable neighbours, all warped by the same homography.
+__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const RefPatch &rp, const short2 *nb,
+                                              int px, int py, const float4 pl)
+{
+    float qx, qy, qz;
+    plane_q(pl, qx, qy, qz);
+    const Homography H = make_homography(fa, vc, qx, qy, qz);
+    float cx, cy;
+    correspond(H, (float)px, (float)py, cx, cy);
+    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
+        return 2.0f;
+    }
+    // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above)
+    const float center_cost = ncc_fixed(fa, vc, rp, px, py, qx, qy, qz);
+    float strong_cost = 0.0f;
+    int strong_count = 0;
+    for (int k = 1; k < APD_NEIGHBOUR_NUM; ++k) {
+        const short2 q = nb[k];
+        if (q.x == -1 || q.y == -1) {
+            continue;
+        }
+        float nx, ny;
+        correspond(H, (float)q.x, (float)q.y, nx, ny);
+        if (nx < 0 || ny < 0 || nx >= (float)fa.W || ny >= (float)fa.H) {
+            const uint32_t vi = fa.selected_views[q.x + q.y * fa.W];
+            if (bit_test(vi, (unsigned)v)) {
+                strong_cost += 2.0f;
+                strong_count++;
+            }
+            continue;
+        }
+        strong_cost += patch_cost_generic(fa, vc, H, q.x, q.y, 5, 5);
+        strong_count++;
+    }
+    if (strong_count == 0) {
+        return center_cost;
+    }
+    strong_cost /= (float)strong_count;
+    strong_cost = (strong_cost > 2.0f) ? 2.0f : strong_cost;
+    return (float)(0.25 * (double)center_cost + 0.75 * (double)strong_cost);
+}
+
+// Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
+// plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
+template <int NMAX>
+__global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour, int iter)
+{
+    // one wave per 16x8 footprint; WEAK pixels are sparse, keep workgroups small
+    const int tiles_x = (fa.W + 15) / 16;
+    const int tile = blockIdx.x;
+    const int ty0 = (tile / tiles_x) * 8, tx0 = (tile - (tile / tiles_x) * tiles_x) * 16;
+    const int lane = threadIdx.x;
+    const int ly = lane >> 3;
+    const int py = ty0 + ly;
+    const int px = tx0 + 2 * (lane & 7) + ((py + colour) & 1);
+    if (px >= fa.W || py >= fa.H || py >= fa.half_rows) {
+        return;
+    }
+    const int W = fa.W;
+    const int center = py * W + px;
+    if (fa.weak_info[center] != APD_WEAK) {
+        return;
+    }
+    const int nsrc = fa.num_src;
+    const short2 *nb = &fa.neighbours[(size_t)fa.neighbours_map[center] * APD_NEIGHBOUR_NUM];
+    RefPatch rp;
+    ref_patch_from_global(rp, fa.ref_img, W, fa.H, px, py);
+    Rng rng = rng_load(fa.rng, center);
+
+    float cost_array[9][NMAX];
+    for (int h = 0; h < 9; ++h) {
+        for (int v = 0; v < NMAX; ++v) {
+            cost_array[h][v] = 0.0f;
+        }
+    }
+    cost_array[0][0] = 2.0f;  // APD.cu:1345
+    unsigned flags = 0;
+    float4 cand[8];
+    uint8_t vw[APD_MAX_IMAGES];
+    for (int i = 0; i < APD_MAX_IMAGES; ++i) {
+        vw[i] = 0;
+    }
+    float weight_norm = 0.0f;
+    uint32_t sel = 0;
+    float4 plane_now = fa.planes[center];
+    float4 plane_final = plane_now;
+    float depth_now = 0.0f, cost_now = 0.0f, cost_committed = 0.0f;
+    float ref_depths[5];
+    float4 ref_normals[5];
+    bool skip_refine = false;
+
+#pragma unroll 1
+    for (int h = 0; h < 16; ++h) {
+        float4 pl;
+        if (h < 8) {
+            const short2 q = nb[h + 1];
+            if (q.x == -1 || q.y == -1 || fa.weak_info[q.x + q.y * W] != APD_STRONG) {
+                continue;
+            }
+            flags |= 1u << h;
+            pl = fa.planes[q.x + q.y * W];
+            cand[h] = pl;
+        } else if (h == 8) {
+            pl = plane_now;
+        } else if (h == 9) {
+            // ---- joint view selection (:1365-1434), adopt (:1436-1485) ----
+            float priors[NMAX];
+            for (int j = 0; j < NMAX; ++j) {
+                priors[j] = 0.0f;
+            }
+            for (int i = 0; i < 8; ++i) {
+                const short2 q = nb[i + 1];
+                if (q.x == -1 || q.y == -1) {
+                    continue;
+                }
+                const uint32_t sv = fa.selected_views[q.x + q.y * W];
+                for (int j = 0; j < nsrc; ++j) {
+                    priors[j] += bit_test(sv, (unsigned)j) == 1 ? 0.9f : 0.1f;
+                }
+            }
+            select_views<NMAX>(fa, iter, cost_array, priors, rng, vw, sel, weight_norm);
+            store_view_weight(fa, center, vw);
+            float final_costs[8];
+            for (int i = 0; i < 8; ++i) {
+                float f = 0.0f;
+                for (int j = 0; j < nsrc; ++j) {
+                    if (vw[j] > 0) {
+                        if (fa.geom_consistency) {
+                            if (flags & (1u << i)) {
+                                f += (float)vw[j] * (cost_array[i][j] + fa.geom_factor * geom_cost(fa, fa.views[j], px, py, cand[i]));
+                            } else {
+                                f += (float)vw[j] * (cost_array[i][j] + fa.geom_factor * 3.0f);
+                            }
+                        } else {
+                            f += (float)vw[j] * cost_array[i][j];
+                        }
+                    }
+                }
+                final_costs[i] = f / weight_norm;
+            }
+            int best = 0;
+            float best_c = final_costs[0];
+            for (int i = 1; i < 8; ++i) {
+                if (final_costs[i] <= best_c) {
+                    best_c = final_costs[i];
+                    best = i;
+                }
+            }
+            cost_now = 0.0f;
+            for (int i = 0; i < nsrc; ++i) {
+                if (fa.geom_consistency) {
+                    cost_now += (float)vw[i] * (cost_array[8][i] + fa.geom_factor * geom_cost(fa, fa.views[i], px, py, plane_now));
+                } else {
+                    cost_now += (float)vw[i] * cost_array[8][i];
+                }
+            }
+            cost_now /= weight_norm;
+            cost_committed = cost_now;
+            depth_now = depth_from_plane(fa, plane_now, px, py);
+            if (flags & (1u << best)) {
+                const float d = depth_from_plane(fa, cand[best], px, py);
+                if (d >= fa.depth_min && d <= fa.depth_max && final_costs[best] < cost_now) {
+                    depth_now = d;
+                    plane_now = cand[best];
+                    cost_now = final_costs[best];
+                    fa.selected_views[center] = sel;
+                }
+            }
+            // PlaneHypothesisRefinementWeak: fit plane first (:910-936)
+            pl = fa.fit_planes[center];
+            if (pl.x == 0 && pl.y == 0 && pl.z == 0) {
+                skip_refine = true;  // returns before the random refinement too (:912-914)
+            }
+        } else if (h == 15) {
+            // commit (:1488-1497), then re-score with the fixed patch (:1499-1507)
+            if (fa.state == APD_REFINE_INIT) {
+                if ((double)cost_now < (double)cost_committed - 0.1) {
+                    plane_final = plane_now;
+                }
+            } else {
+                plane_final = plane_now;
+            }
+            pl = plane_final;
+        } else {
+            if (h == 10 && !skip_refine) {
+                make_refinement_set(fa, px, py, rng, plane_now, depth_now, ref_depths, ref_normals);
+            }
+            pl = ref_normals[h - 10];
+            pl.w = distance_to_origin(fa, px, py, ref_depths[h - 10], pl.x, pl.y, pl.z);
+        }
+        if (h >= 9 && h <= 14 && skip_refine) {
+            continue;
+        }
+        float tc = 0.0f;
+#pragma unroll 1
+        for (int v = 0; v < nsrc; ++v) {
+            const ViewConst &vc = fa.views[v];
+            if (h < 9) {
+                cost_array[h][v] = ncc_deformed(fa, vc, v, rp, nb, px, py, pl);
+            } else if (h == 15) {
+                float qx, qy, qz;
+                plane_q(pl, qx, qy, qz);
+                tc += (float)vw[v] * ncc_fixed(fa, vc, rp, px, py, qx, qy, qz);
+            } else {
+                const float c = ncc_deformed(fa, vc, v, rp, nb, px, py, pl);
+                if (vw[v] > 0) {
+                    if (fa.geom_consistency) {
+                        tc += (float)vw[v] * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
+                    } else {
+                        tc += (float)vw[v] * c;
+                    }
+                }
+            }
+        }
+        if (h >= 9 && h <= 14) {
+            tc /= weight_norm;
+            const float d = depth_from_plane(fa, pl, px, py);
+            if (d >= fa.depth_min && d <= fa.depth_max && tc < cost_now) {
+                depth_now = d;
+                plane_now = pl;
+                cost_now = tc;
+            }
+        } else if (h == 15) {
+            fa.costs[center] = tc / weight_norm;
+            fa.planes[center] = plane_final;
+        }
+    }
+    rng_store(fa.rng, center, rng);
+}
+
+// ------------------------------------------------------------------------------------------------
+// export of main.cpp:105-115 on the device (depth with out-of-range -> 0, normal)
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_export_depth_normal(FrameArgs fa, float *depth, float *normal)
+{
+    const int center = blockIdx.x * 256 + threadIdx.x;
+    if (center >= fa.W * fa.H) {
+        return;
+    }
+    const float4 pl = fa.planes[center];
+    float d = pl.w;
+    if (d < fa.depth_min || d > fa.depth_max) {
+        d = 0.0f;
+    }
+    depth[center] = d;
+    if (normal) {
+        normal[3 * (size_t)center + 0] = pl.x;
+        normal[3 * (size_t)center + 1] = pl.y;
+        normal[3 * (size_t)center + 2] = pl.z;
+    }
+}
+
+hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_export_depth_normal, dim3((fa.W * fa.H + 255) / 256), dim3(256), 0, s, fa, depth, normal);
+    return hipGetLastError();
+}
+
+template <int NMAX>
+static void launch_k910(const FrameArgs &fa, int colour, int iter, hipStream_t s)
+{
+    const int tiles = ((fa.W + 15) / 16) * ((fa.H + 7) / 8);
+    hipLaunchKernelGGL(k910_update_weak<NMAX>, dim3(tiles), dim3(64), 0, s, fa, colour, iter);
+}
+
+hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s)
+{
+    const int n = fa.W * fa.H;
+    switch (kernel_id) {
+    case APD_K2_FIND_NEAREST_STRONG:
+        // one wave per pixel: 4 pixels per 256-thread workgroup
+        hipLaunchKernelGGL(k2_find_nearest_strong, dim3((n + 3) / 4), dim3(256), 0, s, fa);
+        break;
+    case APD_K3_GEN_NEIGHBOURS:
+        hipLaunchKernelGGL(k3_gen_neighbours, dim3((fa.W + 7) / 8, (fa.H + 7) / 8), dim3(64), 0, s, fa);
+        break;
+    case APD_K4_NEIGHBOUR_UPDATE:
+        hipLaunchKernelGGL(k4_neighbour_update, dim3((n + 255) / 256), dim3(256), 0, s, fa);
+        break;
+    case APD_K8_RANSAC_FIT_PLANE:
+        hipLaunchKernelGGL(k8_ransac_fit_plane, dim3((n + 255) / 256), dim3(256), 0, s, fa);
+        break;
+    case APD_K9_BLACK_UPDATE_WEAK:
+    case APD_K10_RED_UPDATE_WEAK: {
+        const int colour = (kernel_id == APD_K9_BLACK_UPDATE_WEAK) ? 0 : 1;
+        if (fa.num_src <= 8) {
+            launch_k910<8>(fa, colour, iter, s);
+        } else if (fa.num_src <= 16) {
+            launch_k910<16>(fa, colour, iter, s);
+        } else {
+            launch_k910<32>(fa, colour, iter, s);
+        }
+        break;
+    }
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace apd

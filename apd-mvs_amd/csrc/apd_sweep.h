@@ -1,0 +1,175 @@
+// apd_sweep.h -- pieces shared by the strong and weak checkerboard kernels.
+#pragma once
+
+#include <float.h>
+
+#include "apd_device.h"
+
+namespace apd {
+
+__device__ __forceinline__ void sort_ascending(float *d, int n)  // APD.cu:3-12
+{
+    for (int i = 1; i < n; ++i) {
+        const float v = d[i];
+        int j = i;
+        while (j >= 1 && v < d[j - 1]) {
+            d[j] = d[j - 1];
+            --j;
+        }
+        d[j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// checkerboard tiling shared by K6/K7, K9/K10, K12/K13
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kTileW = 32, kTileH = 16, kHalo = kPatchRadius;
+constexpr int kLdsW = kTileW + 2 * kHalo;      // 42
+constexpr int kLdsH = kTileH + 2 * kHalo;      // 26
+constexpr int kLdsPitch = kLdsW + 1;           // 43: odd pitch spreads the column reads over banks
+
+struct TilePixel {
+    int tx0, ty0;  // tile origin
+    int lx, ly;    // pixel inside the tile
+    int px, py;
+};
+
+// colour 0 = black ((x + y) even), 1 = red; wave w covers the 16x8 sub-tile (w&1, w>>1).
+__device__ __forceinline__ TilePixel checkerboard_pixel(const FrameArgs &fa, int colour)
+{
+    const int tiles_x = (fa.W + kTileW - 1) / kTileW;
+    const int tiles_y = (fa.H + kTileH - 1) / kTileH;
+    const int tile = xcd_band_tile(blockIdx.x, tiles_x * tiles_y);
+    TilePixel t;
+    t.ty0 = (tile / tiles_x) * kTileH;
+    t.tx0 = (tile - (tile / tiles_x) * tiles_x) * kTileW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    t.ly = (wave >> 1) * 8 + (lane >> 3);
+    t.lx = (wave & 1) * 16 + 2 * (lane & 7) + ((t.ly + colour) & 1);
+    t.px = t.tx0 + t.lx;
+    t.py = t.ty0 + t.ly;
+    return t;
+}
+
+__device__ __forceinline__ bool checkerboard_active(const FrameArgs &fa, const TilePixel &t)
+{
+    // rows beyond half_rows are never visited by the reference's HALF launch (APD.cu:2402)
+    return t.px < fa.W && t.py < fa.H && t.py < fa.half_rows;
+}
+
+// ------------------------------------------------------------------------------------------------
+// view selection shared by strong (:1203-1271) and weak (:1365-1434) propagation
+// ------------------------------------------------------------------------------------------------
+
+template <int NMAX>
+__device__ __forceinline__ void select_views(const FrameArgs &fa, int iter, const float (*cost_array)[NMAX], const float *priors,
+                                             Rng &rng, uint8_t *vw, uint32_t &sel_out, float &weight_norm_out)
+{
+    const int nsrc = fa.num_src;
+    float probs[NMAX];
+    const float thr = (float)(0.8 * (double)exp_poly((float)(iter * iter) / (-90.0f)));
+    for (int i = 0; i < nsrc; ++i) {
+        float count = 0;
+        int count_false = 0;
+        float tmpw = 0;
+        for (int j = 0; j < 8; ++j) {
+            const float c = cost_array[j][i];
+            if (c < thr) {
+                tmpw += exp_poly(c * c / (-0.18f));
+                count++;
+            }
+            if (c > 1.2f) {
+                count_false++;
+            }
+        }
+        float p = 0.0f;
+        if (count > 2 && count_false < 3) {
+            p = tmpw / count;
+        } else if (count_false < 3) {
+            p = exp_poly(thr * thr / (-0.32f));
+        }
+        probs[i] = p * priors[i];
+    }
+    // TransformPDFToCDF, APD.cu:143-157
+    float sum = 0.0f;
+    for (int i = 0; i < nsrc; ++i) {
+        sum += probs[i];
+    }
+    const float inv = 1.0f / sum;
+    float acc = 0.0f;
+    for (int i = 0; i < nsrc; ++i) {
+        acc += probs[i] * inv;
+        probs[i] = acc;
+    }
+    for (int sample = 0; sample < 15; ++sample) {
+        const float rp = rng_uniform(rng) - FLT_EPSILON;
+        for (int v = 0; v < nsrc; ++v) {
+            if (probs[v] > rp) {
+                vw[v] += 1;
+                break;
+            }
+        }
+    }
+    uint32_t sel = 0;
+    float wn = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        if (vw[i] > 0) {
+            sel |= 1u << i;
+            wn += (float)vw[i];
+        }
+    }
+    sel_out = sel;
+    weight_norm_out = wn;
+}
+
+__device__ __forceinline__ void store_view_weight(const FrameArgs &fa, int center, const uint8_t *vw)
+{
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        w[i] = (uint32_t)vw[4 * i] | ((uint32_t)vw[4 * i + 1] << 8) | ((uint32_t)vw[4 * i + 2] << 16) | ((uint32_t)vw[4 * i + 3] << 24);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(fa.view_weight + (size_t)center * APD_MAX_IMAGES);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// The five refinement hypotheses of APD.cu:855-867 / :939-951 (RNG order: depth, normal, depth, 3 angles).
+__device__ __forceinline__ void make_refinement_set(const FrameArgs &fa, int px, int py, Rng &rng, const float4 plane, float depth,
+                                                    float *depths, float4 *normals)
+{
+    const float depth_perturbation = 0.02f, normal_perturbation = 0.02f;
+    const float depth_rand = rng_uniform(rng) * (fa.depth_max - fa.depth_min) + fa.depth_min;
+    const float4 n_rand = random_normal(fa, px, py, rng, depth);
+    const float lo = (1 - depth_perturbation) * depth;
+    const float hi = (1 + depth_perturbation) * depth;
+    const float depth_pert = rng_uniform(rng) * (hi - lo) + lo;  // the reference's do-while never loops
+    const float4 n_pert = perturbed_normal(fa, px, py, plane, rng, (float)((double)normal_perturbation * 3.14159265358979323846));
+    depths[0] = depth_rand;
+    depths[1] = depth;
+    depths[2] = depth_rand;
+    depths[3] = depth;
+    depths[4] = depth_pert;
+    normals[0] = plane;
+    normals[1] = n_rand;
+    normals[2] = n_rand;
+    normals[3] = n_pert;
+    normals[4] = plane;
+}
+
+__device__ __forceinline__ void load_view_weight(const FrameArgs &fa, int center, uint8_t *vw)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(fa.view_weight + (size_t)center * APD_MAX_IMAGES);
+    const uint4 a = src[0], b = src[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        vw[4 * i + 0] = (uint8_t)(w[i] & 0xFF);
+        vw[4 * i + 1] = (uint8_t)((w[i] >> 8) & 0xFF);
+        vw[4 * i + 2] = (uint8_t)((w[i] >> 16) & 0xFF);
+        vw[4 * i + 3] = (uint8_t)(w[i] >> 24);
+    }
+}
+
+}  // namespace apd

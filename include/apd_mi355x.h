@@ -1,0 +1,185 @@
+/*
+ * apd_mi355x.h -- C ABI of the MI355X-native PatchMatch path of APD-MVS.
+ *
+ * The reference (whoiszzj/APD-MVS) has no C ABI / FFI layer: its boundary for this path is the C++
+ * class `APD` (APD.h:67-145) driven by `ProcessProblem` (main.cpp:91-138).  This header is the
+ * flat `extern "C"` equivalent of that class: one handle == one `APD` object == one
+ * (reference view, pass).  Every entry point cites the reference member it replaces.  The C++
+ * drop-in class (apd-mvs_amd/host/APD.h) and the Python host mirror (apd-mvs_amd/__init__.py)
+ * are thin layers over exactly these symbols.
+ *
+ * Conventions: all functions return 0 on success and a negative apd_status otherwise (the
+ * reference calls exit(); a library must not).  apd_last_error() gives the message of the last
+ * failure on the calling thread.  Caller owns every buffer it passes.  A handle is bound to one
+ * device and is not thread-safe; distinct handles on distinct devices may run concurrently.
+ * Pointers passed to upload/download may be host or device pointers (hipMemcpyDefault).
+ */
+#ifndef APD_MI355X_H_
+#define APD_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APD_MAX_IMAGES 32        /* main.h:37 MAX_IMAGES */
+#define APD_NEIGHBOUR_NUM 9      /* main.h:38 NEIGHBOUR_NUM */
+#define APD_MAX_SEARCH_RADIUS 4096 /* main.h:39 */
+
+typedef enum { APD_FIRST_INIT = 0, APD_REFINE_INIT = 1, APD_REFINE_ITER = 2 } apd_run_state; /* main.h:63-67 */
+typedef enum { APD_WEAK = 0, APD_STRONG = 1, APD_UNKNOWN = 2 } apd_pixel_state;              /* main.h:69-73 */
+
+typedef enum {
+    APD_OK = 0,
+    APD_ERR_INVALID = -1,   /* bad argument */
+    APD_ERR_HIP = -2,       /* HIP runtime error (reference: CudaSafeCall -> exit, APD.cpp:315-323) */
+    APD_ERR_TOO_MANY = -3,  /* > APD_MAX_IMAGES images (reference: exit, APD.cpp:428-431) */
+    APD_ERR_STATE = -4,     /* call order violated (e.g. run before upload) */
+    APD_ERR_UNSUPPORTED = -5
+} apd_status;
+
+/* Byte-compatible with the reference `Camera` (main.h:47-56, 112 bytes). */
+typedef struct apd_camera {
+    float K[9];
+    float R[9];
+    float t[3];
+    float c[3];
+    int height;
+    int width;
+    float depth_min;
+    float depth_max;
+} apd_camera;
+
+/* Fields of `PatchMatchParams` (main.h:75-94) in the reference's order, then the additive knobs. */
+typedef struct apd_params {
+    int max_iterations;     /* 3 */
+    int num_images;         /* set by apd_upload_views */
+    float sigma_spatial;    /* 5.0  (dead in the reference: weight == 1, APD.cu:473,575) */
+    float sigma_color;      /* 3.0  (dead) */
+    int top_k;              /* 4 */
+    float depth_min;        /* 0.6 * ref camera depth_min (APD.cpp:454) */
+    float depth_max;        /* 1.2 * ref camera depth_max (APD.cpp:455) */
+    int geom_consistency;   /* bool */
+    int strong_radius;      /* 5 */
+    int strong_increment;   /* 2 */
+    int weak_radius;        /* 5 */
+    int weak_increment;     /* 5 */
+    int use_APD;            /* bool */
+    int weak_peak_radius;   /* 2 */
+    int rotate_time;        /* 4 */
+    float ransac_threshold; /* 0.005 */
+    float geom_factor;      /* 0.2 */
+    int state;              /* apd_run_state */
+    /* ---- additive knobs (absent in the reference; defaults keep reference behaviour) ---- */
+    uint64_t seed;          /* replaces clock64() in curand_init, APD.cu:803 */
+} apd_params;
+
+typedef struct apd_context *apd_handle;
+
+/* Kernel ids for apd_run_kernel / apd_profile_get. */
+enum {
+    APD_K1_INIT_RANDOM_STATES = 1,   /* APD.cu:791  */
+    APD_K2_FIND_NEAREST_STRONG = 2,  /* APD.cu:2234 */
+    APD_K3_GEN_NEIGHBOURS = 3,       /* APD.cu:1750 */
+    APD_K4_NEIGHBOUR_UPDATE = 4,     /* APD.cu:1971 */
+    APD_K5_RANDOM_INITIALIZATION = 5,/* APD.cu:806  */
+    APD_K6_BLACK_UPDATE_STRONG = 6,  /* APD.cu:1547 */
+    APD_K7_RED_UPDATE_STRONG = 7,    /* APD.cu:1567 */
+    APD_K8_RANSAC_FIT_PLANE = 8,     /* APD.cu:2272 */
+    APD_K9_BLACK_UPDATE_WEAK = 9,    /* APD.cu:1510 */
+    APD_K10_RED_UPDATE_WEAK = 10,    /* APD.cu:1529 */
+    APD_K11_GET_DEPTH_NORMAL = 11,   /* APD.cu:1587 */
+    APD_K12_BLACK_FILTER = 12,       /* APD.cu:1716 */
+    APD_K13_RED_FILTER = 13,         /* APD.cu:1733 */
+    APD_K14_DEPTH_TO_WEAK = 14,      /* APD.cu:1990 */
+    APD_K15_LOCAL_REFINE = 15,       /* APD.cu:2146 */
+    APD_KERNEL_COUNT = 16
+};
+
+/* State arrays readable with apd_download_state (tests / snapshots). */
+enum {
+    APD_STATE_PLANES = 0,        /* float4  [H*W]      plane_hypotheses_cuda      */
+    APD_STATE_FIT_PLANES = 1,    /* float4  [H*W]      fit_plane_hypotheses_cuda  */
+    APD_STATE_COSTS = 2,         /* float   [H*W]      costs_cuda                 */
+    APD_STATE_RNG = 3,           /* uint32  [H*W*6]    rand_states_cuda (x0..x4,d)*/
+    APD_STATE_SELECTED_VIEWS = 4,/* uint32  [H*W]      selected_views_cuda        */
+    APD_STATE_VIEW_WEIGHT = 5,   /* uint8   [H*W*32]   view_weight_cuda           */
+    APD_STATE_WEAK_INFO = 6,     /* uint8   [H*W]      weak_info_cuda             */
+    APD_STATE_WEAK_RELIABLE = 7, /* uint8   [H*W]      weak_reliable_cuda         */
+    APD_STATE_NEAREST_STRONG = 8,/* short2  [H*W]      weak_nearest_strong        */
+    APD_STATE_NEIGHBOURS_MAP = 9,/* int32   [H*W]      neighbours_map_cuda        */
+    APD_STATE_NEIGHBOURS = 10    /* short2  [weak*9]   neighbours_cuda            */
+};
+
+/* Defaults of PatchMatchParams (main.h:75-94), seed = 12345. */
+void apd_default_params(apd_params *p);
+
+/* APD::APD(const Problem&) (APD.cpp:356-359) + the allocations of CudaSpaceInitialization
+ * (APD.cpp:636-666).  `device` < 0 keeps the current device (reference: cudaSetDevice, main.cpp:153). */
+int apd_create(apd_handle *out, int device, int width, int height, const apd_params *params);
+
+/* ~APD (APD.cpp:361-397). */
+int apd_destroy(apd_handle h);
+
+/* Image / depth / camera upload of CudaSpaceInitialization (APD.cpp:588-634).  images[0] is the
+ * reference view; `depths` may be NULL unless params.geom_consistency.  All images are W*H floats,
+ * row-major, no padding.  Sets params.num_images. */
+int apd_upload_views(apd_handle h, int num_images, const apd_camera *cameras, const float *const *images,
+                     const float *const *depths);
+
+/* Prior state of a previous pass (APD.cpp:552-581, 643-661): planes = (world normal xyz, depth w),
+ * selected-view bitmasks and weak map.  Any pointer may be NULL: planes/views zero, weak = all STRONG
+ * (APD.cpp:541-547).  Builds the weak index map of APD.cpp:526-537. */
+int apd_upload_prior(apd_handle h, const float *planes4, const uint32_t *selected_views, const uint8_t *weak_info);
+
+/* APD::RunPatchMatch (APD.cu:2386-2495), without the final device->host copies. */
+int apd_run(apd_handle h);
+
+/* One kernel of the schedule (single stepping for snapshot tests). */
+int apd_run_kernel(apd_handle h, int kernel_id, int iter);
+
+/* The metric's timed region: loop body APD.cu:2443-2457 (K6,K7,K8,K9,K10) for
+ * iter = first_iter .. first_iter+iters-1.  Asynchronous; pair with apd_synchronize. */
+int apd_run_sweeps(apd_handle h, int first_iter, int iters);
+
+int apd_synchronize(apd_handle h);
+
+/* The three copies at the end of RunPatchMatch (APD.cu:2490-2492) == GetPlaneHypothesis /
+ * GetPixelStates / GetSelectedViews (APD.cpp:701-711).  Any pointer may be NULL. */
+int apd_download(apd_handle h, float *planes4, uint8_t *weak_info, uint32_t *selected_views);
+
+/* Raw copy of one state array (see APD_STATE_*).  `bytes` must not exceed the array size. */
+int apd_download_state(apd_handle h, int which, void *dst, size_t bytes);
+int apd_upload_state(apd_handle h, int which, const void *src, size_t bytes);
+size_t apd_state_bytes(apd_handle h, int which);
+
+/* Post-processing of ProcessProblem (main.cpp:105-115) done on the device: depth = plane.w with
+ * out-of-range -> 0, normal = plane.xyz.  `depth_dev` (W*H floats) and `normal_dev` (3*W*H floats)
+ * are DEVICE pointers (e.g. torch tensors handed to an RCCL all-gather). */
+int apd_export_depth_normal_device(apd_handle h, float *depth_dev, float *normal_dev);
+
+/* Getters of APD.h:76-81. */
+int apd_width(apd_handle h);
+int apd_height(apd_handle h);
+float apd_depth_min(apd_handle h);
+float apd_depth_max(apd_handle h);
+int apd_weak_count(apd_handle h);
+
+/* Per-kernel timing with HIP events on the handle's stream. */
+int apd_profile_enable(apd_handle h, int on);
+int apd_profile_reset(apd_handle h);
+int apd_profile_get(apd_handle h, int kernel_id, double *total_ms, int *launches);
+
+/* Use an existing HIP stream (hipStream_t) instead of the handle's own. */
+int apd_set_stream(apd_handle h, void *hip_stream);
+
+const char *apd_last_error(void);
+int apd_version(void);
+int apd_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APD_MI355X_H_ */
