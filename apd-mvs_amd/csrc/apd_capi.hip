@@ -234,6 +234,7 @@ int apd_create(apd_handle *out, int device, int width, int height, const apd_par
     HIP_TRY(hipMemsetAsync(c->neighbours_map, 0, n * sizeof(int), c->stream));
     HIP_TRY(hipMalloc(&c->neighbours, APD_NEIGHBOUR_NUM * sizeof(short2)));
     c->neighbours_cap = 1;
+    HIP_TRY(hipMemsetAsync(c->neighbours, 0, APD_NEIGHBOUR_NUM * sizeof(short2), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     refresh_frame_args(c);
     *out = c;
@@ -406,6 +407,7 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
         HIP_TRY(hipMalloc(&c->neighbours, need * APD_NEIGHBOUR_NUM * sizeof(short2)));
         c->neighbours_cap = need;
     }
+    HIP_TRY(hipMemsetAsync(c->neighbours, 0, c->neighbours_cap * APD_NEIGHBOUR_NUM * sizeof(short2), c->stream));
     HIP_TRY(hipMemsetAsync(c->fit_planes, 0, n * sizeof(float4), c->stream));
     HIP_TRY(hipMemsetAsync(c->view_weight, 0, n * APD_MAX_IMAGES, c->stream));
     HIP_TRY(hipMemsetAsync(c->weak_reliable, 0, n, c->stream));

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpix*iterations/s of the PatchMatch sweep (BASELINE.json metric) on 1..8 MI355X.
+
+One "step" = one iteration of the loop body APD.cu:2443-2457 (K6 black + K7 red strong update,
+K8 fit-plane, K9/K10 weak update when WEAK pixels exist) over one reference view.  N=1 workload =
+BASELINE.json configs[1]: ETH3D-office-shaped stand-in, 6200x4130, 8 source views (datasets are not
+in the image: SURVEY.md 8d synthetic generator).  With --gpus N each rank sweeps its own reference
+view (views shard, no collective in the data path: weak scaling) and the final depth/normal maps are
+all-gathered over RCCL after the timed region, as they would be before fusion.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+WORKLOADS = {
+    # name: (width, height, num_src)
+    "eth3d_office_fullres_8src": (6200, 4130, 8),    # BASELINE.json configs[1]
+    "eth3d_pipes_fullres_10src": (6200, 4130, 10),   # configs[2] shape (strong pixels only here)
+    "synthetic_4096x3072_16src": (4096, 3072, 16),   # configs[4]
+    "tt_family_1080p_10src": (1920, 1080, 10),       # configs[3] shape
+    "small": (640, 480, 8),
+}
+
+
+def algorithmic_bytes_per_strong_pixel(num_src):
+    """14*N NCCs x 36 samples x (4 B ref texel + 16 B bilinear taps) + 176 B of state."""
+    return 10080 * num_src + 176
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="eth3d_office_fullres_8src", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="512x384", help="WxH of the CPU-baseline sample")
+    ap.add_argument("--seed", type=int, default=12345)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from apd_mvs_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if distributed else 0)
+
+    W, H, N = WORKLOADS[args.workload]
+    # every rank owns a different reference view of the same camera ring
+    sc = synth.make_scene(W, H, N, seed=0, ref_view=rank, device=dev)
+    cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+    total_iters = args.warmup + args.steps
+    params = pkg.default_params(num_images=N + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0,
+                                state=pkg.FIRST_INIT, max_iterations=total_iters, seed=args.seed)
+    h = pkg.Handle(W, H, params, device=dev.index)
+    h.upload_views(cams, sc.images)  # device->device copies: inputs are resident in HBM before timing
+    del sc.images[:]
+    torch.cuda.empty_cache()
+    # everything before the loop of APD.cu:2443 (not timed): K1, K2, K5
+    h.run_kernel(pkg.K1)
+    h.run_kernel(pkg.K2)
+    h.run_kernel(pkg.K5)
+    # warmup iterations
+    if args.warmup > 0:
+        h.run_sweeps(0, args.warmup)
+    h.profile_enable(True)
+    h.profile_reset()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        h.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    h.run_sweeps(args.warmup, args.steps, sync=False)
+    h.synchronize()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if distributed:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    prof = h.profile()
+    h.profile_enable(False)
+
+    # after the timed region: post-loop kernels + all-gather of depth/normal maps (before fusion)
+    allgather_ms = None
+    t_post0 = time.perf_counter()
+    for kid in (pkg.K11, pkg.K12, pkg.K13):
+        h.run_kernel(kid)
+    depth = torch.empty((H, W), device=dev, dtype=torch.float32)
+    normal = torch.empty((H, W, 3), device=dev, dtype=torch.float32)
+    h.export_depth_normal(depth, normal)
+    torch.cuda.synchronize()
+    if distributed:
+        gathered_d = torch.empty((world, H, W), device=dev, dtype=torch.float32)
+        gathered_n = torch.empty((world, H, W, 3), device=dev, dtype=torch.float32)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        dist.all_gather_into_tensor(gathered_d, depth)
+        dist.all_gather_into_tensor(gathered_n, normal)
+        torch.cuda.synchronize()
+        allgather_ms = (time.perf_counter() - ta) * 1e3
+    gt = sc.gt_depth
+    err = (depth - gt).abs() / gt
+    within = float((err[8:-8, 8:-8] < 0.01).float().mean().item())
+    post_ms = (time.perf_counter() - t_post0) * 1e3
+
+    mpix = W * H / 1e6
+    value = world * mpix * args.steps / elapsed
+
+    # roofline of the dominant kernel (K6/K7 strong update), from HIP events on the handle's stream
+    k6 = prof.get(pkg.K6, (0.0, 0))
+    k7 = prof.get(pkg.K7, (0.0, 0))
+    launches = k6[1] + k7[1]
+    avg_ms = (k6[0] + k7[0]) / max(launches, 1)
+    bytes_per_launch = (W * H / 2.0) * algorithmic_bytes_per_strong_pixel(N)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": "k67_update_strong (Black/RedPixelUpdateStrong)", "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "avg_launch_ms": round(avg_ms, 3), "launches": launches,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "bytes_per_pixel_iter": algorithmic_bytes_per_strong_pixel(N),
+    }
+    kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0], 3) for k, v in sorted(prof.items())}
+
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args, N, np)
+
+    if rank == 0:
+        out = {
+            "metric": "Mpix*iterations/sec (PatchMatch sweep)",
+            "value": round(value, 4),
+            "unit": "Mpix*iter/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "width": W, "height": H, "num_src": N, "state": "FIRST_INIT",
+                       "views_per_gpu": 1, "parallelism": "views sharded, %d rank(s)" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernel_ms_timed_region": kernel_ms,
+            "post_loop_ms": round(post_ms, 1),
+            "allgather_ms": None if allgather_ms is None else round(allgather_ms, 3),
+            "quality_within_1pct_depth": round(within, 4),
+        }
+        print(json.dumps(out), flush=True)
+    h.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(args, num_src, np):
+    """The oracle (kind "port": plain-C restatement of the reference path, OpenMP over pixels) timed on
+    this host's cores on a bounded sample of the same workload: same generator, same N, smaller frame."""
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from apd_mvs_amd import synth
+    from oracle import binding as ob
+
+    w, hgt = [int(v) for v in args.cpu_sample.lower().split("x")]
+    sc = synth.make_scene(w, hgt, num_src, seed=0)
+    imgs = sc.images_numpy()
+    cams = [ob.make_camera(sc.K[i], sc.R[i], sc.t[i], w, hgt, sc.depth_min, sc.depth_max) for i in range(num_src + 1)]
+    p = ob.default_params(num_images=num_src + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0,
+                          state=ob.FIRST_INIT, max_iterations=2, seed=args.seed)
+    o = ob.Oracle(w, hgt, p, cams, imgs)
+    for kid in (1, 2, 5):
+        o.run_kernel(kid)
+    o.run_sweeps(0, 1)  # warm caches / thread pool
+    iters = 0
+    t0 = time.perf_counter()
+    while True:
+        o.run_sweeps(1 + iters, 1)
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or iters >= 8:
+            break
+    cores = ob.lib().orc_get_threads()
+    o.close()
+    return {"value": round(w * hgt * iters / dt / 1e6, 5), "unit": "Mpix*iter/s", "cores": int(cores), "kind": "port",
+            "sample": "%dx%d frame of the same synthetic scene, %d src views, %d iterations, %.1f s" % (w, hgt, num_src, iters, dt)}
+
+
+if __name__ == "__main__":
+    main()
