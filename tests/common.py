@@ -1,0 +1,82 @@
+"""Shared scene / handle / oracle construction for the tests."""
+import numpy as np
+
+
+def scene_inputs(synth, W, H, N, seed=1, textureless=0.0, rotate=True):
+    sc = synth.make_scene(W, H, N, seed=seed, textureless=textureless, rotate=rotate)
+    return sc, sc.images_numpy()
+
+
+def base_params(sc, N, **kw):
+    p = dict(num_images=N + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0, state=0,
+             max_iterations=2, seed=7)
+    p.update(kw)
+    return p
+
+
+def make_oracle(ob, sc, imgs, N, params, depths=None, prior=None):
+    W, H = sc.width, sc.height
+    cams = [ob.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+    pr = prior or (None, None, None)
+    return ob.Oracle(W, H, ob.default_params(**params), cams, imgs, depths=depths, prior_planes=pr[0], prior_views=pr[1],
+                     prior_weak=pr[2])
+
+
+def make_handle(pkg, sc, imgs, N, params, depths=None, prior=None, device=0):
+    W, H = sc.width, sc.height
+    cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+    h = pkg.Handle(W, H, pkg.default_params(**params), device=device)
+    h.upload_views(cams, imgs, depths)
+    if prior is not None:
+        h.upload_prior(*prior)
+    return h
+
+
+ORACLE_STATES = [("planes", "STATE_PLANES", "planes"), ("costs", "STATE_COSTS", "costs"), ("rng", "STATE_RNG", "rng"),
+                 ("views", "STATE_SELECTED_VIEWS", "selected_views"), ("view_weight", "STATE_VIEW_WEIGHT", "view_weight"),
+                 ("weak", "STATE_WEAK_INFO", "weak_info"), ("fit", "STATE_FIT_PLANES", "fit_planes"),
+                 ("reliable", "STATE_WEAK_RELIABLE", "weak_reliable"), ("nearest", "STATE_NEAREST_STRONG", "nearest_strong"),
+                 ("neighbours", "STATE_NEIGHBOURS", "neighbours")]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def assert_state_equal(pkg, h, o, where, skip=()):
+    """Bit-exact comparison of every state array (integer / byte / index work and float32 alike)."""
+    for name, hs, oa in ORACLE_STATES:
+        if name in skip or (name == "neighbours" and h.weak_count == 0):
+            continue
+        a, b = h.state(getattr(pkg, hs)), getattr(o, oa)
+        if not np.array_equal(bits(a), bits(b)):
+            neq = bits(a).reshape(a.shape[0], -1) != bits(b).reshape(a.shape[0], -1)
+            raise AssertionError("%s: HIP and oracle differ in `%s` (%d bytes differ)" % (where, name, int(neq.sum())))
+
+
+def postprocess(planes, weak, views, dmin, dmax, unknown=2):
+    """ProcessProblem post-processing (main.cpp:105-115): out-of-range depth -> 0 and UNKNOWN."""
+    planes, weak = planes.copy(), weak.copy()
+    d = planes[..., 3]
+    bad = (d < dmin) | (d > dmax)
+    d[bad] = 0
+    weak[bad] = unknown
+    return planes, views.copy(), weak
+
+
+def depth_of_planes(planes, K):
+    """ComputeDepthfromPlaneHypothesis (APD.cu:206-209) in float64, for quality metrics only."""
+    H, W = planes.shape[:2]
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    pl = planes.astype(np.float64)
+    return -pl[..., 3] * K[0] / ((xs - K[2]) * pl[..., 0] + (K[0] / K[4]) * (ys - K[5]) * pl[..., 1] + K[0] * pl[..., 2])
+
+
+def fake_depth_maps(W, H, n):
+    ys, xs = np.mgrid[0:H, 0:W]
+    out = []
+    for k in range(n):
+        d = (2.2 + 0.1 * np.sin(0.05 * xs + k) + 0.05 * np.cos(0.07 * ys)).astype(np.float32)
+        d[(xs % 17 == 0) & (ys % 13 == 0)] = 0.0
+        out.append(d)
+    return out

@@ -1,0 +1,90 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle cannot finish these in
+seconds): determinism, value ranges, quality against the analytic scene, and consistency of the
+full-size run with an oracle run on a window whose dependency cone it fully contains."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def _run_full(gpu_pkg, synth, W, H, N, iters, seed=12345):
+    import torch
+    sc = synth.make_scene(W, H, N, seed=0, device="cuda")
+    cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+    p = gpu_pkg.default_params(num_images=N + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0,
+                               state=gpu_pkg.FIRST_INIT, max_iterations=iters, seed=seed)
+    h = gpu_pkg.Handle(W, H, p, device=0)
+    h.upload_views(cams, sc.images)
+    for k in (1, 2, 5):
+        h.run_kernel(k)
+    h.run_sweeps(0, iters)
+    planes = h.state(gpu_pkg.STATE_PLANES)
+    costs = h.state(gpu_pkg.STATE_COSTS)
+    views = h.state(gpu_pkg.STATE_SELECTED_VIEWS)
+    gt = sc.gt_depth.cpu().numpy()
+    K = sc.K[0].astype(np.float64)
+    h.close()
+    del sc
+    torch.cuda.empty_cache()
+    return planes, costs, views, gt, K, p
+
+
+def test_full_size_config1_properties(gpu_pkg, synth):
+    """configs[1] shape: 6200x4130, 8 source views."""
+    W, H, N, iters = 6200, 4130, 8, 2
+    planes, costs, views, gt, K, p = _run_full(gpu_pkg, synth, W, H, N, iters)
+    d1 = _digest([planes, costs, views])
+    # ranges: costs in [0, 2] or NaN (live NaN path, Appendix A #9); bit j of the view mask < N
+    finite = np.isfinite(costs)
+    assert finite.mean() > 0.999
+    assert (costs[finite] >= 0).all() and (costs[finite] <= 2.0).all()
+    assert (views >> N == 0).all()
+    nrm = np.linalg.norm(planes[..., :3].astype(np.float64), axis=-1)
+    assert np.abs(nrm - 1).max() < 1e-3
+    # quality against the analytic scene after 2 sweeps
+    d = common.depth_of_planes(planes[::7, ::7], K) if False else None
+    ys, xs = np.mgrid[0:H:5, 0:W:5]
+    pl = planes[::5, ::5].astype(np.float64)
+    dd = -pl[..., 3] * K[0] / ((xs - K[2]) * pl[..., 0] + (K[0] / K[4]) * (ys - K[5]) * pl[..., 1] + K[0] * pl[..., 2])
+    g = gt[::5, ::5]
+    assert ((np.abs(dd - g) / g)[4:-4, 4:-4] < 0.01).mean() > 0.97
+    # determinism: a second handle with the same seed gives the same bits
+    planes2, costs2, views2, _, _, _ = _run_full(gpu_pkg, synth, W, H, N, iters)
+    assert _digest([planes2, costs2, views2]) == d1
+
+
+def test_full_size_stress_shape_determinism(gpu_pkg, synth):
+    """configs[4] shape: 4096x3072, 16 source views (NMAX = 16 kernel), one sweep."""
+    W, H, N = 4096, 3072, 16
+    a = _run_full(gpu_pkg, synth, W, H, N, 1, seed=99)
+    b = _run_full(gpu_pkg, synth, W, H, N, 1, seed=99)
+    assert _digest(a[:3]) == _digest(b[:3])
+    c = _run_full(gpu_pkg, synth, W, H, N, 1, seed=100)
+    assert _digest(a[:3]) != _digest(c[:3])
+
+
+def test_red_black_independence(gpu_pkg, ob, synth):
+    """Within one colour the processing order must not matter: the XCD-banded tile order of the HIP
+    launch and the row-major order of the oracle give identical bits at a size with many tiles."""
+    W, H, N = 416, 304, 4
+    sc, imgs = common.scene_inputs(synth, W, H, N)
+    p = common.base_params(sc, N, max_iterations=1)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p)
+    o = common.make_oracle(ob, sc, imgs, N, p)
+    for kid in (1, 2, 5, 6, 7):
+        h.run_kernel(kid, 0)
+        o.run_kernel(kid, 0)
+    common.assert_state_equal(gpu_pkg, h, o, "416x304 one sweep", skip=("fit",))
+    h.close()
+    o.close()
