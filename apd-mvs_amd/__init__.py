@@ -70,6 +70,12 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ApdError("HIP library %s is missing: run __graft_entry__.build() first" % LIB_PATH)
+    try:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; if it is going to
+        # be used (streams, device tensors, RCCL) it must be the copy that gets loaded, so import it first.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     H = C.c_void_p
     fpp = C.POINTER(C.c_void_p)

@@ -56,5 +56,36 @@ def build_library(force=False, verbose=False, extra_flags=()):
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_BIN = os.path.join(OUT_DIR, "APD")
+HOST_LIB = os.path.join(OUT_DIR, "libapd_host.so")
+HOST_SOURCES = ["APD.cpp", "jpeg_gray.cpp"]
+
+
+def build_host(force=False, verbose=False):
+    """The C++ drop-in: `_build/APD` (reference CLI) and `_build/libapd_host.so` (file-format helpers)."""
+    build_library()
+    cxx = os.environ.get("CXX", "g++")
+    srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, "APD.h"), os.path.join(HOST_DIR, "main.cpp"), os.path.join(HOST_DIR, "host_capi.cpp"),
+                   os.path.join(HERE, "..", "include", "apd_mi355x.h"), LIB_PATH]
+    common = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+    link = ["-L" + OUT_DIR, "-lapd_mi355x", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + OUT_DIR]
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host build failed:\n" + " ".join(cmd) + "\n" + r.stdout)
+
+    if force or _newer(HOST_BIN, deps):
+        run([cxx] + common + srcs + [os.path.join(HOST_DIR, "main.cpp"), "-o", HOST_BIN] + link)
+    if force or _newer(HOST_LIB, deps):
+        run([cxx] + common + ["-shared"] + srcs + [os.path.join(HOST_DIR, "host_capi.cpp"), "-o", HOST_LIB] + link)
+    return HOST_BIN, HOST_LIB
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,494 @@
+// APD.cpp -- host side of the drop-in `APD` class over the C ABI (see APD.h).
+#include "APD.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height);
+
+// ---------------------------------------------------------------------------------------------
+// file formats (APD.cpp:3-92, 350-354)
+// ---------------------------------------------------------------------------------------------
+
+bool ReadBinMat(const path &mat_path, Mat &mat)
+{
+    std::ifstream in(mat_path, std::ios_base::binary);
+    if (!in) {  // the reference tests in.bad(), which a failed open does not set; here it is an error
+        std::cerr << "Error opening file: " << mat_path << std::endl;
+        return false;
+    }
+    int32_t version = 0, rows = 0, cols = 0, type = 0;
+    in.read((char *)&version, sizeof(int32_t));
+    in.read((char *)&rows, sizeof(int32_t));
+    in.read((char *)&cols, sizeof(int32_t));
+    in.read((char *)&type, sizeof(int32_t));
+    if (version != 1) {
+        std::cerr << "Version error: " << mat_path << std::endl;
+        return false;
+    }
+    if (rows < 0 || cols < 0 || Mat::elemSizeOf(type) == 0) {
+        std::cerr << "Unsupported matrix header in " << mat_path << std::endl;
+        return false;
+    }
+    mat.create(rows, cols, type);
+    in.read((char *)mat.data(), (std::streamsize)(mat.step() * (size_t)mat.rows));
+    return (bool)in;
+}
+
+bool WriteBinMat(const path &mat_path, const Mat &mat)
+{
+    std::ofstream out(mat_path, std::ios_base::binary);
+    if (!out) {
+        std::cout << "Error opening file: " << mat_path << std::endl;
+        return false;
+    }
+    const int32_t version = 1, rows = mat.rows, cols = mat.cols, type = mat.type;
+    out.write((const char *)&version, sizeof(int32_t));
+    out.write((const char *)&rows, sizeof(int32_t));
+    out.write((const char *)&cols, sizeof(int32_t));
+    out.write((const char *)&type, sizeof(int32_t));
+    out.write((const char *)mat.data(), (std::streamsize)(mat.step() * (size_t)mat.rows));
+    return (bool)out;
+}
+
+bool ReadCamera(const path &cam_path, Camera &cam)
+{
+    std::ifstream in(cam_path);
+    if (!in) {
+        return false;
+    }
+    std::string token;
+    in >> token;  // "extrinsic"
+    for (int i = 0; i < 3; ++i) {
+        in >> cam.R[3 * i + 0] >> cam.R[3 * i + 1] >> cam.R[3 * i + 2] >> cam.t[i];
+    }
+    float last_row[4];
+    in >> last_row[0] >> last_row[1] >> last_row[2] >> last_row[3];
+    in >> token;  // "intrinsic"
+    for (int i = 0; i < 3; ++i) {
+        in >> cam.K[3 * i + 0] >> cam.K[3 * i + 1] >> cam.K[3 * i + 2];
+    }
+    // camera centre in world coordinates, evaluated in double (APD.cpp:73-77)
+    for (int j = 0; j < 3; ++j) {
+        cam.c[j] = -float(double(cam.R[0 + j]) * double(cam.t[0]) + double(cam.R[3 + j]) * double(cam.t[1]) +
+                          double(cam.R[6 + j]) * double(cam.t[2]));
+    }
+    // TAT & ETH layout: depth_min interval depth_num depth_max (APD.cpp:80-82)
+    float depth_num = 0, interval = 0;
+    in >> cam.depth_min >> interval >> depth_num >> cam.depth_max;
+    return !in.fail();
+}
+
+std::string ToFormatIndex(int index)
+{
+    std::stringstream ss;
+    ss << std::setw(8) << std::setfill('0') << index;
+    return ss.str();
+}
+
+// Nearest-neighbour resampling of prior state; keeps the reference's swapped scale factors
+// (row / scale_x, column / scale_y; APD.cpp:766-767).
+template <typename TYPE> void RescaleMatToTargetSize(const Mat &src, Mat &dst, int target_width, int target_height)
+{
+    if (src.cols == target_width && src.rows == target_height) {
+        return;
+    }
+    const float scale_x = target_width / static_cast<float>(src.cols);
+    const float scale_y = target_height / static_cast<float>(src.rows);
+    const Mat src_clone = src.clone();
+    Mat out(target_height, target_width, src.type);
+    for (int r = 0; r < target_height; ++r) {
+        for (int c = 0; c < target_width; ++c) {
+            const int o_r = static_cast<int>(r / scale_x);
+            const int o_c = static_cast<int>(c / scale_y);
+            if (o_r < 0 || o_c < 0 || o_r >= src_clone.rows || o_c >= src_clone.cols) {
+                continue;
+            }
+            out.at<TYPE>(r, c) = src_clone.at<TYPE>(o_r, o_c);
+        }
+    }
+    dst = out;
+}
+template void RescaleMatToTargetSize<float>(const Mat &, Mat &, int, int);
+template void RescaleMatToTargetSize<uint8_t>(const Mat &, Mat &, int, int);
+template void RescaleMatToTargetSize<uint32_t>(const Mat &, Mat &, int, int);
+template void RescaleMatToTargetSize<Vec3f>(const Mat &, Mat &, int, int);
+
+// ---------------------------------------------------------------------------------------------
+// images
+// ---------------------------------------------------------------------------------------------
+
+static bool read_file(const path &p, std::vector<uint8_t> &bytes)
+{
+    std::ifstream in(p, std::ios_base::binary);
+    if (!in) {
+        return false;
+    }
+    in.seekg(0, std::ios_base::end);
+    const std::streamoff n = in.tellg();
+    in.seekg(0, std::ios_base::beg);
+    bytes.resize((size_t)n);
+    in.read((char *)bytes.data(), n);
+    return (bool)in;
+}
+
+static bool read_pgm(const std::vector<uint8_t> &b, Mat &out)
+{
+    // binary PGM "P5 <w> <h> <maxval>\n<data>", 8 bit
+    size_t pos = 0;
+    auto token = [&]() {
+        std::string t;
+        while (pos < b.size()) {
+            if (b[pos] == '#') {
+                while (pos < b.size() && b[pos] != '\n') {
+                    ++pos;
+                }
+            } else if (isspace(b[pos])) {
+                ++pos;
+            } else {
+                break;
+            }
+        }
+        while (pos < b.size() && !isspace(b[pos])) {
+            t.push_back((char)b[pos++]);
+        }
+        return t;
+    };
+    if (token() != "P5") {
+        return false;
+    }
+    const int w = atoi(token().c_str()), h = atoi(token().c_str()), maxval = atoi(token().c_str());
+    ++pos;  // single whitespace after maxval
+    if (w <= 0 || h <= 0 || maxval != 255 || pos + (size_t)w * h > b.size()) {
+        return false;
+    }
+    out.create(h, w, MAT_32FC1);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        out.ptr<float>()[i] = (float)b[pos + i];
+    }
+    return true;
+}
+
+bool ReadGrayImage(const path &stem, Mat &image_float)
+{
+    std::vector<uint8_t> bytes;
+    path p = stem;
+    p += ".jpg";
+    if (read_file(p, bytes)) {
+        std::vector<uint8_t> gray;
+        int w = 0, h = 0;
+        if (!DecodeJpegGray(bytes.data(), bytes.size(), gray, w, h)) {
+            std::cerr << "Unsupported JPEG (only baseline sequential Huffman is built): " << p << std::endl;
+            return false;
+        }
+        image_float.create(h, w, MAT_32FC1);  // image_uint.convertTo(image_float, CV_32FC1), APD.cpp:411-413
+        for (size_t i = 0; i < gray.size(); ++i) {
+            image_float.ptr<float>()[i] = (float)gray[i];
+        }
+        return true;
+    }
+    p = stem;
+    p += ".pgm";
+    if (read_file(p, bytes)) {
+        return read_pgm(bytes, image_float);
+    }
+    std::cerr << "Can't read image: " << stem << ".{jpg,pgm}" << std::endl;
+    return false;
+}
+
+// cv::resize(src, dst, Size(new_cols, new_rows), 0, 0, INTER_LINEAR) on a float image:
+// fx = (dx + 0.5) * (src/dst) - 0.5, taps floor(fx) and floor(fx)+1 clamped, float weights.
+void ResizeLinear(const Mat &src, Mat &dst, int new_cols, int new_rows)
+{
+    Mat out(new_rows, new_cols, MAT_32FC1);
+    const double sx = (double)src.cols / new_cols, sy = (double)src.rows / new_rows;
+    std::vector<int> x0(new_cols), x1(new_cols);
+    std::vector<float> ax(new_cols);
+    for (int dx = 0; dx < new_cols; ++dx) {
+        float fx = (float)((dx + 0.5) * sx - 0.5);
+        int ix = (int)std::floor(fx);
+        fx -= ix;
+        if (ix < 0) {
+            ix = 0;
+            fx = 0;
+        }
+        if (ix >= src.cols - 1) {
+            ix = src.cols - 1;
+            fx = 0;
+        }
+        x0[dx] = ix;
+        x1[dx] = ix + 1 < src.cols ? ix + 1 : ix;
+        ax[dx] = fx;
+    }
+    for (int dy = 0; dy < new_rows; ++dy) {
+        float fy = (float)((dy + 0.5) * sy - 0.5);
+        int iy = (int)std::floor(fy);
+        fy -= iy;
+        if (iy < 0) {
+            iy = 0;
+            fy = 0;
+        }
+        if (iy >= src.rows - 1) {
+            iy = src.rows - 1;
+            fy = 0;
+        }
+        const float *r0 = src.ptr<float>(iy);
+        const float *r1 = src.ptr<float>(iy + 1 < src.rows ? iy + 1 : iy);
+        float *o = out.ptr<float>(dy);
+        for (int dx = 0; dx < new_cols; ++dx) {
+            const float a = ax[dx];
+            const float top = r0[x0[dx]] * (1.f - a) + r0[x1[dx]] * a;
+            const float bot = r1[x0[dx]] * (1.f - a) + r1[x1[dx]] * a;
+            o[dx] = top * (1.f - fy) + bot * fy;
+        }
+    }
+    dst = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// class APD
+// ---------------------------------------------------------------------------------------------
+
+static int g_device = -1;
+void APD::SetDevice(int device) { g_device = device; }
+
+static void ApdSafeCall(int rc, const char *what)
+{
+    if (rc != APD_OK) {  // reference: CudaSafeCall -> print + exit (APD.cpp:315-323)
+        std::cerr << what << " failed: " << apd_last_error() << std::endl;
+        exit(EXIT_FAILURE);
+    }
+}
+
+APD::APD(const Problem &problem)
+{
+    params_host = problem.params;
+    this->problem = problem;
+}
+
+APD::~APD()
+{
+    if (handle) {
+        apd_destroy(handle);
+    }
+}
+
+void APD::InuputInitialization()
+{
+    images.clear();
+    cameras.clear();
+    const path image_folder = problem.dense_folder / path("images");
+    const path cam_folder = problem.dense_folder / path("cams");
+    // reference image then source images (APD.cpp:409-427)
+    std::vector<int> ids;
+    ids.push_back(problem.ref_image_id);
+    for (int id : problem.src_image_ids) {
+        ids.push_back(id);
+    }
+    for (size_t i = 0; i < ids.size(); ++i) {
+        Mat image_float;
+        if (!ReadGrayImage(image_folder / path(ToFormatIndex(ids[i])), image_float)) {
+            exit(EXIT_FAILURE);
+        }
+        if (i == 0) {
+            width = image_float.cols;
+            height = image_float.rows;
+        }
+        images.push_back(image_float);
+    }
+    if (images.size() > MAX_IMAGES) {
+        std::cerr << "Can't process so much images: " << images.size() << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    for (size_t i = 0; i < ids.size(); ++i) {
+        Camera cam;
+        memset(&cam, 0, sizeof(cam));
+        if (!ReadCamera(cam_folder / path(ToFormatIndex(ids[i]) + "_cam.txt"), cam)) {
+            std::cerr << "Can't read camera " << ids[i] << std::endl;
+            exit(EXIT_FAILURE);
+        }
+        cam.width = width;
+        cam.height = height;
+        cameras.push_back(cam);
+    }
+    params_host.depth_min = cameras[0].depth_min * 0.6f;
+    params_host.depth_max = cameras[0].depth_max * 1.2f;
+    params_host.num_images = (int)images.size();
+    num_images = (int)images.size();
+    std::cout << "Read images and camera done\n";
+    std::cout << "Depth range: " << params_host.depth_min << " " << params_host.depth_max << std::endl;
+    std::cout << "Num images: " << params_host.num_images << std::endl;
+    // scale images and intrinsics (APD.cpp:464-488)
+    if (problem.scale_size != 1) {
+        for (int i = 0; i < num_images; ++i) {
+            const float factor = 1.0f / (float)(problem.scale_size);
+            const int new_cols = (int)std::round(images[i].cols * factor);
+            const int new_rows = (int)std::round(images[i].rows * factor);
+            const float scale_x = new_cols / static_cast<float>(images[i].cols);
+            const float scale_y = new_rows / static_cast<float>(images[i].rows);
+            Mat scaled;
+            ResizeLinear(images[i], scaled, new_cols, new_rows);
+            images[i] = scaled;
+            width = scaled.cols;
+            height = scaled.rows;
+            cameras[i].K[0] *= scale_x;
+            cameras[i].K[2] *= scale_x;
+            cameras[i].K[4] *= scale_y;
+            cameras[i].K[5] *= scale_y;
+            cameras[i].width = width;
+            cameras[i].height = height;
+        }
+        std::cout << "Scale images and cameras done\n";
+    }
+    std::cout << "Image size: " << width << " * " << height << std::endl;
+    // depth maps of the previous pass for the geometric term (APD.cpp:492-510)
+    depths.clear();
+    if (params_host.geom_consistency) {
+        Mat ref_depth;
+        ReadBinMat(problem.result_folder / path("depths.dmb"), ref_depth);
+        depths.push_back(ref_depth);
+        for (int src_idx : problem.src_image_ids) {
+            Mat src_depth;
+            ReadBinMat(problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx)) / path("depths.dmb"), src_depth);
+            depths.push_back(src_depth);
+        }
+        for (auto &depth : depths) {
+            if (depth.empty()) {
+                std::cerr << "Missing depth map of a previous pass\n";
+                exit(EXIT_FAILURE);
+            }
+            if (depth.cols != width || depth.rows != height) {
+                RescaleMatToTargetSize<float>(depth, depth, width, height);
+            }
+        }
+    }
+    // weak map (APD.cpp:513-548)
+    if (params_host.use_APD) {
+        const path weak_info_path = problem.result_folder / path("weak.bin");
+        if (!std::filesystem::exists(weak_info_path)) {
+            std::cerr << "Can't find weak info file: " << weak_info_path.string() << std::endl;
+            exit(EXIT_FAILURE);
+        }
+        ReadBinMat(weak_info_path, weak_info_host);
+        if (weak_info_host.cols != width || weak_info_host.rows != height) {
+            std::cerr << "Weak info doesn't match the images' size!\n";
+            RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
+            std::cout << "Scale done\n";
+        }
+        weak_count = 0;
+        for (int r = 0; r < height; ++r) {
+            for (int c = 0; c < width; ++c) {
+                if (weak_info_host.at<uint8_t>(r, c) == WEAK) {
+                    weak_count++;
+                }
+            }
+        }
+        std::cout << "Weak count: " << weak_count << " / " << width * height << " = "
+                  << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
+    } else {
+        weak_info_host.create(height, width, MAT_8UC1);
+        memset(weak_info_host.data(), STRONG, (size_t)width * height);
+        weak_count = 0;
+    }
+    plane_hypotheses_host.assign((size_t)width * height, float4{0, 0, 0, 0});
+    selected_views_host.create(height, width, MAT_32SC1);
+    has_prior = false;
+    if (params_host.state != FIRST_INIT) {  // APD.cpp:552-581
+        Mat depth, normal;
+        ReadBinMat(problem.result_folder / path("depths.dmb"), depth);
+        ReadBinMat(problem.result_folder / path("normals.dmb"), normal);
+        if (depth.empty() || normal.empty()) {
+            std::cerr << "Missing depths.dmb / normals.dmb of a previous pass\n";
+            exit(EXIT_FAILURE);
+        }
+        if (depth.cols != width || depth.rows != height || normal.cols != width || normal.rows != height) {
+            std::cerr << "Depth and Normal doesn't match the images' size!\n";
+            RescaleMatToTargetSize<float>(depth, depth, width, height);
+            RescaleMatToTargetSize<Vec3f>(normal, normal, width, height);
+        }
+        for (int row = 0; row < height; ++row) {
+            for (int col = 0; col < width; ++col) {
+                float4 &p = plane_hypotheses_host[(size_t)row * width + col];
+                const Vec3f &n = normal.at<Vec3f>(row, col);
+                p.w = depth.at<float>(row, col);
+                p.x = n[0];
+                p.y = n[1];
+                p.z = n[2];
+            }
+        }
+        ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
+        if (selected_views_host.cols != width || selected_views_host.rows != height) {
+            std::cerr << "Select view doesn't match the images' size!\n";
+            RescaleMatToTargetSize<uint32_t>(selected_views_host, selected_views_host, width, height);
+        }
+        has_prior = true;
+    }
+}
+
+void APD::CudaSpaceInitialization()
+{
+    apd_params p;
+    apd_default_params(&p);
+    p.max_iterations = params_host.max_iterations;
+    p.num_images = params_host.num_images;
+    p.sigma_spatial = params_host.sigma_spatial;
+    p.sigma_color = params_host.sigma_color;
+    p.top_k = params_host.top_k;
+    p.depth_min = params_host.depth_min;
+    p.depth_max = params_host.depth_max;
+    p.geom_consistency = params_host.geom_consistency ? 1 : 0;
+    p.strong_radius = params_host.strong_radius;
+    p.strong_increment = params_host.strong_increment;
+    p.weak_radius = params_host.weak_radius;
+    p.weak_increment = params_host.weak_increment;
+    p.use_APD = params_host.use_APD ? 1 : 0;
+    p.weak_peak_radius = params_host.weak_peak_radius;
+    p.rotate_time = params_host.rotate_time;
+    p.ransac_threshold = params_host.ransac_threshold;
+    p.geom_factor = params_host.geom_factor;
+    p.state = (int)params_host.state;
+    p.seed = params_host.seed;
+    ApdSafeCall(apd_create(&handle, g_device, width, height, &p), "apd_create");
+    std::vector<const float *> img_ptrs, depth_ptrs;
+    for (auto &im : images) {
+        img_ptrs.push_back(im.ptr<float>());
+    }
+    for (auto &d : depths) {
+        depth_ptrs.push_back(d.ptr<float>());
+    }
+    ApdSafeCall(apd_upload_views(handle, num_images, cameras.data(), img_ptrs.data(), depths.empty() ? nullptr : depth_ptrs.data()),
+                "apd_upload_views");
+    if (has_prior || params_host.use_APD) {
+        ApdSafeCall(apd_upload_prior(handle, has_prior ? &plane_hypotheses_host[0].x : nullptr,
+                                     has_prior ? selected_views_host.ptr<uint32_t>() : nullptr,
+                                     params_host.use_APD ? weak_info_host.ptr<uint8_t>() : nullptr),
+                    "apd_upload_prior");
+    }
+}
+
+void APD::SetDataPassHelperInCuda()
+{
+    // The reference fills a DataPassHelper of raw device pointers here (APD.cpp:673-699); the C ABI
+    // builds its kernel argument block inside apd_upload_views / apd_upload_prior.
+}
+
+void APD::RunPatchMatch()
+{
+    ApdSafeCall(apd_run(handle), "apd_run");
+    // APD.cu:2490-2492
+    ApdSafeCall(apd_download(handle, &plane_hypotheses_host[0].x, weak_info_host.ptr<uint8_t>(), selected_views_host.ptr<uint32_t>()),
+                "apd_download");
+}
+
+float4 APD::GetPlaneHypothesis(int r, int c) { return plane_hypotheses_host[(size_t)c + (size_t)r * width]; }
+Mat APD::GetPixelStates() { return weak_info_host; }
+Mat APD::GetSelectedViews() { return selected_views_host; }
+int APD::GetWidth() { return width; }
+int APD::GetHeight() { return height; }
+float APD::GetDepthMin() { return params_host.depth_min; }
+float APD::GetDepthMax() { return params_host.depth_max; }

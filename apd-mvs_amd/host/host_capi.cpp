@@ -1,0 +1,81 @@
+// host_capi.cpp -- flat C entry points over the host-side file-format helpers, so the Python tests
+// can exercise ReadBinMat / WriteBinMat / ReadCamera / image decode / resampling without a GPU.
+#include <cstring>
+
+#include "APD.h"
+
+bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height);
+
+extern "C" {
+
+// returns 0 on success; *type gets the OpenCV type code; data copied into `out` (cap bytes)
+int apdhost_read_bin_mat(const char *p, int *rows, int *cols, int *type, void *out, size_t cap)
+{
+    Mat m;
+    if (!ReadBinMat(path(p), m)) {
+        return -1;
+    }
+    *rows = m.rows;
+    *cols = m.cols;
+    *type = m.type;
+    const size_t n = m.step() * (size_t)m.rows;
+    if (out && n <= cap) {
+        memcpy(out, m.data(), n);
+    }
+    return 0;
+}
+
+int apdhost_write_bin_mat(const char *p, int rows, int cols, int type, const void *data)
+{
+    Mat m(rows, cols, type);
+    memcpy(m.data(), data, m.step() * (size_t)rows);
+    return WriteBinMat(path(p), m) ? 0 : -1;
+}
+
+int apdhost_read_camera(const char *p, apd_camera *cam)
+{
+    memset(cam, 0, sizeof(*cam));
+    return ReadCamera(path(p), *cam) ? 0 : -1;
+}
+
+int apdhost_read_gray_image(const char *stem, int *rows, int *cols, float *out, size_t cap_floats)
+{
+    Mat m;
+    if (!ReadGrayImage(path(stem), m)) {
+        return -1;
+    }
+    *rows = m.rows;
+    *cols = m.cols;
+    if (out && (size_t)m.rows * m.cols <= cap_floats) {
+        memcpy(out, m.data(), (size_t)m.rows * m.cols * sizeof(float));
+    }
+    return 0;
+}
+
+int apdhost_resize_linear(const float *src, int rows, int cols, float *dst, int new_rows, int new_cols)
+{
+    Mat s(rows, cols, MAT_32FC1), d;
+    memcpy(s.data(), src, (size_t)rows * cols * sizeof(float));
+    ResizeLinear(s, d, new_cols, new_rows);
+    memcpy(dst, d.data(), (size_t)new_rows * new_cols * sizeof(float));
+    return 0;
+}
+
+int apdhost_rescale_nearest_f32(const float *src, int rows, int cols, float *dst, int new_rows, int new_cols)
+{
+    Mat s(rows, cols, MAT_32FC1), d;
+    memcpy(s.data(), src, (size_t)rows * cols * sizeof(float));
+    d = s;
+    RescaleMatToTargetSize<float>(s, d, new_cols, new_rows);
+    memcpy(dst, d.data(), (size_t)new_rows * new_cols * sizeof(float));
+    return 0;
+}
+
+const char *apdhost_format_index(int index)
+{
+    static thread_local std::string s;
+    s = ToFormatIndex(index);
+    return s.c_str();
+}
+
+}  // extern "C"

@@ -1,0 +1,476 @@
+// jpeg_gray.cpp -- dependency-free baseline JPEG decoder that returns the LUMA plane as 8-bit grey.
+//
+// The reference reads `images/%08d.jpg` with cv::imread(IMREAD_GRAYSCALE) (APD.cpp:410-427), i.e.
+// libjpeg decoding straight to one channel: the Y component of a YCbCr file, no RGB round trip
+// (SURVEY.md Appendix E).  Neither OpenCV nor libjpeg headers exist in this image, so this file
+// restates the published algorithm: ITU-T T.81 baseline sequential Huffman decoding + the
+// "islow" accurate integer inverse DCT (Loeffler-Ligtenberg-Moschytz, 13-bit constants) that libjpeg
+// uses by default.  Chroma blocks are entropy-decoded (to keep the bit stream in step) and dropped.
+// Supported: SOF0/SOF1 8-bit, 1 or 3 components, any sampling factors, restart intervals.
+// Not supported (returns false): progressive (SOF2), arithmetic coding, 12-bit.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct HuffTable {
+    // canonical Huffman decoding tables (T.81 Annex F.2.2.3)
+    int mincode[17], maxcode[18], valptr[17];
+    uint8_t vals[256];
+    bool present = false;
+};
+
+struct Component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int dc_pred = 0;
+};
+
+struct BitReader {
+    const uint8_t *p, *end;
+    uint32_t acc = 0;
+    int bits = 0;
+    bool hit_marker = false;
+
+    void fill()
+    {
+        while (bits <= 24) {
+            int b = 0;
+            if (!hit_marker && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    int b2 = (p < end) ? *p : 0xD9;
+                    if (b2 == 0x00) {
+                        ++p;  // stuffed zero
+                    } else {
+                        --p;  // a marker: feed zeros from here on
+                        hit_marker = true;
+                        b = 0;
+                    }
+                }
+            }
+            acc |= (uint32_t)b << (24 - bits);
+            bits += 8;
+        }
+    }
+    int get_bit()
+    {
+        if (bits < 1) {
+            fill();
+        }
+        const int v = (int)(acc >> 31);
+        acc <<= 1;
+        --bits;
+        return v;
+    }
+    int get_bits(int n)
+    {
+        if (n == 0) {
+            return 0;
+        }
+        if (bits < n) {
+            fill();
+        }
+        const int v = (int)(acc >> (32 - n));
+        acc <<= n;
+        bits -= n;
+        return v;
+    }
+    void reset()
+    {
+        acc = 0;
+        bits = 0;
+        hit_marker = false;
+    }
+};
+
+const int kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+bool build_huff(HuffTable &t, const uint8_t counts[16], const uint8_t *vals, int nvals)
+{
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        t.valptr[l] = k;
+        t.mincode[l] = code;
+        code += counts[l - 1];
+        k += counts[l - 1];
+        t.maxcode[l] = counts[l - 1] ? code - 1 : -1;
+        code <<= 1;
+    }
+    t.maxcode[17] = 0x7fffffff;
+    if (k != nvals || nvals > 256) {
+        return false;
+    }
+    memcpy(t.vals, vals, (size_t)nvals);
+    t.present = true;
+    return true;
+}
+
+int decode_symbol(BitReader &br, const HuffTable &t)
+{
+    int code = br.get_bit();
+    int l = 1;
+    while (l <= 16 && (t.maxcode[l] < 0 || code > t.maxcode[l])) {
+        code = (code << 1) | br.get_bit();
+        ++l;
+    }
+    if (l > 16) {
+        return -1;
+    }
+    return t.vals[t.valptr[l] + code - t.mincode[l]];
+}
+
+inline int extend(int v, int n) { return (n && v < (1 << (n - 1))) ? v - (1 << n) + 1 : v; }
+
+// libjpeg "islow" inverse DCT: CONST_BITS = 13, PASS1_BITS = 2; coefficients already dequantised.
+void idct_islow(const int *coef, uint8_t *out, int stride)
+{
+    const int FIX_0_298631336 = 2446, FIX_0_390180644 = 3196, FIX_0_541196100 = 4433, FIX_0_765366865 = 6270,
+              FIX_0_899976223 = 7373, FIX_1_175875602 = 9633, FIX_1_501321110 = 12299, FIX_1_847759065 = 15137,
+              FIX_1_961570560 = 16069, FIX_2_053119869 = 16819, FIX_2_562915447 = 20995, FIX_3_072711026 = 25172;
+    const int CONST_BITS = 13, PASS1_BITS = 2;
+    long ws[64];
+    auto descale = [](long x, int n) { return (x + (1L << (n - 1))) >> n; };
+    for (int c = 0; c < 8; ++c) {  // columns
+        const int *in = coef + c;
+        if (in[8] == 0 && in[16] == 0 && in[24] == 0 && in[32] == 0 && in[40] == 0 && in[48] == 0 && in[56] == 0) {
+            const long dc = (long)in[0] << PASS1_BITS;
+            for (int r = 0; r < 8; ++r) {
+                ws[r * 8 + c] = dc;
+            }
+            continue;
+        }
+        long z2 = in[16], z3 = in[48];
+        long z1 = (z2 + z3) * FIX_0_541196100;
+        long tmp2 = z1 + z3 * (-FIX_1_847759065);
+        long tmp3 = z1 + z2 * FIX_0_765366865;
+        z2 = in[0];
+        z3 = in[32];
+        long tmp0 = (z2 + z3) << CONST_BITS;
+        long tmp1 = (z2 - z3) << CONST_BITS;
+        long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = in[56];
+        tmp1 = in[40];
+        tmp2 = in[24];
+        tmp3 = in[8];
+        z1 = tmp0 + tmp3;
+        z2 = tmp1 + tmp2;
+        z3 = tmp0 + tmp2;
+        long z4 = tmp1 + tmp3;
+        long z5 = (z3 + z4) * FIX_1_175875602;
+        tmp0 *= FIX_0_298631336;
+        tmp1 *= FIX_2_053119869;
+        tmp2 *= FIX_3_072711026;
+        tmp3 *= FIX_1_501321110;
+        z1 *= -FIX_0_899976223;
+        z2 *= -FIX_2_562915447;
+        z3 *= -FIX_1_961570560;
+        z4 *= -FIX_0_390180644;
+        z3 += z5;
+        z4 += z5;
+        tmp0 += z1 + z3;
+        tmp1 += z2 + z4;
+        tmp2 += z2 + z3;
+        tmp3 += z1 + z4;
+        ws[0 * 8 + c] = descale(tmp10 + tmp3, CONST_BITS - PASS1_BITS);
+        ws[7 * 8 + c] = descale(tmp10 - tmp3, CONST_BITS - PASS1_BITS);
+        ws[1 * 8 + c] = descale(tmp11 + tmp2, CONST_BITS - PASS1_BITS);
+        ws[6 * 8 + c] = descale(tmp11 - tmp2, CONST_BITS - PASS1_BITS);
+        ws[2 * 8 + c] = descale(tmp12 + tmp1, CONST_BITS - PASS1_BITS);
+        ws[5 * 8 + c] = descale(tmp12 - tmp1, CONST_BITS - PASS1_BITS);
+        ws[3 * 8 + c] = descale(tmp13 + tmp0, CONST_BITS - PASS1_BITS);
+        ws[4 * 8 + c] = descale(tmp13 - tmp0, CONST_BITS - PASS1_BITS);
+    }
+    for (int r = 0; r < 8; ++r) {  // rows
+        const long *w = ws + r * 8;
+        long z2 = w[2], z3 = w[6];
+        long z1 = (z2 + z3) * FIX_0_541196100;
+        long tmp2 = z1 + z3 * (-FIX_1_847759065);
+        long tmp3 = z1 + z2 * FIX_0_765366865;
+        long tmp0 = (w[0] + w[4]) << CONST_BITS;
+        long tmp1 = (w[0] - w[4]) << CONST_BITS;
+        long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = w[7];
+        tmp1 = w[5];
+        tmp2 = w[3];
+        tmp3 = w[1];
+        z1 = tmp0 + tmp3;
+        z2 = tmp1 + tmp2;
+        z3 = tmp0 + tmp2;
+        long z4 = tmp1 + tmp3;
+        long z5 = (z3 + z4) * FIX_1_175875602;
+        tmp0 *= FIX_0_298631336;
+        tmp1 *= FIX_2_053119869;
+        tmp2 *= FIX_3_072711026;
+        tmp3 *= FIX_1_501321110;
+        z1 *= -FIX_0_899976223;
+        z2 *= -FIX_2_562915447;
+        z3 *= -FIX_1_961570560;
+        z4 *= -FIX_0_390180644;
+        z3 += z5;
+        z4 += z5;
+        tmp0 += z1 + z3;
+        tmp1 += z2 + z4;
+        tmp2 += z2 + z3;
+        tmp3 += z1 + z4;
+        const int sh = CONST_BITS + PASS1_BITS + 3;
+        auto put = [&](int c, long v) {
+            long s = descale(v, sh) + 128;
+            out[r * stride + c] = (uint8_t)(s < 0 ? 0 : (s > 255 ? 255 : s));
+        };
+        put(0, tmp10 + tmp3);
+        put(7, tmp10 - tmp3);
+        put(1, tmp11 + tmp2);
+        put(6, tmp11 - tmp2);
+        put(2, tmp12 + tmp1);
+        put(5, tmp12 - tmp1);
+        put(3, tmp13 + tmp0);
+        put(4, tmp13 - tmp0);
+    }
+}
+
+inline int be16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
+
+}  // namespace
+
+// Decodes `data` (a whole .jpg file) to grey; returns false on unsupported / corrupt input.
+bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height)
+{
+    if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) {
+        return false;
+    }
+    uint16_t qt[4][64];
+    bool qt_present[4] = {false, false, false, false};
+    HuffTable dc[4], ac[4];
+    Component comp[4];
+    int ncomp = 0, restart_interval = 0;
+    int hmax = 1, vmax = 1;
+    bool have_sof = false;
+    size_t pos = 2;
+    while (pos + 4 <= size) {
+        if (data[pos] != 0xFF) {
+            ++pos;
+            continue;
+        }
+        const int marker = data[pos + 1];
+        pos += 2;
+        if (marker == 0xD8 || marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7) || marker == 0xFF) {
+            if (marker == 0xFF) {
+                --pos;
+            }
+            continue;
+        }
+        if (marker == 0xD9) {
+            break;
+        }
+        if (pos + 2 > size) {
+            return false;
+        }
+        const int len = be16(data + pos);
+        if (len < 2 || pos + len > size) {
+            return false;
+        }
+        const uint8_t *seg = data + pos + 2;
+        const int seglen = len - 2;
+        if (marker == 0xDB) {  // DQT
+            int i = 0;
+            while (i < seglen) {
+                const int pq = seg[i] >> 4, tq = seg[i] & 15;
+                ++i;
+                if (tq > 3 || i + (pq ? 128 : 64) > seglen) {
+                    return false;
+                }
+                for (int k = 0; k < 64; ++k) {
+                    qt[tq][kZigZag[k]] = pq ? (uint16_t)be16(seg + i + 2 * k) : seg[i + k];
+                }
+                i += pq ? 128 : 64;
+                qt_present[tq] = true;
+            }
+        } else if (marker == 0xC4) {  // DHT
+            int i = 0;
+            while (i + 17 <= seglen) {
+                const int tc = seg[i] >> 4, th = seg[i] & 15;
+                int n = 0;
+                for (int k = 0; k < 16; ++k) {
+                    n += seg[i + 1 + k];
+                }
+                if (th > 3 || tc > 1 || i + 17 + n > seglen) {
+                    return false;
+                }
+                if (!build_huff(tc ? ac[th] : dc[th], seg + i + 1, seg + i + 17, n)) {
+                    return false;
+                }
+                i += 17 + n;
+            }
+        } else if (marker == 0xC0 || marker == 0xC1) {  // SOF0 / SOF1
+            if (seglen < 6 || seg[0] != 8) {
+                return false;
+            }
+            height = be16(seg + 1);
+            width = be16(seg + 3);
+            ncomp = seg[5];
+            if ((ncomp != 1 && ncomp != 3) || seglen < 6 + 3 * ncomp || width <= 0 || height <= 0) {
+                return false;
+            }
+            for (int c = 0; c < ncomp; ++c) {
+                comp[c].id = seg[6 + 3 * c];
+                comp[c].h = seg[7 + 3 * c] >> 4;
+                comp[c].v = seg[7 + 3 * c] & 15;
+                comp[c].tq = seg[8 + 3 * c];
+                if (comp[c].h < 1 || comp[c].v < 1 || comp[c].tq > 3) {
+                    return false;
+                }
+                hmax = comp[c].h > hmax ? comp[c].h : hmax;
+                vmax = comp[c].v > vmax ? comp[c].v : vmax;
+            }
+            have_sof = true;
+        } else if (marker >= 0xC2 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) {
+            return false;  // progressive / lossless / arithmetic: not built
+        } else if (marker == 0xDD) {  // DRI
+            if (seglen < 2) {
+                return false;
+            }
+            restart_interval = be16(seg);
+        } else if (marker == 0xDA) {  // SOS: baseline has a single interleaved scan (or one per component)
+            if (!have_sof || seglen < 1) {
+                return false;
+            }
+            const int ns = seg[0];
+            if (ns < 1 || ns > ncomp || seglen < 1 + 2 * ns + 3) {
+                return false;
+            }
+            int scan_comp[4];
+            for (int s = 0; s < ns; ++s) {
+                int ci = -1;
+                for (int c = 0; c < ncomp; ++c) {
+                    if (comp[c].id == seg[1 + 2 * s]) {
+                        ci = c;
+                    }
+                }
+                if (ci < 0) {
+                    return false;
+                }
+                comp[ci].td = seg[2 + 2 * s] >> 4;
+                comp[ci].ta = seg[2 + 2 * s] & 15;
+                scan_comp[s] = ci;
+            }
+            pos += len;
+            // luma plane padded to whole MCUs
+            const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
+            const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
+            const int yc = 0;  // component 0 is Y by JFIF convention
+            const int plane_w = mcus_x * comp[yc].h * 8, plane_h = mcus_y * comp[yc].v * 8;
+            static thread_local std::vector<uint8_t> plane;
+            if (plane.size() != (size_t)plane_w * plane_h) {
+                plane.assign((size_t)plane_w * plane_h, 0);
+            }
+            BitReader br{data + pos, data + size};
+            for (int c = 0; c < ncomp; ++c) {
+                comp[c].dc_pred = 0;
+            }
+            int restart_count = 0;
+            const bool interleaved = ns > 1;
+            int blocks_x = 0, blocks_y = 0;
+            if (!interleaved) {  // non-interleaved scan of one component: its own block raster
+                const Component &cc = comp[scan_comp[0]];
+                blocks_x = ((width * cc.h + hmax - 1) / hmax + 7) / 8;
+                blocks_y = ((height * cc.v + vmax - 1) / vmax + 7) / 8;
+            }
+            const int units = interleaved ? mcus_x * mcus_y : blocks_x * blocks_y;
+            int coef[64];
+            for (int u = 0; u < units; ++u) {
+                if (restart_interval && u > 0 && (u % restart_interval) == 0) {
+                    // align to the RSTn marker
+                    br.reset();
+                    const uint8_t *q = br.p;
+                    while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) {
+                        ++q;
+                    }
+                    if (q + 1 >= br.end) {
+                        return false;
+                    }
+                    br.p = q + 2;
+                    for (int c = 0; c < ncomp; ++c) {
+                        comp[c].dc_pred = 0;
+                    }
+                    ++restart_count;
+                }
+                for (int s = 0; s < ns; ++s) {
+                    Component &cc = comp[scan_comp[s]];
+                    const int nbh = interleaved ? cc.h : 1, nbv = interleaved ? cc.v : 1;
+                    if (!dc[cc.td].present || !ac[cc.ta].present || !qt_present[cc.tq]) {
+                        return false;
+                    }
+                    for (int by = 0; by < nbv; ++by) {
+                        for (int bx = 0; bx < nbh; ++bx) {
+                            memset(coef, 0, sizeof(coef));
+                            int t = decode_symbol(br, dc[cc.td]);
+                            if (t < 0 || t > 11) {
+                                return false;
+                            }
+                            cc.dc_pred += extend(br.get_bits(t), t);
+                            coef[0] = cc.dc_pred * qt[cc.tq][0];
+                            for (int k = 1; k < 64;) {
+                                const int rs = decode_symbol(br, ac[cc.ta]);
+                                if (rs < 0) {
+                                    return false;
+                                }
+                                const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) {
+                                    if (r == 15) {
+                                        k += 16;
+                                        continue;
+                                    }
+                                    break;  // EOB
+                                }
+                                k += r;
+                                if (k > 63) {
+                                    return false;
+                                }
+                                coef[kZigZag[k]] = extend(br.get_bits(sz), sz) * qt[cc.tq][kZigZag[k]];
+                                ++k;
+                            }
+                            if (scan_comp[s] == yc) {
+                                int px, py;
+                                if (interleaved) {
+                                    px = ((u % mcus_x) * cc.h + bx) * 8;
+                                    py = ((u / mcus_x) * cc.v + by) * 8;
+                                } else {
+                                    px = (u % blocks_x) * 8;
+                                    py = (u / blocks_x) * 8;
+                                }
+                                if (px + 8 <= plane_w && py + 8 <= plane_h) {
+                                    idct_islow(coef, &plane[(size_t)py * plane_w + px], plane_w);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            (void)restart_count;
+            // continue parsing after the entropy-coded segment (further scans of a non-interleaved file)
+            const uint8_t *q = br.p;
+            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0x00 && !(q[1] >= 0xD0 && q[1] <= 0xD7))) {
+                ++q;
+            }
+            pos = (size_t)(q - data);
+            bool luma_done = false;
+            for (int s = 0; s < ns; ++s) {
+                luma_done |= scan_comp[s] == yc;
+            }
+            if (luma_done) {
+                gray.resize((size_t)width * height);
+                for (int y = 0; y < height; ++y) {
+                    memcpy(&gray[(size_t)y * width], &plane[(size_t)y * plane_w], (size_t)width);
+                }
+                return true;
+            }
+            continue;
+        }
+        pos += len;
+    }
+    return false;
+}

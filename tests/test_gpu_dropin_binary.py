@@ -1,0 +1,129 @@
+"""The C++ drop-in binary (`_build/APD dense_folder gpu`) against the same 4-pass schedule driven from
+Python through the C ABI: same on-disk inputs, same seeds -> identical depths.dmb / normals.dmb /
+weak.bin / selected_views.bin, bit for bit.  Exercises pair.txt / cam / image / .dmb I/O, the per-pass
+parameters of main.cpp:168-215 and the Gauss-Seidel exchange of depth maps between views."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+APD_BIN = os.path.join(ROOT, "apd-mvs_amd", "_build", "APD")
+
+
+def _write_dense_folder(tmp, synth, W, H, nviews, jpeg=False):
+    (tmp / "images").mkdir()
+    (tmp / "cams").mkdir()
+    sc = synth.make_scene(W, H, nviews - 1, seed=4)
+    imgs = sc.images_numpy()
+    for i in range(nviews):
+        a = imgs[i].astype(np.uint8)
+        if jpeg:
+            from PIL import Image
+            Image.fromarray(a, "L").save(tmp / "images" / ("%08d.jpg" % i), quality=95)
+        else:
+            (tmp / "images" / ("%08d.pgm" % i)).write_bytes(b"P5\n%d %d\n255\n" % (W, H) + a.tobytes())
+        R, t, K = sc.R[i].reshape(3, 3), sc.t[i], sc.K[i].reshape(3, 3)
+        txt = "extrinsic\n"
+        for r in range(3):
+            txt += "%.9g %.9g %.9g %.9g\n" % (R[r, 0], R[r, 1], R[r, 2], t[r])
+        txt += "0 0 0 1\n\nintrinsic\n"
+        for r in range(3):
+            txt += "%.9g %.9g %.9g\n" % (K[r, 0], K[r, 1], K[r, 2])
+        txt += "\n%.9g 0.01 192 %.9g\n" % (sc.depth_min, sc.depth_max)
+        (tmp / "cams" / ("%08d_cam.txt" % i)).write_text(txt)
+    pair = "%d\n" % nviews
+    for i in range(nviews):
+        srcs = [j for j in range(nviews) if j != i]
+        pair += "%d\n%d %s\n" % (i, len(srcs), " ".join("%d %.1f" % (j, 10.0 - k) for k, j in enumerate(srcs)))
+    (tmp / "pair.txt").write_text(pair)
+    return sc
+
+
+def _read_cam(path, pkg, W, H):
+    tok = open(path).read().split()
+    assert tok[0] == "extrinsic"
+    v = [float(x) for x in tok[1:17]]
+    R = [v[0], v[1], v[2], v[4], v[5], v[6], v[8], v[9], v[10]]
+    t = [v[3], v[7], v[11]]
+    assert tok[17] == "intrinsic"
+    K = [float(x) for x in tok[18:27]]
+    dmin, _, _, dmax = [float(x) for x in tok[27:31]]
+    return pkg.make_camera(K, R, t, W, H, dmin, dmax)
+
+
+def _read_dmb(path):
+    raw = open(path, "rb").read()
+    version, rows, cols, typ = struct.unpack("<4i", raw[:16])
+    assert version == 1
+    dt, ch = {5: (np.float32, 1), 21: (np.float32, 3), 0: (np.uint8, 1), 4: (np.uint32, 1)}[typ]
+    a = np.frombuffer(raw[16:], dt)
+    return a.reshape(rows, cols, ch) if ch > 1 else a.reshape(rows, cols)
+
+
+def _read_image(tmp, i, jpeg):
+    if jpeg:
+        from PIL import Image
+        im = Image.open(tmp / "images" / ("%08d.jpg" % i))
+        im.draft("L", im.size)
+        return np.asarray(im, np.float32)
+    raw = (tmp / "images" / ("%08d.pgm" % i)).read_bytes()
+    hdr, data = raw.split(b"255\n", 1)
+    w, h = [int(x) for x in hdr.split()[1:3]]
+    return np.frombuffer(data, np.uint8).reshape(h, w).astype(np.float32)
+
+
+@pytest.mark.parametrize("jpeg", [False, True])
+def test_binary_matches_c_abi_schedule(gpu_pkg, synth, tmp_path, jpeg):
+    assert os.path.exists(APD_BIN), "run __graft_entry__.build() first"
+    W, H, nviews, seed, iters = 80, 60, 3, 77, 2
+    _write_dense_folder(tmp_path, synth, W, H, nviews, jpeg=jpeg)
+    r = subprocess.run([APD_BIN, str(tmp_path), "0", "--seed", str(seed), "--iters", str(iters)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "Round nums: 1" in r.stdout  # max(W,H) <= 1000 -> one pyramid level (main.cpp:83-86)
+
+    pkg = gpu_pkg
+    cams = [_read_cam(tmp_path / "cams" / ("%08d_cam.txt" % i), pkg, W, H) for i in range(nviews)]
+    imgs = [_read_image(tmp_path, i, jpeg) for i in range(nviews)]
+    dmin, dmax = np.float32(cams[0].depth_min) * np.float32(0.6), np.float32(cams[0].depth_max) * np.float32(1.2)
+    store = {}
+    passes = [dict(state=pkg.FIRST_INIT, geom_consistency=0, weak_peak_radius=6)]
+    passes += [dict(state=pkg.REFINE_ITER, geom_consistency=1, weak_peak_radius=max(4 - 2 * j, 2)) for j in range(3)]
+    for it_index, extra in enumerate(passes):
+        for idx in range(nviews):  # Gauss-Seidel over views: later views see earlier views' new depth maps
+            order = [idx] + [j for j in range(nviews) if j != idx]
+            p = pkg.default_params(num_images=nviews, depth_min=float(dmin), depth_max=float(dmax), use_APD=0,
+                                   max_iterations=iters, seed=seed + it_index * 7919 + idx, **extra)
+            h = pkg.Handle(W, H, p, device=0)
+            deps = [store[j]["depth"] for j in order] if extra["geom_consistency"] else None
+            h.upload_views([cams[j] for j in order], [imgs[j] for j in order], deps)
+            if extra["state"] != pkg.FIRST_INIT:
+                prior_planes = np.concatenate([store[idx]["normal"], store[idx]["depth"][..., None]], -1)
+                h.upload_prior(np.ascontiguousarray(prior_planes), store[idx]["views"], None)
+            h.run()
+            planes, weak, views = h.download()
+            planes, views, weak = common.postprocess(planes, weak, views, dmin, dmax)
+            store[idx] = dict(depth=np.ascontiguousarray(planes[..., 3]), normal=np.ascontiguousarray(planes[..., :3]),
+                              weak=weak, views=views)
+            h.close()
+    for idx in range(nviews):
+        d = tmp_path / "APD" / ("%08d" % idx)
+        assert np.array_equal(_read_dmb(d / "depths.dmb").view(np.uint32), store[idx]["depth"].view(np.uint32)), idx
+        assert np.array_equal(_read_dmb(d / "normals.dmb").view(np.uint32), store[idx]["normal"].view(np.uint32)), idx
+        assert np.array_equal(_read_dmb(d / "weak.bin"), store[idx]["weak"]), idx
+        assert np.array_equal(_read_dmb(d / "selected_views.bin"), store[idx]["views"]), idx
+
+
+def test_binary_usage_and_bad_device(gpu_pkg, tmp_path):
+    r = subprocess.run([APD_BIN], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "USAGE" in r.stdout
+    (tmp_path / "pair.txt").write_text("0\n")
+    r = subprocess.run([APD_BIN, str(tmp_path), "99"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "found" in r.stdout

@@ -1,0 +1,158 @@
+"""Host-side drop-in pieces (apd-mvs_amd/host): on-disk formats of the reference (.dmb/.bin, *_cam.txt),
+grey JPEG input, resampling.  No GPU needed."""
+import ctypes as C
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_LIB = os.path.join(ROOT, "apd-mvs_amd", "_build", "libapd_host.so")
+
+
+@pytest.fixture(scope="module")
+def host(pkg):
+    assert os.path.exists(HOST_LIB), "run __graft_entry__.build() first"
+    pkg.lib()  # libapd_host.so depends on libapd_mi355x.so
+    L = C.CDLL(HOST_LIB)
+    L.apdhost_format_index.restype = C.c_char_p
+    L.apdhost_format_index.argtypes = [C.c_int]
+    ip = C.POINTER(C.c_int)
+    fp = C.POINTER(C.c_float)
+    L.apdhost_read_bin_mat.argtypes = [C.c_char_p, ip, ip, ip, C.c_void_p, C.c_size_t]
+    L.apdhost_write_bin_mat.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.apdhost_read_camera.argtypes = [C.c_char_p, C.c_void_p]
+    L.apdhost_read_gray_image.argtypes = [C.c_char_p, ip, ip, fp, C.c_size_t]
+    L.apdhost_resize_linear.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+    L.apdhost_rescale_nearest_f32.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+    return L
+
+
+def test_format_index(host):
+    assert host.apdhost_format_index(7) == b"00000007"
+    assert host.apdhost_format_index(12345678) == b"12345678"
+
+
+@pytest.mark.parametrize("dtype,code,ch", [(np.float32, 5, 1), (np.float32, 21, 3), (np.uint8, 0, 1), (np.int32, 4, 1)])
+def test_bin_mat_layout_and_round_trip(host, tmp_path, dtype, code, ch):
+    """int32 version=1, rows, cols, OpenCV type code, then the raw row-major payload (APD.cpp:3-49)."""
+    rows, cols = 5, 7
+    rng = np.random.RandomState(0)
+    a = (rng.rand(rows, cols * ch) * 200).astype(dtype)
+    p = str(tmp_path / "m.dmb").encode()
+    assert host.apdhost_write_bin_mat(p, rows, cols, code, a.ctypes.data) == 0
+    raw = open(p, "rb").read()
+    assert struct.unpack("<4i", raw[:16]) == (1, rows, cols, code)
+    assert raw[16:] == a.tobytes()
+    r, c, t = C.c_int(), C.c_int(), C.c_int()
+    out = np.zeros_like(a)
+    assert host.apdhost_read_bin_mat(p, C.byref(r), C.byref(c), C.byref(t), out.ctypes.data, out.nbytes) == 0
+    assert (r.value, c.value, t.value) == (rows, cols, code)
+    assert np.array_equal(out, a)
+
+
+def test_bin_mat_rejects_wrong_version_and_missing_file(host, tmp_path):
+    p = tmp_path / "bad.dmb"
+    p.write_bytes(struct.pack("<4i", 2, 1, 1, 5) + b"\0\0\0\0")
+    r, c, t = C.c_int(), C.c_int(), C.c_int()
+    assert host.apdhost_read_bin_mat(str(p).encode(), C.byref(r), C.byref(c), C.byref(t), None, 0) != 0
+    assert host.apdhost_read_bin_mat(str(tmp_path / "nope.dmb").encode(), C.byref(r), C.byref(c), C.byref(t), None, 0) != 0
+
+
+def test_read_camera(host, pkg, tmp_path):
+    """MVSNet-style cam file: extrinsic [R t] rows, intrinsic K, `depth_min interval depth_num depth_max`;
+    camera centre c = -R^T t (APD.cpp:51-92)."""
+    R = np.array([[0.8, 0.0, 0.6], [0.0, 1.0, 0.0], [-0.6, 0.0, 0.8]])
+    t = np.array([0.1, -0.2, 0.3])
+    txt = "extrinsic\n"
+    for i in range(3):
+        txt += "%f %f %f %f\n" % (R[i, 0], R[i, 1], R[i, 2], t[i])
+    txt += "0.0 0.0 0.0 1.0\n\nintrinsic\n1000.5 0 320.25\n0 1001.5 240.75\n0 0 1\n\n0.5 0.01 192 7.25\n"
+    p = tmp_path / "00000003_cam.txt"
+    p.write_text(txt)
+    cam = pkg.Camera()
+    assert host.apdhost_read_camera(str(p).encode(), C.byref(cam)) == 0
+    assert np.allclose(np.array(list(cam.R)).reshape(3, 3), R, atol=1e-6)
+    assert np.allclose(list(cam.t), t, atol=1e-6)
+    assert np.allclose(list(cam.K), [1000.5, 0, 320.25, 0, 1001.5, 240.75, 0, 0, 1], atol=1e-4)
+    assert np.allclose(list(cam.c), -R.T @ t, atol=1e-6)
+    assert abs(cam.depth_min - 0.5) < 1e-7 and abs(cam.depth_max - 7.25) < 1e-7
+
+
+def _read_image(host, stem, shape):
+    r, c = C.c_int(), C.c_int()
+    out = np.zeros(shape, np.float32)
+    rc = host.apdhost_read_gray_image(str(stem).encode(), C.byref(r), C.byref(c), out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
+    return rc, (r.value, c.value), out
+
+
+def test_pgm_input(host, tmp_path):
+    a = (np.arange(6 * 9) % 256).astype(np.uint8).reshape(6, 9)
+    (tmp_path / "00000001.pgm").write_bytes(b"P5\n# comment\n9 6\n255\n" + a.tobytes())
+    rc, shp, out = _read_image(host, tmp_path / "00000001", (6, 9))
+    assert rc == 0 and shp == (6, 9)
+    assert np.array_equal(out, a.astype(np.float32))
+
+
+@pytest.mark.parametrize("mode,subsampling,size", [("L", 0, (64, 48)), ("RGB", 0, (61, 45)), ("RGB", 2, (70, 50)), ("RGB", 1, (33, 17))])
+def test_baseline_jpeg_luma_matches_libjpeg(host, tmp_path, mode, subsampling, size):
+    """cv::imread(IMREAD_GRAYSCALE) == libjpeg decoding straight to the Y plane.  PIL's draft('L') asks
+    its bundled libjpeg for exactly that, so the two decoders must agree bit for bit."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(1)
+    w, h = size
+    base = rng.rand(h // 4 + 2, w // 4 + 2, 3)
+    img = np.kron(base, np.ones((4, 4, 1)))[:h, :w] * 255
+    img += rng.rand(h, w, 3) * 20
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    im = PIL.fromarray(img if mode == "RGB" else img[..., 0], mode)
+    path = tmp_path / "00000002.jpg"
+    kw = {} if mode == "L" else {"subsampling": subsampling}
+    im.save(path, quality=90, **kw)
+    ref = PIL.open(path)
+    ref.draft("L", ref.size)
+    ref = np.asarray(ref.convert("L") if ref.mode != "L" else ref, np.float32)
+    rc, shp, out = _read_image(host, tmp_path / "00000002", (h, w))
+    assert rc == 0 and shp == (h, w)
+    assert np.array_equal(out, ref)
+
+
+def test_progressive_jpeg_is_refused_not_misdecoded(host, tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    im = PIL.fromarray((np.random.RandomState(0).rand(32, 32) * 255).astype(np.uint8), "L")
+    im.save(tmp_path / "00000004.jpg", progressive=True)
+    rc, _, _ = _read_image(host, tmp_path / "00000004", (32, 32))
+    assert rc != 0
+
+
+def test_resize_linear_power_of_two_is_centre_box(host):
+    """cv::resize INTER_LINEAR at an exact 1/2 ratio averages the 2x2 block."""
+    rng = np.random.RandomState(3)
+    a = (rng.rand(12, 16) * 255).astype(np.float32)
+    out = np.zeros((6, 8), np.float32)
+    host.apdhost_resize_linear(a.ctypes.data_as(C.POINTER(C.c_float)), 12, 16, out.ctypes.data_as(C.POINTER(C.c_float)), 6, 8)
+    ref = (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2]) / 4
+    assert np.allclose(out, ref, atol=1e-4)
+    # 1/4: the two middle rows/cols of each 4x4 cell with weights 0.5/0.5, not a full box
+    out4 = np.zeros((3, 4), np.float32)
+    host.apdhost_resize_linear(a.ctypes.data_as(C.POINTER(C.c_float)), 12, 16, out4.ctypes.data_as(C.POINTER(C.c_float)), 3, 4)
+    ref4 = (a[1::4, 1::4] + a[1::4, 2::4] + a[2::4, 1::4] + a[2::4, 2::4]) / 4
+    assert np.allclose(out4, ref4, atol=1e-4)
+
+
+def test_rescale_nearest_keeps_swapped_scale_quirk(host):
+    """RescaleMatToTargetSize divides the ROW by scale_x and the COLUMN by scale_y (APD.cpp:766-767)."""
+    src = np.arange(5 * 7, dtype=np.float32).reshape(5, 7)
+    new_rows, new_cols = 11, 13
+    out = np.zeros((new_rows, new_cols), np.float32)
+    host.apdhost_rescale_nearest_f32(src.ctypes.data_as(C.POINTER(C.c_float)), 5, 7, out.ctypes.data_as(C.POINTER(C.c_float)), new_rows, new_cols)
+    sx, sy = np.float32(new_cols) / np.float32(7), np.float32(new_rows) / np.float32(5)
+    ref = np.zeros_like(out)
+    for r in range(new_rows):
+        for c in range(new_cols):
+            o_r, o_c = int(np.float32(r) / sx), int(np.float32(c) / sy)
+            if 0 <= o_r < 5 and 0 <= o_c < 7:
+                ref[r, c] = src[o_r, o_c]
+    assert np.array_equal(out, ref)
