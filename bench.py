@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="eth3d_office_fullres_8src", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="512x384", help="WxH of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", default="1024x768", help="WxH of the CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=12345)
     args = ap.parse_args()
 
@@ -120,14 +120,14 @@ def main():
     h.export_depth_normal(depth, normal)
     torch.cuda.synchronize()
     if distributed:
-        gathered_d = torch.empty((world, H, W), device=dev, dtype=torch.float32)
-        gathered_n = torch.empty((world, H, W, 3), device=dev, dtype=torch.float32)
+        from apd_mvs_amd import sharding
         torch.cuda.synchronize()
         ta = time.perf_counter()
-        dist.all_gather_into_tensor(gathered_d, depth)
-        dist.all_gather_into_tensor(gathered_n, normal)
+        gathered_d = sharding.allgather_maps({rank: depth.view(H, W, 1)}, world)   # view index == rank here
+        gathered_n = sharding.allgather_maps({rank: normal}, world)
         torch.cuda.synchronize()
         allgather_ms = (time.perf_counter() - ta) * 1e3
+        assert gathered_d.shape[0] == world and torch.equal(gathered_d[rank, :, :, 0], depth)
     gt = sc.gt_depth
     err = (depth - gt).abs() / gt
     within = float((err[8:-8, 8:-8] < 0.01).float().mean().item())
@@ -143,9 +143,11 @@ def main():
     avg_ms = (k6[0] + k7[0]) / max(launches, 1)
     bytes_per_launch = (W * H / 2.0) * algorithmic_bytes_per_strong_pixel(N)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, traffic_src = load_pmc_traffic(args.workload)
     roofline = {
         "bound": "hbm", "kernel": "k67_update_strong (Black/RedPixelUpdateStrong)", "achieved": round(achieved, 1),
-        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "traffic_source": traffic_src,
         "avg_launch_ms": round(avg_ms, 3), "launches": launches,
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "bytes_per_pixel_iter": algorithmic_bytes_per_strong_pixel(N),
@@ -183,6 +185,24 @@ def main():
     h.close()
     if distributed:
         dist.destroy_process_group()
+
+
+def load_pmc_traffic(workload):
+    """HBM bytes per K6/K7 launch from the newest committed rocprofv3 PMC summary of this workload
+    (profiles/rNN/pmc_traffic.json, written by tools/profile.sh: separate --pmc passes, FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this process, so the
+    field is null when no such profile exists."""
+    import glob
+    best = (None, None)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") == workload and rec.get("hbm_bytes_per_launch"):
+            best = (rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
+    return best
 
 
 def run_cpu_baseline(args, num_src, np):

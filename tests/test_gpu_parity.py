@@ -126,9 +126,13 @@ def test_export_matches_process_problem_postprocessing(gpu_pkg, synth):
     import torch
     W, H, N = 64, 48, 3
     sc, imgs = common.scene_inputs(synth, W, H, N)
-    p = common.base_params(sc, N, max_iterations=1, depth_max=2.3)  # tight range -> some depths out of range
+    p = common.base_params(sc, N, max_iterations=1)
     h = common.make_handle(gpu_pkg, sc, imgs, N, p)
     h.run()
+    planes = h.state(gpu_pkg.STATE_PLANES)
+    planes[:5, :, 3] = 100.0   # out of [depth_min, depth_max] -> exported as 0 (main.cpp:109-112)
+    planes[5:8, :, 3] = 0.01
+    h.set_state(gpu_pkg.STATE_PLANES, planes)
     planes, weak, views = h.download()
     depth = torch.empty((H, W), device="cuda", dtype=torch.float32)
     normal = torch.empty((H, W, 3), device="cuda", dtype=torch.float32)

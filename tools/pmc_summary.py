@@ -42,5 +42,31 @@ def main():
     print("wrote", dst, len(rows_out), "rows")
 
 
+def traffic_json(fetch_csv, write_csv, workload, dst, kernel_substr="k67_update_strong"):
+    """FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so the read
+    side is doubled (MI355X_MICROARCH.md, HBM section).  Steady state = minimum over the dispatches (the
+    first launches run on random planes and scatter more)."""
+    import json
+
+    def pick(path, counter):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if kernel_substr in r["kernel"] and r["counter"] == counter:
+                    return float(r["mean"]), float(r["min"]), int(r["dispatches"])
+        return None
+    fe, wr = pick(fetch_csv, "FETCH_SIZE"), pick(write_csv, "WRITE_SIZE")
+    rec = {"workload": workload, "kernel": kernel_substr, "dispatches": fe[2],
+           "fetch_bytes_mean": fe[0] * 1024 * 2, "fetch_bytes_min": fe[1] * 1024 * 2,
+           "write_bytes_mean": wr[0] * 1024, "write_bytes_min": wr[1] * 1024,
+           "hbm_bytes_per_launch": fe[0] * 1024 * 2 + wr[0] * 1024,
+           "note": "FETCH_SIZE x2 (gfx950), WRITE_SIZE uncorrected; mean over dispatches; separate --pmc passes"}
+    with open(dst, "w") as f:
+        json.dump(rec, f, indent=1)
+    print("wrote", dst)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1] == "--traffic":
+        traffic_json(*sys.argv[2:6])
+    else:
+        main()
