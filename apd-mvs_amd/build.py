@@ -29,6 +29,7 @@ def _newer(target, deps):
 
 def build_library(force=False, verbose=False, extra_flags=()):
     os.makedirs(OUT_DIR, exist_ok=True)
+    extra_flags = list(extra_flags) + os.environ.get("APD_EXTRA_FLAGS", "").split()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
     for src in SOURCES:

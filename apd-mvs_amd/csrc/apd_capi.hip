@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -16,6 +17,8 @@ namespace apd {
 hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
 hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
 hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s);
+hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s);
+hipError_t launch_pack_quads(const float *img, int W, int H, uint32_t *quad, hipStream_t s);
 }  // namespace apd
 
 using apd::FrameArgs;
@@ -55,6 +58,9 @@ struct apd_context {
     // device memory
     std::vector<float *> images;
     std::vector<float *> depths;
+    std::vector<uint32_t *> quads;
+    int *flag_dev = nullptr;
+    bool use_quads = false;
     ViewConst *views_dev = nullptr;
     float4 *planes = nullptr, *fit_planes = nullptr;
     float *costs = nullptr;
@@ -114,6 +120,7 @@ static void refresh_frame_args(apd_context *c)
     fa.H = c->H;
     fa.num_src = c->num_images > 0 ? c->num_images - 1 : 0;
     fa.half_rows = 2 * (((c->H / 2) + 15) / 16) * 16;
+    fa.use_quads = c->use_quads ? 1 : 0;
     fa.top_k = p.top_k;
     fa.depth_min = p.depth_min;
     fa.depth_max = p.depth_max;
@@ -254,6 +261,10 @@ int apd_destroy(apd_handle c)
     for (float *p : c->depths) {
         hipFree(p);
     }
+    for (uint32_t *p : c->quads) {
+        hipFree(p);
+    }
+    hipFree(c->flag_dev);
     hipFree(c->views_dev);
     hipFree(c->planes);
     hipFree(c->fit_planes);
@@ -313,8 +324,12 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     for (float *p : c->depths) {
         hipFree(p);
     }
+    for (uint32_t *p : c->quads) {
+        hipFree(p);
+    }
     c->images.assign(num_images, nullptr);
     c->depths.assign(num_images, nullptr);
+    c->quads.assign(num_images, nullptr);
     for (int i = 0; i < num_images; ++i) {
         if (cameras[i].width != c->W || cameras[i].height != c->H) {
             return fail(APD_ERR_INVALID, "apd_upload_views: camera %d is %dx%d, handle is %dx%d", i, cameras[i].width, cameras[i].height,
@@ -325,6 +340,32 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         if (depths) {
             HIP_TRY(hipMalloc(&c->depths[i], n * sizeof(float)));
             HIP_TRY(hipMemcpyAsync(c->depths[i], depths[i], n * sizeof(float), hipMemcpyDefault, c->stream));
+        }
+    }
+    // 8-bit input (integers 0..255 in every view)?  Then also keep the source views as texel quads.
+    if (!c->flag_dev) {
+        HIP_TRY(hipMalloc(&c->flag_dev, sizeof(int)));
+    }
+    const int one = 1;
+    HIP_TRY(hipMemcpyAsync(c->flag_dev, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    for (int i = 1; i < num_images; ++i) {
+        hipError_t e = apd::launch_check_u8(c->images[i], (int)n, c->flag_dev, c->stream);
+        if (e != hipSuccess) {
+            return fail(APD_ERR_HIP, "k_check_u8 failed: %s", hipGetErrorString(e));
+        }
+    }
+    int all_u8 = 0;
+    HIP_TRY(hipMemcpyAsync(&all_u8, c->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->use_quads = all_u8 != 0 && getenv("APD_NO_QUADS") == nullptr;
+    if (c->use_quads) {
+        const size_t qn = (size_t)(c->W + 1) * (c->H + 1);
+        for (int i = 1; i < num_images; ++i) {
+            HIP_TRY(hipMalloc(&c->quads[i], qn * sizeof(uint32_t)));
+            hipError_t e = apd::launch_pack_quads(c->images[i], c->W, c->H, c->quads[i], c->stream);
+            if (e != hipSuccess) {
+                return fail(APD_ERR_HIP, "k_pack_quads failed: %s", hipGetErrorString(e));
+            }
         }
     }
     c->num_images = num_images;
@@ -356,6 +397,7 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         memcpy(vc.c, src.c, sizeof(vc.c));
         vc.img = c->images[v + 1];
         vc.depth = c->depths[v + 1];
+        vc.quad = c->quads[v + 1];
     }
     HIP_TRY(hipMemcpyAsync(c->views_dev, vcs.data(), vcs.size() * sizeof(ViewConst), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

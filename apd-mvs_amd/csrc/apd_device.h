@@ -31,12 +31,17 @@ struct ViewConst {
     float c[3];
     const float *img;    // W*H floats
     const float *depth;  // W*H floats or nullptr
+    // Texel-quad image (only when every pixel of every view is an integer 0..255, i.e. 8-bit input at
+    // scale 1): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], packs the four clamped taps
+    // {I(qx,qy), I(qx+1,qy), I(qx,qy+1), I(qx+1,qy+1)} of one bilinear fetch into one dword.
+    const uint32_t *quad;  // (H+1)*(W+1) dwords or nullptr
 };
 
 struct FrameArgs {
     int W, H;
     int num_src;       // num_images - 1
     int half_rows;     // rows reachable by the reference HALF launch: 2*ceil((H/2)/16)*16 (APD.cu:2402)
+    int use_quads;     // 1: source images are also available as texel quads (ViewConst::quad)
     // params (main.h:75-94)
     int top_k;
     float depth_min, depth_max;
@@ -381,6 +386,24 @@ __device__ __forceinline__ float sample_bilinear(const float *__restrict__ img, 
     return fmaf(b, bot - top, top);
 }
 
+// Same fetch from the texel-quad image: one dword gather instead of four.  Bit-identical to
+// sample_bilinear on 8-bit data (the taps are the same floats, the lerp is the same three fmaf).
+__device__ __forceinline__ float sample_quad(const uint32_t *__restrict__ quad, int W, int H, float sx, float sy)
+{
+    const float fx = floorf(sx), fy = floorf(sy);
+    const float a = sx - fx, b = sy - fy;
+    const int x0 = (int)fminf(fmaxf(fx, -1.0f), (float)W);
+    const int y0 = (int)fminf(fmaxf(fy, -1.0f), (float)H);
+    // x0 >= W-1 clamps both taps to W-1, which is what quad W-1 holds; x0 == -1 is quad -1
+    const int qx = min(x0, W - 1) + 1, qy = min(y0, H - 1) + 1;
+    const uint32_t t = quad[(unsigned)__mul24(qy, W + 1) + (unsigned)qx];
+    const float t00 = (float)(t & 0xFFu), t10 = (float)((t >> 8) & 0xFFu);
+    const float t01 = (float)((t >> 16) & 0xFFu), t11 = (float)(t >> 24);
+    const float top = fmaf(a, t10 - t00, t00);
+    const float bot = fmaf(a, t11 - t01, t01);
+    return fmaf(b, bot - top, top);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fixed 6x6 patch (strong_radius 5, strong_increment 2): the hot NCC of APD.cu:530-614
 // ------------------------------------------------------------------------------------------------
@@ -430,7 +453,8 @@ __device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float 
     ref_patch_finish(rp);
 }
 
-// ComputeBilateralNCCOld for plane q = n/d against source view vc.
+// ComputeBilateralNCCOld for plane q = n/d against source view vc.  kQuad selects the texel-quad image.
+template <bool kQuad>
 __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, int px, int py,
                                            float qx, float qy, float qz)
 {
@@ -445,6 +469,7 @@ __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst 
         return 2.0f;  // the reference tests this after sampling; the result is the same
     }
     const float *__restrict__ src = vc.img;
+    const uint32_t *__restrict__ srcq = vc.quad;
     const int W = fa.W, Hh = fa.H;
     float sum_s = 0.0f, sum_ss = 0.0f, sum_rs = 0.0f;
 #pragma unroll
@@ -460,7 +485,7 @@ __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst 
             const float inv = 1.0f / fmaf(H.h[7], yf, bz);
             const float sx = fmaf(H.h[1], yf, bx) * inv;
             const float sy = fmaf(H.h[4], yf, by) * inv;
-            const float v = sample_bilinear(src, W, Hh, sx, sy);
+            const float v = kQuad ? sample_quad(srcq, W, Hh, sx, sy) : sample_bilinear(src, W, Hh, sx, sy);
             row_s += v;
             row_ss = fmaf(v, v, row_ss);
             row_rs = fmaf(rp.v[i * kPatchN + j], v, row_rs);

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) void k1_init_random_states(FrameArgs fa)
 // K5  RandomInitialization (APD.cu:806-835) with the initial costs of :616-693
 // ------------------------------------------------------------------------------------------------
 
+template <bool kQuad>
 __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
 {
     const int px = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
         int valid = 0;
 #pragma unroll 1
         for (int v = 0; v < fa.num_src; ++v) {
-            const float c = ncc_fixed(fa, fa.views[v], rp, px, py, qx, qy, qz);
+            const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
             sorted[v] = c;
             orig[v] = c;
             if (c < 2.0f) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
 #pragma unroll 1
         for (int v = 0; v < fa.num_src; ++v) {
             if (bit_test(sel, (unsigned)v)) {
-                const float c = ncc_fixed(fa, fa.views[v], rp, px, py, qx, qy, qz);
+                const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
                 if (c < 2.0f) {
                     count++;
                     cost += c;
@@ -187,8 +188,11 @@ __device__ __forceinline__ bool arm_candidate(const FrameArgs &fa, int px, int p
 
 // One launch = one colour.  Hypotheses 0..7 are the propagation arms, 8 the current plane,
 // 9..13 the refinement set; a single loop keeps one inlined copy of the 36-sample NCC.
-template <int NMAX>
-__global__ __launch_bounds__(256) void k67_update_strong(FrameArgs fa, int colour, int iter)
+#ifndef APD_K67_WAVES
+#define APD_K67_WAVES 2  // minimum waves per SIMD the register allocator must leave room for
+#endif
+template <int NMAX, bool kQuad>
+__global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArgs fa, int colour, int iter)
 {
     __shared__ float tile[kLdsH * kLdsPitch];
     const TilePixel t = checkerboard_pixel(fa, colour);
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void k67_update_strong(FrameArgs fa, int colou
         float tc = 0.0f;
 #pragma unroll 1
         for (int v = 0; v < nsrc; ++v) {
-            const float c = ncc_fixed(fa, fa.views[v], rp, px, py, qx, qy, qz);
+            const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
             if (h < 9) {
                 cost_array[h][v] = c;
             } else if (vw[v] > 0) {
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void k1213_filter_strong(FrameArgs fa, int col
 // Weighted cost of one depth sample along the pixel's ray over the selected views.
 //   kLocalRefine == false: sum_sel (ncc + gf*geom) * w           (:2070-2080, :2031-2035)
 //   kLocalRefine == true : sum_sel ncc*w (+ gf*geom*w)            (:2217-2220)
-template <bool kLocalRefine>
+template <bool kLocalRefine, bool kQuad>
 __device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, const RefPatch &rp, int px, int py, const float4 origin,
                                                        float depth, uint32_t sel, const uint8_t *vw)
 {
@@ -419,7 +423,7 @@ __device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, cons
 #pragma unroll 1
     for (int v = 0; v < fa.num_src; ++v) {
         if (bit_test(sel, (unsigned)v)) {
-            const float c = ncc_fixed(fa, fa.views[v], rp, px, py, qx, qy, qz);
+            const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
             if (kLocalRefine) {
                 acc += c * (float)vw[v];
                 if (fa.geom_consistency) {
@@ -460,6 +464,7 @@ __device__ __forceinline__ int baseline_and_weight(const FrameArgs &fa, uint32_t
     return valid;
 }
 
+template <bool kQuad>
 __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
 {
     const int px = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
             pc[pd + RADIUS] = 2.0f;
             continue;
         }
-        float p_cost = disparity_sample_cost<false>(fa, rp, px, py, origin, p_depth, sel, vw);
+        float p_cost = disparity_sample_cost<false, kQuad>(fa, rp, px, py, origin, p_depth, sel, vw);
         p_cost /= weight_normal;
         pc[pd + RADIUS] = (2.0f > p_cost) ? p_cost : 2.0f;  // MIN(2.0f, p_cost): NaN -> 2
     }
@@ -540,6 +545,7 @@ __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
     fa.weak_info[center] = (var > 0.2f) ? APD_STRONG : APD_WEAK;
 }
 
+template <bool kQuad>
 __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
 {
     const int px = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -574,14 +580,14 @@ __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
 #pragma unroll 1
     for (int pd = -radius - 1; pd <= radius; ++pd) {
         if (pd == -radius - 1) {
-            cost_now = disparity_sample_cost<false>(fa, rp, px, py, origin, origin_depth, sel, vw) / weight_normal;
+            cost_now = disparity_sample_cost<false, kQuad>(fa, rp, px, py, origin, origin_depth, sel, vw) / weight_normal;
             continue;
         }
         const float p_depth = fa.K[0] * base_line / (disp + (float)pd);
         if (p_depth < fa.depth_min || p_depth > fa.depth_max) {
             continue;
         }
-        const float tc = disparity_sample_cost<true>(fa, rp, px, py, origin, p_depth, sel, vw) / weight_normal;
+        const float tc = disparity_sample_cost<true, kQuad>(fa, rp, px, py, origin, p_depth, sel, vw) / weight_normal;
         if (tc < min_cost) {
             min_cost = tc;
             best_depth = p_depth;
@@ -590,6 +596,46 @@ __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
     if ((double)(cost_now - min_cost) > 0.1) {
         fa.planes[center].w = best_depth;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// texel-quad images (built once per upload)
+// ------------------------------------------------------------------------------------------------
+
+// *flag stays 1 only if every pixel is an integer in [0, 255] (8-bit input at scale 1)
+__global__ __launch_bounds__(256) void k_check_u8(const float *__restrict__ img, int n, int *flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float v = img[i];
+        if (!(v >= 0.0f && v <= 255.0f && v == floorf(v))) {
+            *flag = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_quads(const float *__restrict__ img, int W, int H, uint32_t *__restrict__ quad)
+{
+    const int qx = blockIdx.x * 32 + (threadIdx.x & 31);  // 0..W  <-> image x = qx - 1
+    const int qy = blockIdx.y * 8 + (threadIdx.x >> 5);   // 0..H
+    if (qx > W || qy > H) {
+        return;
+    }
+    const uint32_t t00 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy - 1), t10 = (uint32_t)fetch_texel(img, W, H, qx, qy - 1);
+    const uint32_t t01 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy), t11 = (uint32_t)fetch_texel(img, W, H, qx, qy);
+    quad[(size_t)qy * (W + 1) + qx] = t00 | (t10 << 8) | (t01 << 16) | (t11 << 24);
+}
+
+hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_check_u8, dim3((n + 255) / 256), dim3(256), 0, s, img, n, flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_quads(const float *img, int W, int H, uint32_t *quad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pack_quads, dim3((W + 1 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, quad);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -602,7 +648,11 @@ static inline int checkerboard_tiles(const FrameArgs &fa) { return ((fa.W + kTil
 template <int NMAX>
 static void launch_k67(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
-    hipLaunchKernelGGL(k67_update_strong<NMAX>, dim3(checkerboard_tiles(fa)), dim3(256), 0, s, fa, colour, iter);
+    if (fa.use_quads) {
+        hipLaunchKernelGGL((k67_update_strong<NMAX, true>), dim3(checkerboard_tiles(fa)), dim3(256), 0, s, fa, colour, iter);
+    } else {
+        hipLaunchKernelGGL((k67_update_strong<NMAX, false>), dim3(checkerboard_tiles(fa)), dim3(256), 0, s, fa, colour, iter);
+    }
 }
 
 hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s)
@@ -614,7 +664,11 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
         break;
     }
     case APD_K5_RANDOM_INITIALIZATION:
-        hipLaunchKernelGGL(k5_random_initialization, grid_32x8(fa), dim3(256), 0, s, fa);
+        if (fa.use_quads) {
+            hipLaunchKernelGGL(k5_random_initialization<true>, grid_32x8(fa), dim3(256), 0, s, fa);
+        } else {
+            hipLaunchKernelGGL(k5_random_initialization<false>, grid_32x8(fa), dim3(256), 0, s, fa);
+        }
         break;
     case APD_K6_BLACK_UPDATE_STRONG:
     case APD_K7_RED_UPDATE_STRONG: {
@@ -637,10 +691,18 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
                            (kernel_id == APD_K12_BLACK_FILTER) ? 0 : 1);
         break;
     case APD_K14_DEPTH_TO_WEAK:
-        hipLaunchKernelGGL(k14_depth_to_weak, grid_32x8(fa), dim3(256), 0, s, fa);
+        if (fa.use_quads) {
+            hipLaunchKernelGGL(k14_depth_to_weak<true>, grid_32x8(fa), dim3(256), 0, s, fa);
+        } else {
+            hipLaunchKernelGGL(k14_depth_to_weak<false>, grid_32x8(fa), dim3(256), 0, s, fa);
+        }
         break;
     case APD_K15_LOCAL_REFINE:
-        hipLaunchKernelGGL(k15_local_refine, grid_32x8(fa), dim3(256), 0, s, fa);
+        if (fa.use_quads) {
+            hipLaunchKernelGGL(k15_local_refine<true>, grid_32x8(fa), dim3(256), 0, s, fa);
+        } else {
+            hipLaunchKernelGGL(k15_local_refine<false>, grid_32x8(fa), dim3(256), 0, s, fa);
+        }
         break;
     default:
         return hipErrorInvalidValue;

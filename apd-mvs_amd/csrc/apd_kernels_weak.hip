@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256) void k8_ransac_fit_plane(FrameArgs fa)
 
 // ComputeBilateralNCCNew (APD.cu:400-528): centre 6x6 patch + up to eight 3x3 sub-patches around the
 // reliable neighbours, all warped by the same homography.
+template <bool kQuad>
 __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const RefPatch &rp, const short2 *nb,
                                               int px, int py, const float4 pl)
 {
@@ -436,7 +437,7 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
         return 2.0f;
     }
     // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above)
-    const float center_cost = ncc_fixed(fa, vc, rp, px, py, qx, qy, qz);
+    const float center_cost = ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
     float strong_cost = 0.0f;
     int strong_count = 0;
     for (int k = 1; k < APD_NEIGHBOUR_NUM; ++k) {
@@ -467,7 +468,7 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
 
 // Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
 // plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
-template <int NMAX>
+template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour, int iter)
 {
     // one wave per 16x8 footprint; WEAK pixels are sparse, keep workgroups small
@@ -621,13 +622,13 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour,
         for (int v = 0; v < nsrc; ++v) {
             const ViewConst &vc = fa.views[v];
             if (h < 9) {
-                cost_array[h][v] = ncc_deformed(fa, vc, v, rp, nb, px, py, pl);
+                cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, nb, px, py, pl);
             } else if (h == 15) {
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                tc += (float)vw[v] * ncc_fixed(fa, vc, rp, px, py, qx, qy, qz);
+                tc += (float)vw[v] * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
             } else {
-                const float c = ncc_deformed(fa, vc, v, rp, nb, px, py, pl);
+                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, nb, px, py, pl);
                 if (vw[v] > 0) {
                     if (fa.geom_consistency) {
                         tc += (float)vw[v] * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
@@ -686,7 +687,11 @@ template <int NMAX>
 static void launch_k910(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
     const int tiles = ((fa.W + 15) / 16) * ((fa.H + 7) / 8);
-    hipLaunchKernelGGL(k910_update_weak<NMAX>, dim3(tiles), dim3(64), 0, s, fa, colour, iter);
+    if (fa.use_quads) {
+        hipLaunchKernelGGL((k910_update_weak<NMAX, true>), dim3(tiles), dim3(64), 0, s, fa, colour, iter);
+    } else {
+        hipLaunchKernelGGL((k910_update_weak<NMAX, false>), dim3(tiles), dim3(64), 0, s, fa, colour, iter);
+    }
 }
 
 hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s)

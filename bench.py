@@ -27,6 +27,7 @@ WORKLOADS = {
     "eth3d_pipes_fullres_10src": (6200, 4130, 10),   # configs[2] shape (strong pixels only here)
     "synthetic_4096x3072_16src": (4096, 3072, 16),   # configs[4]
     "tt_family_1080p_10src": (1920, 1080, 10),       # configs[3] shape
+    "synthetic_4096x3072_8src": (4096, 3072, 8),     # tuning workload
     "small": (640, 480, 8),
 }
 

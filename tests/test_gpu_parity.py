@@ -48,6 +48,20 @@ def test_first_pass_lockstep(gpu_pkg, ob, synth, W, H, N, iters):
     o.close()
 
 
+def test_float_image_path(gpu_pkg, ob, synth):
+    """Non-integer images (what a downscaled pyramid level holds, APD.cpp:474) cannot use the packed
+    8-bit texel quads: the float sampler path must give the same bits as the oracle too."""
+    W, H, N = 72, 56, 3
+    sc, imgs = common.scene_inputs(synth, W, H, N)
+    imgs = [im * np.float32(0.5) + np.float32(0.37) for im in imgs]
+    p = common.base_params(sc, N, max_iterations=2, weak_peak_radius=6)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p)
+    o = common.make_oracle(ob, sc, imgs, N, p)
+    _lockstep(gpu_pkg, h, o, 2, "float images")
+    h.close()
+    o.close()
+
+
 @pytest.mark.parametrize("N", [9, 16, 17, 31])
 def test_many_source_views(gpu_pkg, ob, synth, N):
     """NMAX = 16 and 32 instantiations of the sweep kernels (MAX_IMAGES = 32 -> at most 31 sources)."""
