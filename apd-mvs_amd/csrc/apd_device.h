@@ -370,7 +370,8 @@ __device__ __forceinline__ float fetch_texel(const float *__restrict__ img, int 
     return img[(unsigned)(clampi(y, 0, H - 1) * W + clampi(x, 0, W - 1))];
 }
 
-__device__ __forceinline__ float sample_bilinear(const float *__restrict__ img, int W, int H, float sx, float sy)
+template <typename Ptr>
+__device__ __forceinline__ float sample_bilinear(Ptr img, int W, int H, float sx, float sy)
 {
     const float fx = floorf(sx), fy = floorf(sy);
     const float a = sx - fx, b = sy - fy;
@@ -386,17 +387,26 @@ __device__ __forceinline__ float sample_bilinear(const float *__restrict__ img, 
     return fmaf(b, bot - top, top);
 }
 
+// Pointers into HBM as the compiler should see them: global address space (a pointer loaded from a
+// struct would otherwise be "generic" and cost flat_load + 64-bit address arithmetic per gather).
+typedef const __attribute__((address_space(1))) uint32_t *global_u32_ptr;
+typedef const __attribute__((address_space(1))) float *global_f32_ptr;
+
 // Same fetch from the texel-quad image: one dword gather instead of four.  Bit-identical to
 // sample_bilinear on 8-bit data (the taps are the same floats, the lerp is the same three fmaf).
-__device__ __forceinline__ float sample_quad(const uint32_t *__restrict__ quad, int W, int H, float sx, float sy)
+// Index math: floor -> v_med3_f32 clamp to [-1, W-1] -> cvt; a NaN/Inf coordinate gives a NaN weight,
+// so the sample is NaN whatever texel is read and the clamp only has to keep the address in range
+// (v_med3_f32 returns min3 of its inputs when one is NaN, i.e. -1).
+__device__ __forceinline__ float sample_quad(global_u32_ptr quad, unsigned pitch, float wm1f, float hm1f, float sx, float sy)
 {
     const float fx = floorf(sx), fy = floorf(sy);
     const float a = sx - fx, b = sy - fy;
-    const int x0 = (int)fminf(fmaxf(fx, -1.0f), (float)W);
-    const int y0 = (int)fminf(fmaxf(fy, -1.0f), (float)H);
-    // x0 >= W-1 clamps both taps to W-1, which is what quad W-1 holds; x0 == -1 is quad -1
-    const int qx = min(x0, W - 1) + 1, qy = min(y0, H - 1) + 1;
-    const uint32_t t = quad[(unsigned)__mul24(qy, W + 1) + (unsigned)qx];
+    const int qx = (int)__builtin_amdgcn_fmed3f(fx, -1.0f, wm1f);
+    const int qy = (int)__builtin_amdgcn_fmed3f(fy, -1.0f, hm1f);
+    // entry (qx, qy) lives at (qy + 1) * pitch + (qx + 1): byte offset = qy*4*pitch + 4*(pitch+1) + 4*qx >= 0
+    const int row4 = __mul24(qy, (int)(4u * pitch)) + (int)(4u * pitch + 4u);
+    const unsigned off = (unsigned)((qx << 2) + row4);
+    const uint32_t t = *(global_u32_ptr)((const __attribute__((address_space(1))) char *)quad + off);
     const float t00 = (float)(t & 0xFFu), t10 = (float)((t >> 8) & 0xFFu);
     const float t01 = (float)((t >> 16) & 0xFFu), t11 = (float)(t >> 24);
     const float top = fmaf(a, t10 - t00, t00);
@@ -468,9 +478,11 @@ __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst 
     if (rp.var < kMinVar) {
         return 2.0f;  // the reference tests this after sampling; the result is the same
     }
-    const float *__restrict__ src = vc.img;
-    const uint32_t *__restrict__ srcq = vc.quad;
+    const global_f32_ptr src = (global_f32_ptr)vc.img;
+    const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
     const int W = fa.W, Hh = fa.H;
+    const unsigned qpitch = (unsigned)(W + 1);
+    const float wm1f = (float)(W - 1), hm1f = (float)(Hh - 1);
     float sum_s = 0.0f, sum_ss = 0.0f, sum_rs = 0.0f;
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
@@ -485,7 +497,7 @@ __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst 
             const float inv = 1.0f / fmaf(H.h[7], yf, bz);
             const float sx = fmaf(H.h[1], yf, bx) * inv;
             const float sy = fmaf(H.h[4], yf, by) * inv;
-            const float v = kQuad ? sample_quad(srcq, W, Hh, sx, sy) : sample_bilinear(src, W, Hh, sx, sy);
+            const float v = kQuad ? sample_quad(srcq, qpitch, wm1f, hm1f, sx, sy) : sample_bilinear(src, W, Hh, sx, sy);
             row_s += v;
             row_ss = fmaf(v, v, row_ss);
             row_rs = fmaf(rp.v[i * kPatchN + j], v, row_rs);
