@@ -231,10 +231,8 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
     cost_array[0][0] = 2.0f;  // "= { 2.0f }" sets only the first element (APD.cu:1004)
     int positions[8];
     unsigned flags = 0;
-    uint8_t vw[APD_MAX_IMAGES];
-    for (int i = 0; i < APD_MAX_IMAGES; ++i) {
-        vw[i] = 0;
-    }
+    ViewWeights<NMAX> vw;
+    vw.clear();
     float weight_norm = 0.0f;
     uint32_t sel = 0;
     float4 plane_now = fa.planes[center];
@@ -260,13 +258,14 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
                 }
             }
             select_views<NMAX>(fa, iter, cost_array, priors, rng, vw, sel, weight_norm);
-            store_view_weight(fa, center, vw);
+            vw.store(fa, center);
             float final_costs[8];
             for (int i = 0; i < 8; ++i) {
                 float f = 0.0f;
                 for (int j = 0; j < nsrc; ++j) {
-                    if (vw[j] > 0) {
-                        f += (float)vw[j] * cost_array[i][j];
+                    const uint32_t wj = vw.get(j);
+                    if (wj > 0) {
+                        f += (float)wj * cost_array[i][j];
                     }
                 }
                 final_costs[i] = f / weight_norm;
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
             }
             cost_now = 0.0f;
             for (int i = 0; i < nsrc; ++i) {
-                cost_now += (float)vw[i] * cost_array[8][i];
+                cost_now += (float)vw.get(i) * cost_array[8][i];
             }
             cost_now /= weight_norm;
             cost_committed = cost_now;  // costs[center] = cost_now (:1295)
@@ -321,8 +320,11 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
             const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
             if (h < 9) {
                 cost_array[h][v] = c;
-            } else if (vw[v] > 0) {
-                tc += (float)vw[v] * c;
+            } else {
+                const uint32_t wv = vw.get(v);
+                if (wv > 0) {
+                    tc += (float)wv * c;
+                }
             }
         }
         if (h >= 9) {  // PlaneHypothesisRefinementStrong accept test (:881-888)
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256) void k1213_filter_strong(FrameArgs fa, int col
 //   kLocalRefine == true : sum_sel ncc*w (+ gf*geom*w)            (:2217-2220)
 template <bool kLocalRefine, bool kQuad>
 __device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, const RefPatch &rp, int px, int py, const float4 origin,
-                                                       float depth, uint32_t sel, const uint8_t *vw)
+                                                       float depth, uint32_t sel, const ViewWeights<32> &vw)
 {
     float4 pl = origin;
     pl.w = distance_to_origin(fa, px, py, depth, pl.x, pl.y, pl.z);
@@ -425,9 +427,10 @@ __device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, cons
         if (bit_test(sel, (unsigned)v)) {
             const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
             if (kLocalRefine) {
-                acc += c * (float)vw[v];
+                const float wv = (float)vw.get(v);
+                acc += c * wv;
                 if (fa.geom_consistency) {
-                    acc += fa.geom_factor * geom_cost(fa, fa.views[v], px, py, pl) * (float)vw[v];
+                    acc += fa.geom_factor * geom_cost(fa, fa.views[v], px, py, pl) * wv;
                 }
             } else {
                 float tc = 0.0f;
@@ -435,7 +438,7 @@ __device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, cons
                 if (fa.geom_consistency) {
                     tc += fa.geom_factor * geom_cost(fa, fa.views[v], px, py, pl);
                 }
-                acc += tc * (float)vw[v];
+                acc += tc * (float)vw.get(v);
             }
         }
     }
@@ -443,14 +446,14 @@ __device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, cons
 }
 
 // baseline + weight sum over the selected views (:2036-2044); no image access
-__device__ __forceinline__ int baseline_and_weight(const FrameArgs &fa, uint32_t sel, const uint8_t *vw, float &base_line, float &weight_normal)
+__device__ __forceinline__ int baseline_and_weight(const FrameArgs &fa, uint32_t sel, const ViewWeights<32> &vw, float &base_line, float &weight_normal)
 {
     float bl = 0, wn = 0.0f;
     int valid = 0;
     for (int v = 0; v < fa.num_src; ++v) {
         if (bit_test(sel, (unsigned)v)) {
             const ViewConst &vc = fa.views[v];
-            wn += (float)vw[v];
+            wn += (float)vw.get(v);
             const float d0 = fa.c[0] - vc.c[0];
             const float d1 = fa.c[1] - vc.c[1];
             const float d2 = fa.c[2] - vc.c[2];
@@ -486,8 +489,8 @@ __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
         return;
     }
     const uint32_t sel = fa.selected_views[center];
-    uint8_t vw[APD_MAX_IMAGES];
-    load_view_weight(fa, center, vw);
+    ViewWeights<32> vw;
+    vw.load(fa, center);
     float base_line, weight_normal;
     const int valid = baseline_and_weight(fa, sel, vw, base_line, weight_normal);
     if (valid == 0) {
@@ -561,8 +564,8 @@ __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
         return;
     }
     const uint32_t sel = fa.selected_views[center];
-    uint8_t vw[APD_MAX_IMAGES];
-    load_view_weight(fa, center, vw);
+    ViewWeights<32> vw;
+    vw.load(fa, center);
     float base_line, weight_normal;
     const int valid = baseline_and_weight(fa, sel, vw, base_line, weight_normal);
     if (weight_normal == 0 || valid == 0) {

@@ -502,10 +502,8 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour,
     cost_array[0][0] = 2.0f;  // APD.cu:1345
     unsigned flags = 0;
     float4 cand[8];
-    uint8_t vw[APD_MAX_IMAGES];
-    for (int i = 0; i < APD_MAX_IMAGES; ++i) {
-        vw[i] = 0;
-    }
+    ViewWeights<NMAX> vw;
+    vw.clear();
     float weight_norm = 0.0f;
     uint32_t sel = 0;
     float4 plane_now = fa.planes[center];
@@ -545,20 +543,20 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour,
                 }
             }
             select_views<NMAX>(fa, iter, cost_array, priors, rng, vw, sel, weight_norm);
-            store_view_weight(fa, center, vw);
+            vw.store(fa, center);
             float final_costs[8];
             for (int i = 0; i < 8; ++i) {
                 float f = 0.0f;
                 for (int j = 0; j < nsrc; ++j) {
-                    if (vw[j] > 0) {
+                    if (vw.get(j) > 0) {
                         if (fa.geom_consistency) {
                             if (flags & (1u << i)) {
-                                f += (float)vw[j] * (cost_array[i][j] + fa.geom_factor * geom_cost(fa, fa.views[j], px, py, cand[i]));
+                                f += (float)vw.get(j) * (cost_array[i][j] + fa.geom_factor * geom_cost(fa, fa.views[j], px, py, cand[i]));
                             } else {
-                                f += (float)vw[j] * (cost_array[i][j] + fa.geom_factor * 3.0f);
+                                f += (float)vw.get(j) * (cost_array[i][j] + fa.geom_factor * 3.0f);
                             }
                         } else {
-                            f += (float)vw[j] * cost_array[i][j];
+                            f += (float)vw.get(j) * cost_array[i][j];
                         }
                     }
                 }
@@ -575,9 +573,9 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour,
             cost_now = 0.0f;
             for (int i = 0; i < nsrc; ++i) {
                 if (fa.geom_consistency) {
-                    cost_now += (float)vw[i] * (cost_array[8][i] + fa.geom_factor * geom_cost(fa, fa.views[i], px, py, plane_now));
+                    cost_now += (float)vw.get(i) * (cost_array[8][i] + fa.geom_factor * geom_cost(fa, fa.views[i], px, py, plane_now));
                 } else {
-                    cost_now += (float)vw[i] * cost_array[8][i];
+                    cost_now += (float)vw.get(i) * cost_array[8][i];
                 }
             }
             cost_now /= weight_norm;
@@ -626,14 +624,14 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour,
             } else if (h == 15) {
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                tc += (float)vw[v] * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
+                tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
             } else {
                 const float c = ncc_deformed<kQuad>(fa, vc, v, rp, nb, px, py, pl);
-                if (vw[v] > 0) {
+                if (vw.get(v) > 0) {
                     if (fa.geom_consistency) {
-                        tc += (float)vw[v] * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
+                        tc += (float)vw.get(v) * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
                     } else {
-                        tc += (float)vw[v] * c;
+                        tc += (float)vw.get(v) * c;
                     }
                 }
             }

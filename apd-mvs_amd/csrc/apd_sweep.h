@@ -59,12 +59,79 @@ __device__ __forceinline__ bool checkerboard_active(const FrameArgs &fa, const T
 }
 
 // ------------------------------------------------------------------------------------------------
+// view weights: counts 0..15 (15 draws, APD.cu:1249) kept as nibbles in registers; the reference's
+// uchar[32] per pixel (view_weight_cuda) is still what is stored in HBM.
+// ------------------------------------------------------------------------------------------------
+
+template <int NMAX>
+struct ViewWeights {
+    static constexpr int kWords = NMAX / 8;
+    uint32_t w[kWords];
+
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) {
+            w[i] = 0;
+        }
+    }
+    __device__ __forceinline__ uint32_t word(int v) const
+    {
+        uint32_t x = w[0];
+#pragma unroll
+        for (int i = 1; i < kWords; ++i) {
+            x = ((v >> 3) == i) ? w[i] : x;
+        }
+        return x;
+    }
+    __device__ __forceinline__ uint32_t get(int v) const { return (word(v) >> ((v & 7) * 4)) & 15u; }
+    __device__ __forceinline__ void inc(int v)
+    {
+        const uint32_t one = 1u << ((v & 7) * 4);
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) {
+            w[i] += ((v >> 3) == i) ? one : 0u;
+        }
+    }
+    // view_weight_cuda layout: one byte per view, 32 bytes per pixel
+    __device__ __forceinline__ void store(const FrameArgs &fa, int center) const
+    {
+        uint32_t b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t nib = (i / 2 < kWords) ? (w[i / 2 < kWords ? i / 2 : 0] >> ((i & 1) * 16)) & 0xFFFFu : 0u;
+            b[i] = (nib & 15u) | (((nib >> 4) & 15u) << 8) | (((nib >> 8) & 15u) << 16) | (((nib >> 12) & 15u) << 24);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(fa.view_weight + (size_t)center * APD_MAX_IMAGES);
+        dst[0] = make_uint4(b[0], b[1], b[2], b[3]);
+        dst[1] = make_uint4(b[4], b[5], b[6], b[7]);
+    }
+    __device__ __forceinline__ void load(const FrameArgs &fa, int center)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(fa.view_weight + (size_t)center * APD_MAX_IMAGES);
+        const uint4 a = src[0], c = src[1];
+        const uint32_t b[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t d = b[2 * i + k];
+                const uint32_t nib = (d & 15u) | (((d >> 8) & 15u) << 4) | (((d >> 16) & 15u) << 8) | (((d >> 24) & 15u) << 12);
+                x |= nib << (16 * k);
+            }
+            w[i] = x;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // view selection shared by strong (:1203-1271) and weak (:1365-1434) propagation
 // ------------------------------------------------------------------------------------------------
 
 template <int NMAX>
 __device__ __forceinline__ void select_views(const FrameArgs &fa, int iter, const float (*cost_array)[NMAX], const float *priors,
-                                             Rng &rng, uint8_t *vw, uint32_t &sel_out, float &weight_norm_out)
+                                             Rng &rng, ViewWeights<NMAX> &vw, uint32_t &sel_out, float &weight_norm_out)
 {
     const int nsrc = fa.num_src;
     float probs[NMAX];
@@ -106,7 +173,7 @@ __device__ __forceinline__ void select_views(const FrameArgs &fa, int iter, cons
         const float rp = rng_uniform(rng) - FLT_EPSILON;
         for (int v = 0; v < nsrc; ++v) {
             if (probs[v] > rp) {
-                vw[v] += 1;
+                vw.inc(v);
                 break;
             }
         }
@@ -114,25 +181,14 @@ __device__ __forceinline__ void select_views(const FrameArgs &fa, int iter, cons
     uint32_t sel = 0;
     float wn = 0;
     for (int i = 0; i < nsrc; ++i) {
-        if (vw[i] > 0) {
+        const uint32_t wi = vw.get(i);
+        if (wi > 0) {
             sel |= 1u << i;
-            wn += (float)vw[i];
+            wn += (float)wi;
         }
     }
     sel_out = sel;
     weight_norm_out = wn;
-}
-
-__device__ __forceinline__ void store_view_weight(const FrameArgs &fa, int center, const uint8_t *vw)
-{
-    uint32_t w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        w[i] = (uint32_t)vw[4 * i] | ((uint32_t)vw[4 * i + 1] << 8) | ((uint32_t)vw[4 * i + 2] << 16) | ((uint32_t)vw[4 * i + 3] << 24);
-    }
-    uint4 *dst = reinterpret_cast<uint4 *>(fa.view_weight + (size_t)center * APD_MAX_IMAGES);
-    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 // The five refinement hypotheses of APD.cu:855-867 / :939-951 (RNG order: depth, normal, depth, 3 angles).
@@ -156,20 +212,6 @@ __device__ __forceinline__ void make_refinement_set(const FrameArgs &fa, int px,
     normals[2] = n_rand;
     normals[3] = n_pert;
     normals[4] = plane;
-}
-
-__device__ __forceinline__ void load_view_weight(const FrameArgs &fa, int center, uint8_t *vw)
-{
-    const uint4 *src = reinterpret_cast<const uint4 *>(fa.view_weight + (size_t)center * APD_MAX_IMAGES);
-    const uint4 a = src[0], b = src[1];
-    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        vw[4 * i + 0] = (uint8_t)(w[i] & 0xFF);
-        vw[4 * i + 1] = (uint8_t)((w[i] >> 8) & 0xFF);
-        vw[4 * i + 2] = (uint8_t)((w[i] >> 16) & 0xFF);
-        vw[4 * i + 3] = (uint8_t)(w[i] >> 24);
-    }
 }
 
 }  // namespace apd
