@@ -24,7 +24,8 @@ def main():
                 agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
                 meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"], r["SGPR_Count"])
         for (k, c), v in sorted(agg.items()):
-            rows_out.append([k, c, len(v), sum(v) / len(v), min(v), max(v)] + list(meta[k]))
+            tail = v[2:] if len(v) > 2 else v  # drop the warm-up iteration's two launches (bench --warmup 1)
+            rows_out.append([k, c, len(v), sum(v) / len(v), min(v), max(v)] + list(meta[k]) + [sum(tail) / len(tail)])
     for path in sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)):
         agg = collections.defaultdict(list)
         with open(path) as f:
@@ -34,10 +35,11 @@ def main():
                     continue
                 agg[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
         for k, v in sorted(agg.items()):
-            rows_out.append([k, "duration_ns", len(v), sum(v) / len(v), min(v), max(v), "", "", "", "", "", ""])
+            tail = v[2:] if len(v) > 2 else v
+            rows_out.append([k, "duration_ns", len(v), sum(v) / len(v), min(v), max(v), "", "", "", "", "", "", sum(tail) / len(tail)])
     with open(dst, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "counter", "dispatches", "mean", "min", "max", "grid", "workgroup", "lds", "scratch", "vgpr", "sgpr"])
+        w.writerow(["kernel", "counter", "dispatches", "mean", "min", "max", "grid", "workgroup", "lds", "scratch", "vgpr", "sgpr", "mean_after_warmup"])
         w.writerows(rows_out)
     print("wrote", dst, len(rows_out), "rows")
 
@@ -52,14 +54,14 @@ def traffic_json(fetch_csv, write_csv, workload, dst, kernel_substr="k67_update_
         with open(path) as f:
             for r in csv.DictReader(f):
                 if kernel_substr in r["kernel"] and r["counter"] == counter:
-                    return float(r["mean"]), float(r["min"]), int(r["dispatches"])
+                    return float(r.get("mean_after_warmup") or r["mean"]), float(r["min"]), int(r["dispatches"])
         return None
     fe, wr = pick(fetch_csv, "FETCH_SIZE"), pick(write_csv, "WRITE_SIZE")
     rec = {"workload": workload, "kernel": kernel_substr, "dispatches": fe[2],
            "fetch_bytes_mean": fe[0] * 1024 * 2, "fetch_bytes_min": fe[1] * 1024 * 2,
            "write_bytes_mean": wr[0] * 1024, "write_bytes_min": wr[1] * 1024,
            "hbm_bytes_per_launch": fe[0] * 1024 * 2 + wr[0] * 1024,
-           "note": "FETCH_SIZE x2 (gfx950), WRITE_SIZE uncorrected; mean over dispatches; separate --pmc passes"}
+           "note": "FETCH_SIZE x2 (gfx950), WRITE_SIZE uncorrected; mean over the timed-region dispatches (warm-up launches dropped); separate --pmc passes"}
     with open(dst, "w") as f:
         json.dump(rec, f, indent=1)
     print("wrote", dst)
