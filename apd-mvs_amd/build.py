@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(OUT_DIR, "libapd_mi355x.so")
 SOURCES = ["apd_kernels.hip", "apd_kernels_weak.hip", "apd_capi.hip"]
 HEADERS = ["apd_device.h", "apd_sweep.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -67,6 +67,7 @@ struct apd_context {
     uint32_t *rng = nullptr, *selected_views = nullptr;
     uint8_t *view_weight = nullptr, *weak_info = nullptr, *weak_reliable = nullptr;
     short2 *nearest_strong = nullptr, *neighbours = nullptr;
+    int8_t *column_nearest = nullptr;
     int *neighbours_map = nullptr;
     size_t neighbours_cap = 0;
     FrameArgs fa{};
@@ -149,6 +150,7 @@ static void refresh_frame_args(apd_context *c)
     fa.weak_info = c->weak_info;
     fa.weak_reliable = c->weak_reliable;
     fa.nearest_strong = c->nearest_strong;
+    fa.column_nearest = c->column_nearest;
     fa.neighbours_map = c->neighbours_map;
     fa.neighbours = c->neighbours;
 }
@@ -227,6 +229,7 @@ int apd_create(apd_handle *out, int device, int width, int height, const apd_par
     HIP_TRY(hipMalloc(&c->weak_info, n));
     HIP_TRY(hipMalloc(&c->weak_reliable, n));
     HIP_TRY(hipMalloc(&c->nearest_strong, n * sizeof(short2)));
+    HIP_TRY(hipMalloc(&c->column_nearest, n));
     HIP_TRY(hipMalloc(&c->neighbours_map, n * sizeof(int)));
     HIP_TRY(hipMalloc(&c->views_dev, APD_MAX_IMAGES * sizeof(ViewConst)));
     HIP_TRY(hipMemsetAsync(c->costs, 0, n * sizeof(float), c->stream));
@@ -275,6 +278,7 @@ int apd_destroy(apd_handle c)
     hipFree(c->weak_info);
     hipFree(c->weak_reliable);
     hipFree(c->nearest_strong);
+    hipFree(c->column_nearest);
     hipFree(c->neighbours_map);
     hipFree(c->neighbours);
     for (auto &pe : c->pending) {

@@ -70,6 +70,7 @@ struct FrameArgs {
     uint8_t *weak_info;
     uint8_t *weak_reliable;
     short2 *nearest_strong;
+    int8_t *column_nearest;  // K2 scratch: dy of the nearest STRONG pixel in the same column, 127 = none within 100
     const int *neighbours_map;
     short2 *neighbours;      // 9 per weak pixel
 };
@@ -115,6 +116,22 @@ __device__ __forceinline__ float exp_poly(float x)
 }
 
 __device__ __forceinline__ float rsqrt_c4(float x) { return 1.0f / sqrtf(x); }
+
+// Correctly rounded reciprocal (contract C3) without the IEEE division sequence: v_rcp_f32 (<= 1 ulp)
+// followed by one FMA Newton step equals RN(1/z) bit for bit for every z whose biased exponent lies in
+// 27..227 -- checked over all 2^32 inputs on gfx950 by tools/valu_rates.hip.  Outside that range (tiny,
+// huge, zero, Inf, NaN) the IEEE division is taken; `ok` is meant to be hoisted out of sample loops.
+__device__ __forceinline__ bool recip_fast_ok(float z) { return fabsf(z) >= 0x1p-100f && fabsf(z) <= 0x1p100f; }
+
+__device__ __forceinline__ float recip_fast(float z)
+{
+    const float r = __builtin_amdgcn_rcpf(z);
+    const float e = fmaf(-z, r, 1.0f);
+    return fmaf(e, r, r);
+}
+
+__device__ __forceinline__ float recip_rn(float z, bool ok) { return __builtin_expect(ok, 1) ? recip_fast(z) : 1.0f / z; }
+__device__ __forceinline__ float recip_rn(float z) { return recip_rn(z, recip_fast_ok(z)); }
 
 // ------------------------------------------------------------------------------------------------
 // XORWOW (contract C8): state kept in six registers; AoS of 6 words per pixel in HBM
@@ -320,7 +337,7 @@ struct Homography {
 // q = n / d of the plane hypothesis (three multiplies by a correctly rounded 1/d)
 __device__ __forceinline__ void plane_q(const float4 pl, float &qx, float &qy, float &qz)
 {
-    const float inv_w = 1.0f / pl.w;
+    const float inv_w = recip_rn(pl.w);
     qx = pl.x * inv_w;
     qy = pl.y * inv_w;
     qz = pl.z * inv_w;
@@ -354,7 +371,7 @@ __device__ __forceinline__ void correspond(const Homography &H, float xf, float 
     const float X = fmaf(H.h[1], yf, fmaf(H.h[0], xf, H.h[2]));
     const float Y = fmaf(H.h[4], yf, fmaf(H.h[3], xf, H.h[5]));
     const float Z = fmaf(H.h[7], yf, fmaf(H.h[6], xf, H.h[8]));
-    const float inv = 1.0f / Z;
+    const float inv = recip_rn(Z);
     ox = X * inv;
     oy = Y * inv;
 }
@@ -397,21 +414,38 @@ typedef const __attribute__((address_space(1))) float *global_f32_ptr;
 // Index math: floor -> v_med3_f32 clamp to [-1, W-1] -> cvt; a NaN/Inf coordinate gives a NaN weight,
 // so the sample is NaN whatever texel is read and the clamp only has to keep the address in range
 // (v_med3_f32 returns min3 of its inputs when one is NaN, i.e. -1).
-__device__ __forceinline__ float sample_quad(global_u32_ptr quad, unsigned pitch, float wm1f, float hm1f, float sx, float sy)
+// Split in two so a caller can put several gathers in flight before consuming the first one.
+__device__ __forceinline__ unsigned quad_offset(unsigned pitch4, float wm1f, float hm1f, float sx, float sy, float &a, float &b)
 {
     const float fx = floorf(sx), fy = floorf(sy);
-    const float a = sx - fx, b = sy - fy;
+    a = sx - fx;
+    b = sy - fy;
     const int qx = (int)__builtin_amdgcn_fmed3f(fx, -1.0f, wm1f);
     const int qy = (int)__builtin_amdgcn_fmed3f(fy, -1.0f, hm1f);
     // entry (qx, qy) lives at (qy + 1) * pitch + (qx + 1): byte offset = qy*4*pitch + 4*(pitch+1) + 4*qx >= 0
-    const int row4 = __mul24(qy, (int)(4u * pitch)) + (int)(4u * pitch + 4u);
-    const unsigned off = (unsigned)((qx << 2) + row4);
-    const uint32_t t = *(global_u32_ptr)((const __attribute__((address_space(1))) char *)quad + off);
+    const int row4 = __mul24(qy, (int)pitch4) + (int)(pitch4 + 4u);
+    return (unsigned)((qx << 2) + row4);
+}
+
+__device__ __forceinline__ uint32_t quad_fetch(global_u32_ptr quad, unsigned off)
+{
+    return *(global_u32_ptr)((const __attribute__((address_space(1))) char *)quad + off);
+}
+
+__device__ __forceinline__ float quad_lerp(uint32_t t, float a, float b)
+{
     const float t00 = (float)(t & 0xFFu), t10 = (float)((t >> 8) & 0xFFu);
     const float t01 = (float)((t >> 16) & 0xFFu), t11 = (float)(t >> 24);
     const float top = fmaf(a, t10 - t00, t00);
     const float bot = fmaf(a, t11 - t01, t01);
     return fmaf(b, bot - top, top);
+}
+
+__device__ __forceinline__ float sample_quad(global_u32_ptr quad, unsigned pitch, float wm1f, float hm1f, float sx, float sy)
+{
+    float a, b;
+    const unsigned off = quad_offset(4u * pitch, wm1f, hm1f, sx, sy, a, b);
+    return quad_lerp(quad_fetch(quad, off), a, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,6 +497,69 @@ __device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float 
     ref_patch_finish(rp);
 }
 
+// The 36 warped source samples of one fixed patch and their three moments (APD.cu:561-583), summed in the
+// reference's order (row partial sums, then total).  kFastRecip: every denominator is known to be in the
+// range where recip_fast is the correctly rounded reciprocal.
+template <bool kQuad, bool kFastRecip>
+__device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, const Homography &H,
+                                                  int px, int py, float &sum_s, float &sum_ss, float &sum_rs)
+{
+    const global_f32_ptr src = (global_f32_ptr)vc.img;
+    const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
+    const int W = fa.W, Hh = fa.H;
+    const unsigned qpitch = (unsigned)(W + 1);
+    const float wm1f = (float)(W - 1), hm1f = (float)(Hh - 1);
+    sum_s = 0.0f;
+    sum_ss = 0.0f;
+    sum_rs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kPatchN; ++i) {
+        const float xf = (float)(px + kPatchStep * i - kPatchRadius);
+        const float bx = fmaf(H.h[0], xf, H.h[2]);
+        const float by = fmaf(H.h[3], xf, H.h[5]);
+        const float bz = fmaf(H.h[6], xf, H.h[8]);
+        // one row of six samples: all six gathers are issued before the first is consumed
+        float v[kPatchN];
+        if (kQuad) {
+            float a[kPatchN], b[kPatchN];
+            uint32_t t[kPatchN];
+#pragma unroll
+            for (int j = 0; j < kPatchN; ++j) {
+                const float yf = (float)(py + kPatchStep * j - kPatchRadius);
+                const float z = fmaf(H.h[7], yf, bz);
+                const float inv = kFastRecip ? recip_fast(z) : 1.0f / z;
+                const float sx = fmaf(H.h[1], yf, bx) * inv;
+                const float sy = fmaf(H.h[4], yf, by) * inv;
+                t[j] = quad_fetch(srcq, quad_offset(4u * qpitch, wm1f, hm1f, sx, sy, a[j], b[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < kPatchN; ++j) {
+                v[j] = quad_lerp(t[j], a[j], b[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kPatchN; ++j) {
+                const float yf = (float)(py + kPatchStep * j - kPatchRadius);
+                const float z = fmaf(H.h[7], yf, bz);
+                const float inv = kFastRecip ? recip_fast(z) : 1.0f / z;
+                const float sx = fmaf(H.h[1], yf, bx) * inv;
+                const float sy = fmaf(H.h[4], yf, by) * inv;
+                v[j] = sample_bilinear(src, W, Hh, sx, sy);
+            }
+        }
+        float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            row_s += v[j];
+            row_ss = fmaf(v[j], v[j], row_ss);
+            row_rs = fmaf(rp.v[i * kPatchN + j], v[j], row_rs);
+        }
+        sum_s += row_s;
+        sum_ss += row_ss;
+        sum_rs += row_rs;
+    }
+}
+
 // ComputeBilateralNCCOld for plane q = n/d against source view vc.  kQuad selects the texel-quad image.
 template <bool kQuad>
 __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, int px, int py,
@@ -478,33 +575,21 @@ __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst 
     if (rp.var < kMinVar) {
         return 2.0f;  // the reference tests this after sampling; the result is the same
     }
-    const global_f32_ptr src = (global_f32_ptr)vc.img;
-    const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
-    const int W = fa.W, Hh = fa.H;
-    const unsigned qpitch = (unsigned)(W + 1);
-    const float wm1f = (float)(W - 1), hm1f = (float)(Hh - 1);
-    float sum_s = 0.0f, sum_ss = 0.0f, sum_rs = 0.0f;
-#pragma unroll
-    for (int i = 0; i < kPatchN; ++i) {
-        const float xf = (float)(px + kPatchStep * i - kPatchRadius);
-        const float bx = fmaf(H.h[0], xf, H.h[2]);
-        const float by = fmaf(H.h[3], xf, H.h[5]);
-        const float bz = fmaf(H.h[6], xf, H.h[8]);
-        float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kPatchN; ++j) {
-            const float yf = (float)(py + kPatchStep * j - kPatchRadius);
-            const float inv = 1.0f / fmaf(H.h[7], yf, bz);
-            const float sx = fmaf(H.h[1], yf, bx) * inv;
-            const float sy = fmaf(H.h[4], yf, by) * inv;
-            const float v = kQuad ? sample_quad(srcq, qpitch, wm1f, hm1f, sx, sy) : sample_bilinear(src, W, Hh, sx, sy);
-            row_s += v;
-            row_ss = fmaf(v, v, row_ss);
-            row_rs = fmaf(rp.v[i * kPatchN + j], v, row_rs);
-        }
-        sum_s += row_s;
-        sum_ss += row_ss;
-        sum_rs += row_rs;
+    // The denominator h6*x + h7*y + h8 is evaluated with monotone (rounded) fma, so over the 6x6 grid it
+    // stays between its values at the four corner samples: if those share a sign and lie in the
+    // fast-reciprocal range, every sample does.
+    const float x0 = (float)(px - kPatchRadius), x1 = (float)(px + kPatchRadius);
+    const float y0 = (float)(py - kPatchRadius), y1 = (float)(py + kPatchRadius);
+    const float b0 = fmaf(H.h[6], x0, H.h[8]), b1 = fmaf(H.h[6], x1, H.h[8]);
+    const float z00 = fmaf(H.h[7], y0, b0), z01 = fmaf(H.h[7], y1, b0);
+    const float z10 = fmaf(H.h[7], y0, b1), z11 = fmaf(H.h[7], y1, b1);
+    const float lo = fminf(fminf(z00, z01), fminf(z10, z11)), hi = fmaxf(fmaxf(z00, z01), fmaxf(z10, z11));
+    const bool fast_recip = (lo >= 0x1p-100f && hi <= 0x1p100f) || (hi <= -0x1p-100f && lo >= -0x1p100f);
+    float sum_s, sum_ss, sum_rs;
+    if (__builtin_expect(fast_recip, 1)) {
+        ncc_fixed_moments<kQuad, true>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+    } else {
+        ncc_fixed_moments<kQuad, false>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     }
     const float inv_w = 1.0f / 36.0f;
     sum_s *= inv_w;
@@ -537,7 +622,7 @@ __device__ __forceinline__ float patch_cost_generic(const FrameArgs &fa, const V
         for (int j = -radius; j <= radius; j += increment) {
             const float r = fetch_texel(ref, W, Hh, cx + i, cy + j);
             const float yf = (float)(cy + j);
-            const float inv = 1.0f / fmaf(H.h[7], yf, bz);
+            const float inv = recip_rn(fmaf(H.h[7], yf, bz));
             const float sx = fmaf(H.h[1], yf, bx) * inv;
             const float sy = fmaf(H.h[4], yf, by) * inv;
             const float v = sample_bilinear(src, W, Hh, sx, sy);

@@ -13,57 +13,66 @@ namespace apd {
 // ------------------------------------------------------------------------------------------------
 
 // The reference probes the 201x201 window column by column (x outer, y inner) and keeps the first
-// strictly smaller distance.  Here the 64 lanes of a wave share one WEAK pixel's window: each lane
-// scans a strided subset in the reference's order and the wave reduces (distance, visit index)
-// lexicographically, which picks exactly the probe the sequential scan would have kept.
-__global__ __launch_bounds__(256) void k2_find_nearest_strong(FrameArgs fa)
+// strictly smaller distance, i.e. the minimum of d2 = dx^2 + dy^2 with ties going to the smallest
+// (dx, dy) in lexicographic order.  That minimum separates: inside one column the winner is the
+// smallest |dy| (negative dy first), so pass A stores that dy per pixel and pass B scans the 201
+// columns of a WEAK pixel's row -- 402 probes instead of 40,401, same result bit for bit.
+constexpr int kNearestRadius = 100;
+constexpr int8_t kNoStrongInColumn = 127;
+
+__global__ __launch_bounds__(256) void k2a_column_nearest(FrameArgs fa)
 {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int W = fa.W, H = fa.H;
-    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (wave_global >= W * H) {
+    if (px >= W || py >= H) {
         return;
     }
-    const int center = wave_global;
-    const int py = center / W, px = center - py * W;
-    if (lane == 0) {
-        fa.nearest_strong[center] = make_short2(-1, -1);
-    }
-    if (fa.weak_info[center] != APD_WEAK) {
-        return;
-    }
-    const int radius = 100, side = 2 * radius + 1;
-    // sqrtf is monotone and the reference compares sqrt values: two different integer d2 can round
-    // to the same float only above 2^24, far beyond 2*100^2, so comparing d2 is equivalent.
-    int best_d2 = 0x7fffffff, best_idx = 0x7fffffff;
-    for (int idx = lane; idx < side * side; idx += 64) {
-        const int x = idx / side - radius, y = idx - (idx / side) * side - radius;
-        const int qx = px + x, qy = py + y;
-        if (qx < 0 || qy < 0 || qx >= W || qy >= H) {
-            continue;
+    const uint8_t *__restrict__ wi = fa.weak_info;
+    int8_t best = kNoStrongInColumn;
+    for (int k = 0; k <= kNearestRadius; ++k) {
+        if (py - k >= 0 && wi[px + (py - k) * W] == APD_STRONG) {
+            best = (int8_t)(-k);
+            break;
         }
-        if (fa.weak_info[qx + qy * W] == APD_STRONG) {
-            const int d2 = x * x + y * y;
-            if (d2 < best_d2) {  // idx only grows within a lane
-                best_d2 = d2;
-                best_idx = idx;
+        if (py + k < H && wi[px + (py + k) * W] == APD_STRONG) {
+            best = (int8_t)k;
+            break;
+        }
+    }
+    fa.column_nearest[px + py * W] = best;
+}
+
+__global__ __launch_bounds__(256) void k2b_row_search(FrameArgs fa)
+{
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = fa.W;
+    if (px >= W || py >= fa.H) {
+        return;
+    }
+    const int center = px + py * W;
+    short2 out = make_short2(-1, -1);
+    if (fa.weak_info[center] == APD_WEAK) {
+        // sqrtf is monotone and the reference compares sqrt values: two different integer d2 can round
+        // to the same float only above 2^24, far beyond 2*100^2, so comparing d2 is equivalent; its
+        // initial min_dist = 255.0f exceeds every distance in the window.
+        const int8_t *__restrict__ row = fa.column_nearest + py * W;
+        int best_d2 = 0x7fffffff;
+        const int x_lo = max(px - kNearestRadius, 0), x_hi = min(px + kNearestRadius, W - 1);
+        for (int qx = x_lo; qx <= x_hi; ++qx) {
+            const int dy = row[qx];
+            if (dy != kNoStrongInColumn) {
+                const int dx = qx - px;
+                const int d2 = dx * dx + dy * dy;
+                if (d2 < best_d2) {
+                    best_d2 = d2;
+                    out = make_short2((short)qx, (short)(py + dy));
+                }
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const int od2 = __shfl_xor(best_d2, off);
-        const int oidx = __shfl_xor(best_idx, off);
-        if (od2 < best_d2 || (od2 == best_d2 && oidx < best_idx)) {
-            best_d2 = od2;
-            best_idx = oidx;
-        }
-    }
-    if (lane == 0 && best_idx != 0x7fffffff) {
-        // "dist < min_dist" with min_dist = 255.0f initially: sqrt(d2) <= sqrt(20000) < 255 always
-        const int x = best_idx / side - radius, y = best_idx - (best_idx / side) * side - radius;
-        fa.nearest_strong[center] = make_short2((short)(px + x), (short)(py + y));
-    }
+    fa.nearest_strong[center] = out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -696,10 +705,12 @@ hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipS
 {
     const int n = fa.W * fa.H;
     switch (kernel_id) {
-    case APD_K2_FIND_NEAREST_STRONG:
-        // one wave per pixel: 4 pixels per 256-thread workgroup
-        hipLaunchKernelGGL(k2_find_nearest_strong, dim3((n + 3) / 4), dim3(256), 0, s, fa);
+    case APD_K2_FIND_NEAREST_STRONG: {
+        const dim3 grid((fa.W + 63) / 64, (fa.H + 3) / 4);
+        hipLaunchKernelGGL(k2a_column_nearest, grid, dim3(256), 0, s, fa);
+        hipLaunchKernelGGL(k2b_row_search, grid, dim3(256), 0, s, fa);
         break;
+    }
     case APD_K3_GEN_NEIGHBOURS:
         hipLaunchKernelGGL(k3_gen_neighbours, dim3((fa.W + 7) / 8, (fa.H + 7) / 8), dim3(64), 0, s, fa);
         break;

@@ -1,0 +1,219 @@
+// valu_rates.hip -- gfx950 micro-measurements behind the sample loop of ncc_fixed:
+//   (1) issue cost of v_fma_f32 / v_pk_fma_f32 / v_rcp_f32 / IEEE division / rcp+Newton
+//   (2) exhaustive check: is rcp + one FMA Newton step the correctly rounded reciprocal?
+//   (3) exhaustive check of v_fract_f32 against min(x - floor(x), 0x1.fffffep-1f)
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/valu_rates.hip -o /tmp/valu_rates
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define CHECK(x)                                                                     \
+    do {                                                                             \
+        hipError_t e = (x);                                                          \
+        if (e != hipSuccess) {                                                       \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            return 1;                                                                \
+        }                                                                            \
+    } while (0)
+
+constexpr int kChains = 8;
+constexpr int kIters = 4096;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void rate_kernel(float *out, float seed)
+{
+    float a[kChains];
+    v2f p[kChains];
+    for (int i = 0; i < kChains; ++i) {
+        a[i] = seed + (float)(threadIdx.x + i) * 1e-3f;
+        p[i] = v2f{a[i], a[i] + 0.5f};
+    }
+    const float m = 0.999f + seed * 1e-6f, c = 1e-3f;
+    const v2f pm = v2f{m, m}, pc = v2f{c, c};
+#pragma unroll 1
+    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < kChains; ++i) {
+            if (MODE == 0) {
+                a[i] = fmaf(a[i], m, c);
+            } else if (MODE == 1) {
+                p[i] = __builtin_elementwise_fma(p[i], pm, pc);
+            } else if (MODE == 2) {
+                a[i] = __builtin_amdgcn_rcpf(a[i]);
+            } else if (MODE == 3) {
+                a[i] = 1.0f / a[i];
+            } else if (MODE == 4) {
+                const float r = __builtin_amdgcn_rcpf(a[i]);
+                const float e = fmaf(-a[i], r, 1.0f);
+                a[i] = fmaf(e, r, r);
+            } else if (MODE == 5) {
+                a[i] = floorf(a[i] * m);
+            } else if (MODE == 6) {
+                p[i] = p[i] * pm;
+            } else if (MODE == 7) {
+                p[i] = p[i] + pc;
+            } else if (MODE == 8) {
+                a[i] = __builtin_amdgcn_fmed3f(a[i], -1.0f, m);
+            } else if (MODE == 9) {
+                a[i] = (float)(((uint32_t)__float_as_uint(a[i]) >> 8) & 0xFFu) + c;  // cvt_f32_ubyte1 + add
+            } else if (MODE == 10) {
+                a[i] = sqrtf(a[i]);
+            } else if (MODE == 11) {
+                a[i] = __builtin_amdgcn_fractf(a[i] * m);
+            }
+        }
+    }
+    float s = 0.0f;
+    for (int i = 0; i < kChains; ++i) {
+        s += a[i] + p[i].x + p[i].y;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// ---- exhaustive reciprocal check -----------------------------------------------------------------
+__device__ __forceinline__ float recip_newton(float z)
+{
+    const float r = __builtin_amdgcn_rcpf(z);
+    const float e = fmaf(-z, r, 1.0f);
+    return fmaf(e, r, r);
+}
+
+__global__ __launch_bounds__(256) void recip_check(unsigned long long *counts, uint32_t *examples)
+{
+    // counts[0]: mismatches with |z| in [2^-100, 2^100]; [1]: mismatches elsewhere (finite normal z);
+    // [2]: mismatches for denormal/zero/inf/nan z; [3]: raw rcp != exact in the mid range
+    const uint32_t bits = blockIdx.x * 256u + threadIdx.x + (uint32_t)blockIdx.y * 0x01000000u * 1u;
+    (void)bits;
+}
+
+__global__ __launch_bounds__(256) void recip_check2(uint32_t base, unsigned long long *counts, uint32_t *examples)
+{
+    const uint32_t bits = base + blockIdx.x * 256u + threadIdx.x;
+    const float z = __uint_as_float(bits);
+    const float exact = 1.0f / z;
+    const float fast = recip_newton(z);
+    const float raw = __builtin_amdgcn_rcpf(z);
+    const uint32_t ex = (bits >> 23) & 0xFFu;
+    const bool same = (__float_as_uint(exact) == __float_as_uint(fast)) || (exact != exact && fast != fast);
+    int cat;
+    if (ex == 0 || ex == 255) {
+        cat = 2;
+    } else if (ex >= 27 && ex <= 227) {
+        cat = 0;
+    } else {
+        cat = 1;
+    }
+    if (!same) {
+        const unsigned long long k = atomicAdd(&counts[cat], 1ull);
+        if (cat == 0 && k < 16) {
+            examples[2 * k] = bits;
+            examples[2 * k + 1] = __float_as_uint(fast);
+        }
+    }
+    if (cat == 0 && __float_as_uint(raw) != __float_as_uint(exact)) {
+        atomicAdd(&counts[3], 1ull);
+    }
+}
+
+__global__ __launch_bounds__(256) void fract_check(uint32_t base, unsigned long long *counts, uint32_t *examples)
+{
+    const uint32_t bits = base + blockIdx.x * 256u + threadIdx.x;
+    const float x = __uint_as_float(bits);
+    const float hw = __builtin_amdgcn_fractf(x);
+    const float sub = x - floorf(x);
+    const float emu = fminf(sub, 0x1.fffffep-1f);
+    const bool same_emu = (__float_as_uint(hw) == __float_as_uint(emu)) || (hw != hw && emu != emu);
+    const bool same_sub = (__float_as_uint(hw) == __float_as_uint(sub)) || (hw != hw && sub != sub);
+    if (!same_emu) {
+        const unsigned long long k = atomicAdd(&counts[0], 1ull);
+        if (k < 16) {
+            examples[2 * k] = bits;
+            examples[2 * k + 1] = __float_as_uint(hw);
+        }
+    }
+    if (!same_sub) {
+        atomicAdd(&counts[1], 1ull);
+    }
+}
+
+template <int MODE>
+static int run_rate(const char *name, int ops_per_iter_per_chain, float *dout)
+{
+    const int blocks = 256 * 8, threads = 256;  // 8 workgroups (32 waves) per CU: 8 waves per SIMD
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(threads), 0, 0, dout, 1.5f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(threads), 0, 0, dout, 1.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double waves = (double)blocks * threads / 64.0;
+    const double wave_insts = waves * kIters * kChains * ops_per_iter_per_chain;
+    const double simd_cycles = ms * 1e-3 * 2.4e9 * 256 * 4;
+    printf("%-34s %8.3f ms  %6.2f SIMD-cycles per wave-op (at 2.4 GHz)\n", name, ms, simd_cycles / wave_insts);
+    return 0;
+}
+
+int main()
+{
+    float *dout;
+    CHECK(hipMalloc(&dout, 256 * 8 * 256 * sizeof(float)));
+    run_rate<0>("v_fma_f32", 1, dout);
+    run_rate<1>("v_pk_fma_f32 (per pk op)", 1, dout);
+    run_rate<6>("v_pk_mul_f32 (per pk op)", 1, dout);
+    run_rate<7>("v_pk_add_f32 (per pk op)", 1, dout);
+    run_rate<2>("v_rcp_f32", 1, dout);
+    run_rate<10>("sqrtf (IEEE)", 1, dout);
+    run_rate<3>("1.0f/x (IEEE)", 1, dout);
+    run_rate<4>("rcp + 2 fma Newton (whole)", 1, dout);
+    run_rate<5>("mul + floor (2 ops)", 2, dout);
+    run_rate<8>("v_med3_f32", 1, dout);
+    run_rate<9>("cvt_f32_ubyte1 + add (2-3 ops)", 2, dout);
+    run_rate<11>("mul + v_fract_f32 (2 ops)", 2, dout);
+
+    unsigned long long *dcounts, hcounts[4];
+    uint32_t *dex, hex[32];
+    CHECK(hipMalloc(&dcounts, 4 * sizeof(unsigned long long)));
+    CHECK(hipMalloc(&dex, 32 * sizeof(uint32_t)));
+    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
+    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
+    for (uint32_t hi = 0; hi < 256; ++hi) {
+        hipLaunchKernelGGL(recip_check2, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
+    }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
+    printf("recip rcp+Newton vs IEEE 1/z over all 2^32 inputs: mismatches mid-range(exp 27..227)=%llu, outer normal=%llu, "
+           "denormal/zero/inf/nan=%llu; raw v_rcp_f32 != exact in mid-range: %llu\n",
+           hcounts[0], hcounts[1], hcounts[2], hcounts[3]);
+    for (int i = 0; i < 16 && (unsigned long long)i < hcounts[0]; ++i) {
+        float z, f;
+        memcpy(&z, &hex[2 * i], 4);
+        memcpy(&f, &hex[2 * i + 1], 4);
+        printf("   z=%08x (%g) fast=%08x exact=%a\n", hex[2 * i], z, hex[2 * i + 1], 1.0f / z);
+    }
+    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
+    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
+    for (uint32_t hi = 0; hi < 256; ++hi) {
+        hipLaunchKernelGGL(fract_check, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
+    }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
+    printf("v_fract_f32 vs min(x-floor(x), 0x1.fffffep-1): mismatches=%llu ; vs plain x-floor(x): mismatches=%llu\n", hcounts[0],
+           hcounts[1]);
+    for (int i = 0; i < 16 && (unsigned long long)i < hcounts[0]; ++i) {
+        float z;
+        memcpy(&z, &hex[2 * i], 4);
+        printf("   x=%08x (%g) hw=%08x\n", hex[2 * i], z, hex[2 * i + 1]);
+    }
+    return 0;
+}
