@@ -497,6 +497,137 @@ __device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float 
     ref_patch_finish(rp);
 }
 
+// A dependent VALU chain issues one instruction per ~12 cycles per wave on gfx950 and independent ones one per
+// ~5 (tools/valu_rates.hip), and only 2-3 waves fit a SIMD here, so the six samples of a patch row are
+// computed in lock step: every stage below is six independent instructions, and the scheduler is not
+// allowed to re-serialise the chains to save registers.
+#define APD_STAGE() __builtin_amdgcn_sched_barrier(0)
+
+// Sample positions of one patch row (fixed x, six y) -> bilinear weights + texel-quad gathers in flight.
+template <bool kFastRecip>
+__device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN],
+                                               global_u32_ptr srcq, unsigned pitch4, float wm1f, float hm1f,
+                                               float (&a)[kPatchN], float (&b)[kPatchN], uint32_t (&t)[kPatchN])
+{
+    float z[kPatchN], X[kPatchN], Y[kPatchN], r[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        z[j] = fmaf(H.h[7], yf[j], bz);
+        X[j] = fmaf(H.h[1], yf[j], bx);
+        Y[j] = fmaf(H.h[4], yf[j], by);
+    }
+    APD_STAGE();
+    if (kFastRecip) {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = __builtin_amdgcn_rcpf(z[j]);
+        }
+        APD_STAGE();
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            z[j] = fmaf(-z[j], r[j], 1.0f);
+        }
+        APD_STAGE();
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = fmaf(z[j], r[j], r[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = 1.0f / z[j];
+        }
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        X[j] *= r[j];
+        Y[j] *= r[j];
+    }
+    APD_STAGE();
+    float fx[kPatchN], fy[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        fx[j] = floorf(X[j]);
+        fy[j] = floorf(Y[j]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        a[j] = X[j] - fx[j];
+        b[j] = Y[j] - fy[j];
+        fx[j] = __builtin_amdgcn_fmed3f(fx[j], -1.0f, wm1f);
+        fy[j] = __builtin_amdgcn_fmed3f(fy[j], -1.0f, hm1f);
+    }
+    APD_STAGE();
+    int qx[kPatchN], qy[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        qx[j] = (int)fx[j];
+        qy[j] = (int)fy[j];
+    }
+    APD_STAGE();
+    // entry (qx, qy) lives at (qy + 1) * pitch + (qx + 1): byte offset = qy*4*pitch + 4*(pitch+1) + 4*qx >= 0
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        qy[j] = __mul24(qy[j], (int)pitch4) + (int)(pitch4 + 4u);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        qx[j] = (qx[j] << 2) + qy[j];
+    }
+    APD_STAGE();
+#ifdef APD_EXPERIMENT_QUAD_SAME_ADDR  // timing experiment only (wrong results): the 4 lanes of a quad gather one address
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        qx[j] = __builtin_amdgcn_mov_dpp(qx[j], 0x00, 0xF, 0xF, true);
+    }
+    APD_STAGE();
+#endif
+#ifdef APD_EXPERIMENT_ADDR_ZERO  // timing experiment only: every gather hits the same L1 line
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        qx[j] = qx[j] & 0x7c;
+    }
+    APD_STAGE();
+#endif
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        t[j] = quad_fetch(srcq, (unsigned)qx[j]);
+    }
+}
+
+// Gathered quads + weights of one row -> six bilinear values (same three fmaf per sample as quad_lerp).
+__device__ __forceinline__ void quad_row_lerp(const uint32_t (&t)[kPatchN], const float (&a)[kPatchN], const float (&b)[kPatchN],
+                                              float (&v)[kPatchN])
+{
+    float t00[kPatchN], t01[kPatchN], d0[kPatchN], d1[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        t00[j] = (float)(t[j] & 0xFFu);
+        t01[j] = (float)((t[j] >> 16) & 0xFFu);
+        d0[j] = (float)((t[j] >> 8) & 0xFFu) - t00[j];
+        d1[j] = (float)(t[j] >> 24) - t01[j];
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        t00[j] = fmaf(a[j], d0[j], t00[j]);
+        t01[j] = fmaf(a[j], d1[j], t01[j]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        t01[j] -= t00[j];
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        v[j] = fmaf(b[j], t01[j], t00[j]);
+    }
+}
+
 // The 36 warped source samples of one fixed patch and their three moments (APD.cu:561-583), summed in the
 // reference's order (row partial sums, then total).  kFastRecip: every denominator is known to be in the
 // range where recip_fast is the correctly rounded reciprocal.
@@ -507,43 +638,46 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     const global_f32_ptr src = (global_f32_ptr)vc.img;
     const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
     const int W = fa.W, Hh = fa.H;
-    const unsigned qpitch = (unsigned)(W + 1);
+    const unsigned pitch4 = 4u * (unsigned)(W + 1);
     const float wm1f = (float)(W - 1), hm1f = (float)(Hh - 1);
+    float yf[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        yf[j] = (float)(py + kPatchStep * j - kPatchRadius);
+    }
     sum_s = 0.0f;
     sum_ss = 0.0f;
     sum_rs = 0.0f;
+    // software pipeline over the six rows: row i+1's gathers are in flight while row i is reduced
+    float a[2][kPatchN], b[2][kPatchN];
+    uint32_t t[2][kPatchN];
+    if (kQuad) {
+        const float xf = (float)(px - kPatchRadius);
+        quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq, pitch4,
+                                   wm1f, hm1f, a[0], b[0], t[0]);
+    }
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
-        const float xf = (float)(px + kPatchStep * i - kPatchRadius);
-        const float bx = fmaf(H.h[0], xf, H.h[2]);
-        const float by = fmaf(H.h[3], xf, H.h[5]);
-        const float bz = fmaf(H.h[6], xf, H.h[8]);
-        // one row of six samples: all six gathers are issued before the first is consumed
         float v[kPatchN];
         if (kQuad) {
-            float a[kPatchN], b[kPatchN];
-            uint32_t t[kPatchN];
-#pragma unroll
-            for (int j = 0; j < kPatchN; ++j) {
-                const float yf = (float)(py + kPatchStep * j - kPatchRadius);
-                const float z = fmaf(H.h[7], yf, bz);
-                const float inv = kFastRecip ? recip_fast(z) : 1.0f / z;
-                const float sx = fmaf(H.h[1], yf, bx) * inv;
-                const float sy = fmaf(H.h[4], yf, by) * inv;
-                t[j] = quad_fetch(srcq, quad_offset(4u * qpitch, wm1f, hm1f, sx, sy, a[j], b[j]));
+            if (i + 1 < kPatchN) {
+                const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
+                quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq,
+                                           pitch4, wm1f, hm1f, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
             }
-#pragma unroll
-            for (int j = 0; j < kPatchN; ++j) {
-                v[j] = quad_lerp(t[j], a[j], b[j]);
-            }
+            APD_STAGE();
+            quad_row_lerp(t[i & 1], a[i & 1], b[i & 1], v);
         } else {
+            const float xf = (float)(px + kPatchStep * i - kPatchRadius);
+            const float bx = fmaf(H.h[0], xf, H.h[2]);
+            const float by = fmaf(H.h[3], xf, H.h[5]);
+            const float bz = fmaf(H.h[6], xf, H.h[8]);
 #pragma unroll
             for (int j = 0; j < kPatchN; ++j) {
-                const float yf = (float)(py + kPatchStep * j - kPatchRadius);
-                const float z = fmaf(H.h[7], yf, bz);
+                const float z = fmaf(H.h[7], yf[j], bz);
                 const float inv = kFastRecip ? recip_fast(z) : 1.0f / z;
-                const float sx = fmaf(H.h[1], yf, bx) * inv;
-                const float sy = fmaf(H.h[4], yf, by) * inv;
+                const float sx = fmaf(H.h[1], yf[j], bx) * inv;
+                const float sy = fmaf(H.h[4], yf[j], by) * inv;
                 v[j] = sample_bilinear(src, W, Hh, sx, sy);
             }
         }

@@ -189,7 +189,7 @@ __device__ __forceinline__ bool arm_candidate(const FrameArgs &fa, int px, int p
 // One launch = one colour.  Hypotheses 0..7 are the propagation arms, 8 the current plane,
 // 9..13 the refinement set; a single loop keeps one inlined copy of the 36-sample NCC.
 #ifndef APD_K67_WAVES
-#define APD_K67_WAVES 2  // minimum waves per SIMD the register allocator must leave room for
+#define APD_K67_WAVES 3  // minimum waves per SIMD the register allocator must leave room for (2: 32.0 ms, 3: 28.8 ms, 4: 38.4 ms per launch at 4096x3072 N=8)
 #endif
 template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArgs fa, int colour, int iter)

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -82,14 +83,6 @@ __device__ __forceinline__ float recip_newton(float z)
     return fmaf(e, r, r);
 }
 
-__global__ __launch_bounds__(256) void recip_check(unsigned long long *counts, uint32_t *examples)
-{
-    // counts[0]: mismatches with |z| in [2^-100, 2^100]; [1]: mismatches elsewhere (finite normal z);
-    // [2]: mismatches for denormal/zero/inf/nan z; [3]: raw rcp != exact in the mid range
-    const uint32_t bits = blockIdx.x * 256u + threadIdx.x + (uint32_t)blockIdx.y * 0x01000000u * 1u;
-    (void)bits;
-}
-
 __global__ __launch_bounds__(256) void recip_check2(uint32_t base, unsigned long long *counts, uint32_t *examples)
 {
     const uint32_t bits = base + blockIdx.x * 256u + threadIdx.x;
@@ -140,6 +133,62 @@ __global__ __launch_bounds__(256) void fract_check(uint32_t base, unsigned long 
     }
 }
 
+
+// ---- issue rate of one wave vs occupancy and ILP, and the shader clock ------------------------------
+template <int ILP>
+__global__ __launch_bounds__(256) void ilp_kernel(float *out, float seed, long long *clocks)
+{
+    float a[ILP];
+    for (int i = 0; i < ILP; ++i) {
+        a[i] = seed + (float)(threadIdx.x + i) * 1e-3f;
+    }
+    const float m = 0.999f + seed * 1e-6f, c = 1e-3f;
+    const long long t0 = clock64(), w0 = wall_clock64();
+#pragma unroll 1
+    for (int it = 0; it < kIters * 8 / ILP; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+#pragma unroll
+            for (int i = 0; i < ILP; ++i) {
+                a[i] = fmaf(a[i], m, c);
+            }
+        }
+    }
+    const long long t1 = clock64(), w1 = wall_clock64();
+    float s = 0.0f;
+    for (int i = 0; i < ILP; ++i) {
+        s += a[i];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clocks[0] = t1 - t0;
+        clocks[1] = w1 - w0;
+    }
+}
+
+template <int ILP>
+static int run_ilp(int waves_per_simd, float *dout, long long *dclk)
+{
+    const int blocks = 256 * waves_per_simd, threads = 256;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(ilp_kernel<ILP>, dim3(blocks), dim3(threads), 0, 0, dout, 1.5f, dclk);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(ilp_kernel<ILP>, dim3(blocks), dim3(threads), 0, 0, dout, 1.5f, dclk);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    long long hclk[2];
+    CHECK(hipMemcpy(hclk, dclk, sizeof(hclk), hipMemcpyDeviceToHost));
+    const double ops_per_wave = (double)(kIters * 8 / ILP) * 4 * ILP;
+    printf("fma ILP=%d waves/SIMD=%d: %7.3f ms  clock64 ticks/op/wave %.2f  wall_clock64 ticks %lld vs clock64 %lld  -> ns per op per SIMD %.3f\n", ILP,
+           waves_per_simd, ms, (double)hclk[0] / ops_per_wave, hclk[1], hclk[0], ms * 1e6 / (ops_per_wave * waves_per_simd));
+    return 0;
+}
+
 template <int MODE>
 static int run_rate(const char *name, int ops_per_iter_per_chain, float *dout)
 {
@@ -179,6 +228,20 @@ int main()
     run_rate<9>("cvt_f32_ubyte1 + add (2-3 ops)", 2, dout);
     run_rate<11>("mul + v_fract_f32 (2 ops)", 2, dout);
 
+    long long *dclk;
+    CHECK(hipMalloc(&dclk, 2 * sizeof(long long)));
+    for (int w = 1; w <= 8; w = (w < 4) ? w + 1 : w * 2) {
+        run_ilp<1>(w, dout, dclk);
+    }
+    for (int w = 1; w <= 8; w = (w < 4) ? w + 1 : w * 2) {
+        run_ilp<2>(w, dout, dclk);
+    }
+    for (int w = 1; w <= 8; w = (w < 4) ? w + 1 : w * 2) {
+        run_ilp<8>(w, dout, dclk);
+    }
+    if (getenv("VALU_RATES_SKIP_EXHAUSTIVE")) {
+        return 0;
+    }
     unsigned long long *dcounts, hcounts[4];
     uint32_t *dex, hex[32];
     CHECK(hipMalloc(&dcounts, 4 * sizeof(unsigned long long)));
