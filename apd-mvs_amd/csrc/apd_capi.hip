@@ -68,6 +68,8 @@ struct apd_context {
     uint8_t *view_weight = nullptr, *weak_info = nullptr, *weak_reliable = nullptr;
     short2 *nearest_strong = nullptr, *neighbours = nullptr;
     int8_t *column_nearest = nullptr;
+    int *weak_list = nullptr;
+    size_t weak_list_cap = 0;
     int *neighbours_map = nullptr;
     size_t neighbours_cap = 0;
     FrameArgs fa{};
@@ -151,6 +153,8 @@ static void refresh_frame_args(apd_context *c)
     fa.weak_reliable = c->weak_reliable;
     fa.nearest_strong = c->nearest_strong;
     fa.column_nearest = c->column_nearest;
+    fa.weak_list = c->weak_list;
+    fa.weak_list_cap = (int)c->weak_list_cap;
     fa.neighbours_map = c->neighbours_map;
     fa.neighbours = c->neighbours;
 }
@@ -279,6 +283,7 @@ int apd_destroy(apd_handle c)
     hipFree(c->weak_reliable);
     hipFree(c->nearest_strong);
     hipFree(c->column_nearest);
+    hipFree(c->weak_list);
     hipFree(c->neighbours_map);
     hipFree(c->neighbours);
     for (auto &pe : c->pending) {
@@ -352,7 +357,7 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     }
     const int one = 1;
     HIP_TRY(hipMemcpyAsync(c->flag_dev, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    for (int i = 1; i < num_images; ++i) {
+    for (int i = 0; i < num_images; ++i) {  // the reference view too: K9/K10 keep its sub-patch texels as bytes
         hipError_t e = apd::launch_check_u8(c->images[i], (int)n, c->flag_dev, c->stream);
         if (e != hipSuccess) {
             return fail(APD_ERR_HIP, "k_check_u8 failed: %s", hipGetErrorString(e));
@@ -454,6 +459,12 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
         c->neighbours_cap = need;
     }
     HIP_TRY(hipMemsetAsync(c->neighbours, 0, c->neighbours_cap * APD_NEIGHBOUR_NUM * sizeof(short2), c->stream));
+    if (need > c->weak_list_cap) {  // one colour holds at most every WEAK pixel; +1 int for the list length
+        hipFree(c->weak_list);
+        c->weak_list = nullptr;
+        HIP_TRY(hipMalloc(&c->weak_list, (need + 1) * sizeof(int)));
+        c->weak_list_cap = need;
+    }
     HIP_TRY(hipMemsetAsync(c->fit_planes, 0, n * sizeof(float4), c->stream));
     HIP_TRY(hipMemsetAsync(c->view_weight, 0, n * APD_MAX_IMAGES, c->stream));
     HIP_TRY(hipMemsetAsync(c->weak_reliable, 0, n, c->stream));

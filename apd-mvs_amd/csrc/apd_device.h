@@ -73,6 +73,8 @@ struct FrameArgs {
     int8_t *column_nearest;  // K2 scratch: dy of the nearest STRONG pixel in the same column, 127 = none within 100
     const int *neighbours_map;
     short2 *neighbours;      // 9 per weak pixel
+    int *weak_list;          // K9/K10 scratch: compacted WEAK pixels of one colour, then one int: the count
+    int weak_list_cap;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -694,31 +696,30 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     }
 }
 
-// ComputeBilateralNCCOld for plane q = n/d against source view vc.  kQuad selects the texel-quad image.
-template <bool kQuad>
-__device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, int px, int py,
-                                           float qx, float qy, float qz)
+// True when h6*x + h7*y + h8 is, for every (x, y) of the grid [x0, x1] x [y0, y1], in the range where
+// recip_fast is the correctly rounded reciprocal.  The denominator is evaluated with monotone (rounded)
+// fma, so over the grid it stays between its values at the four corners: if those share a sign and lie
+// in the fast range, every sample does.
+__device__ __forceinline__ bool denominators_fast(const Homography &H, float x0, float x1, float y0, float y1)
 {
-    const Homography H = make_homography(fa, vc, qx, qy, qz);
-    float cx, cy;
-    correspond(H, (float)px, (float)py, cx, cy);
-    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
-        return 2.0f;
-    }
-    const float kMinVar = 1e-5f;
-    if (rp.var < kMinVar) {
-        return 2.0f;  // the reference tests this after sampling; the result is the same
-    }
-    // The denominator h6*x + h7*y + h8 is evaluated with monotone (rounded) fma, so over the 6x6 grid it
-    // stays between its values at the four corner samples: if those share a sign and lie in the
-    // fast-reciprocal range, every sample does.
-    const float x0 = (float)(px - kPatchRadius), x1 = (float)(px + kPatchRadius);
-    const float y0 = (float)(py - kPatchRadius), y1 = (float)(py + kPatchRadius);
     const float b0 = fmaf(H.h[6], x0, H.h[8]), b1 = fmaf(H.h[6], x1, H.h[8]);
     const float z00 = fmaf(H.h[7], y0, b0), z01 = fmaf(H.h[7], y1, b0);
     const float z10 = fmaf(H.h[7], y0, b1), z11 = fmaf(H.h[7], y1, b1);
     const float lo = fminf(fminf(z00, z01), fminf(z10, z11)), hi = fmaxf(fmaxf(z00, z01), fmaxf(z10, z11));
-    const bool fast_recip = (lo >= 0x1p-100f && hi <= 0x1p100f) || (hi <= -0x1p-100f && lo >= -0x1p100f);
+    return (lo >= 0x1p-100f && hi <= 0x1p100f) || (hi <= -0x1p-100f && lo >= -0x1p100f);
+}
+
+// The fixed-patch cost for an already projected centre (the caller has done the bounds test of APD.cu:546).
+template <bool kQuad>
+__device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, const Homography &H,
+                                                  int px, int py)
+{
+    const float kMinVar = 1e-5f;
+    if (rp.var < kMinVar) {
+        return 2.0f;  // the reference tests this after sampling; the result is the same
+    }
+    const bool fast_recip = denominators_fast(H, (float)(px - kPatchRadius), (float)(px + kPatchRadius), (float)(py - kPatchRadius),
+                                              (float)(py + kPatchRadius));
     float sum_s, sum_ss, sum_rs;
     if (__builtin_expect(fast_recip, 1)) {
         ncc_fixed_moments<kQuad, true>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
@@ -735,6 +736,145 @@ __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst 
     }
     const float covar = fmaf(-rp.mean, sum_s, sum_rs);
     const float denom = sqrtf(rp.var * var_s);
+    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+}
+
+// ComputeBilateralNCCOld for plane q = n/d against source view vc.  kQuad selects the texel-quad image.
+template <bool kQuad>
+__device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, int px, int py,
+                                           float qx, float qy, float qz)
+{
+    const Homography H = make_homography(fa, vc, qx, qy, qz);
+    float cx, cy;
+    correspond(H, (float)px, (float)py, cx, cy);
+    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
+        return 2.0f;
+    }
+    return ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 sub-patch (weak_radius 5, weak_increment 5) around a reliable neighbour: the k >= 1 terms of
+// ComputeBilateralNCCNew (APD.cu:461-505) on texel-quad images.  The reference side (nine texels and
+// their moments) depends on the neighbour only and is prepared once per pixel by the caller.
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kSubN = 3;       // offsets -5, 0, 5
+constexpr int kSubStep = 5;
+
+// Nine warped samples in lock step (same stages as quad_row_issue), reduced in the reference's order.
+// ref_rows[i] packs the three reference texels of x offset i (y offset j in byte j).
+__device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_u32_ptr srcq, unsigned pitch4, float wm1f, float hm1f,
+                                                    int cx, int cy, const uint32_t (&ref_rows)[kSubN], float mean_r, float var_r)
+{
+    constexpr int N = kSubN * kSubN;
+    float z[N], X[N], Y[N], r[N];
+#pragma unroll
+    for (int i = 0; i < kSubN; ++i) {
+        const float xf = (float)(cx + kSubStep * (i - 1));
+        const float bx = fmaf(H.h[0], xf, H.h[2]);
+        const float by = fmaf(H.h[3], xf, H.h[5]);
+        const float bz = fmaf(H.h[6], xf, H.h[8]);
+#pragma unroll
+        for (int j = 0; j < kSubN; ++j) {
+            const float yf = (float)(cy + kSubStep * (j - 1));
+            z[i * kSubN + j] = fmaf(H.h[7], yf, bz);
+            X[i * kSubN + j] = fmaf(H.h[1], yf, bx);
+            Y[i * kSubN + j] = fmaf(H.h[4], yf, by);
+        }
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        r[k] = __builtin_amdgcn_rcpf(z[k]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        z[k] = fmaf(-z[k], r[k], 1.0f);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        r[k] = fmaf(z[k], r[k], r[k]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        X[k] *= r[k];
+        Y[k] *= r[k];
+    }
+    APD_STAGE();
+    float a[N], b[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        z[k] = floorf(X[k]);
+        r[k] = floorf(Y[k]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        a[k] = X[k] - z[k];
+        b[k] = Y[k] - r[k];
+        z[k] = __builtin_amdgcn_fmed3f(z[k], -1.0f, wm1f);
+        r[k] = __builtin_amdgcn_fmed3f(r[k], -1.0f, hm1f);
+    }
+    APD_STAGE();
+    int qx[N], qy[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        qx[k] = (int)z[k];
+        qy[k] = (int)r[k];
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        qy[k] = __mul24(qy[k], (int)pitch4) + (int)(pitch4 + 4u);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        qx[k] = (qx[k] << 2) + qy[k];
+    }
+    APD_STAGE();
+    uint32_t t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        t[k] = quad_fetch(srcq, (unsigned)qx[k]);
+    }
+    APD_STAGE();
+    float v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        v[k] = quad_lerp(t[k], a[k], b[k]);
+    }
+    float sum_s = 0.0f, sum_ss = 0.0f, sum_rs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kSubN; ++i) {
+        float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kSubN; ++j) {
+            const float val = v[i * kSubN + j];
+            const float ref = (float)((ref_rows[i] >> (8 * j)) & 0xFFu);
+            row_s += val;
+            row_ss = fmaf(val, val, row_ss);
+            row_rs = fmaf(ref, val, row_rs);
+        }
+        sum_s += row_s;
+        sum_ss += row_ss;
+        sum_rs += row_rs;
+    }
+    const float inv_w = 1.0f / 9.0f;
+    sum_s *= inv_w;
+    sum_ss *= inv_w;
+    sum_rs *= inv_w;
+    const float var_s = fmaf(-sum_s, sum_s, sum_ss);
+    const float kMinVar = 1e-5f;
+    if (var_r < kMinVar || var_s < kMinVar) {
+        return 2.0f;
+    }
+    const float covar = fmaf(-mean_r, sum_s, sum_rs);
+    const float denom = sqrtf(var_r * var_s);
     return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
 }
 

@@ -433,9 +433,56 @@ __global__ __launch_bounds__(256) void k8_ransac_fit_plane(FrameArgs fa)
 
 // ComputeBilateralNCCNew (APD.cu:400-528): centre 6x6 patch + up to eight 3x3 sub-patches around the
 // reliable neighbours, all warped by the same homography.
+//
+// Per-pixel, hypothesis-independent data of the eight neighbours lives in LDS ([slot][lane], so a wave
+// reads consecutive banks): position, the nine reference texels of the 3x3 sub-patch (texel-quad mode:
+// bytes, three per dword) and their mean / variance in the reference's summation order.
+struct WeakLds {
+    int nb[8][64];            // x | y << 16, -1 = empty slot
+    uint32_t ref[8][kSubN][64];
+    float mean[8][64];
+    float var[8][64];
+};
+
 template <bool kQuad>
-__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const RefPatch &rp, const short2 *nb,
-                                              int px, int py, const float4 pl)
+__device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, const short2 *nb, WeakLds &lds, int lane)
+{
+    const int W = fa.W, H = fa.H;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const short2 q = nb[k + 1];
+        const bool valid = !(q.x == -1 || q.y == -1);
+        lds.nb[k][lane] = valid ? ((int)(unsigned short)q.x | ((int)q.y << 16)) : -1;
+        if (!valid || !kQuad) {
+            continue;
+        }
+        float sum_r = 0.0f, sum_rr = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kSubN; ++i) {
+            float row_r = 0.0f, row_rr = 0.0f;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < kSubN; ++j) {
+                const float r = fetch_texel(fa.ref_img, W, H, q.x + kSubStep * (i - 1), q.y + kSubStep * (j - 1));
+                row_r += r;
+                row_rr = fmaf(r, r, row_rr);
+                packed |= (uint32_t)r << (8 * j);
+            }
+            sum_r += row_r;
+            sum_rr += row_rr;
+            lds.ref[k][i][lane] = packed;
+        }
+        const float inv_w = 1.0f / 9.0f;
+        sum_r *= inv_w;
+        sum_rr *= inv_w;
+        lds.mean[k][lane] = sum_r;
+        lds.var[k][lane] = fmaf(-sum_r, sum_r, sum_rr);
+    }
+}
+
+template <bool kQuad>
+__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const RefPatch &rp, const WeakLds &lds,
+                                              int lane, int px, int py, const float4 pl)
 {
     float qx, qy, qz;
     plane_q(pl, qx, qy, qz);
@@ -446,25 +493,37 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
         return 2.0f;
     }
     // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above)
-    const float center_cost = ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
+    const float center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+    const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
+    const unsigned pitch4 = 4u * (unsigned)(fa.W + 1);
+    const float wm1f = (float)(fa.W - 1), hm1f = (float)(fa.H - 1);
     float strong_cost = 0.0f;
     int strong_count = 0;
-    for (int k = 1; k < APD_NEIGHBOUR_NUM; ++k) {
-        const short2 q = nb[k];
-        if (q.x == -1 || q.y == -1) {
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const int packed = lds.nb[k][lane];
+        if (packed == -1) {
             continue;
         }
+        const int nbx = (int)(short)(packed & 0xFFFF), nby = packed >> 16;
         float nx, ny;
-        correspond(H, (float)q.x, (float)q.y, nx, ny);
+        correspond(H, (float)nbx, (float)nby, nx, ny);
         if (nx < 0 || ny < 0 || nx >= (float)fa.W || ny >= (float)fa.H) {
-            const uint32_t vi = fa.selected_views[q.x + q.y * fa.W];
+            const uint32_t vi = fa.selected_views[nbx + nby * fa.W];
             if (bit_test(vi, (unsigned)v)) {
                 strong_cost += 2.0f;
                 strong_count++;
             }
             continue;
         }
-        strong_cost += patch_cost_generic(fa, vc, H, q.x, q.y, 5, 5);
+        float c;
+        if (kQuad && denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep))) {
+            const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
+            c = subpatch_cost_quad(H, srcq, pitch4, wm1f, hm1f, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+        } else {
+            c = patch_cost_generic(fa, vc, H, nbx, nby, 5, 5);
+        }
+        strong_cost += c;
         strong_count++;
     }
     if (strong_count == 0) {
@@ -475,29 +534,49 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
     return (float)(0.25 * (double)center_cost + 0.75 * (double)strong_cost);
 }
 
-// Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
-// plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
-template <int NMAX, bool kQuad>
-__global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour, int iter)
+// WEAK pixels are sparse and clustered: compact the ones of this colour into a list (tile by tile, so
+// list neighbours are image neighbours) and let the update kernel run on full waves.
+__global__ __launch_bounds__(64) void k_compact_weak(FrameArgs fa, int colour, int *__restrict__ list, int *__restrict__ count)
 {
-    // one wave per 16x8 footprint; WEAK pixels are sparse, keep workgroups small
     const int tiles_x = (fa.W + 15) / 16;
     const int tile = blockIdx.x;
     const int ty0 = (tile / tiles_x) * 8, tx0 = (tile - (tile / tiles_x) * tiles_x) * 16;
     const int lane = threadIdx.x;
-    const int ly = lane >> 3;
-    const int py = ty0 + ly;
+    const int py = ty0 + (lane >> 3);
     const int px = tx0 + 2 * (lane & 7) + ((py + colour) & 1);
-    if (px >= fa.W || py >= fa.H || py >= fa.half_rows) {
+    // rows beyond half_rows are never visited by the reference's HALF launch (APD.cu:2402)
+    const bool weak = px < fa.W && py < fa.H && py < fa.half_rows && fa.weak_info[py * fa.W + px] == APD_WEAK;
+    const unsigned long long mask = __ballot(weak);
+    if (mask == 0) {
+        return;
+    }
+    int base = 0;
+    if (lane == 0) {
+        base = atomicAdd(count, __popcll(mask));
+    }
+    base = __shfl(base, 0);
+    if (weak) {
+        list[base + __popcll(mask & ((1ull << lane) - 1ull))] = py * fa.W + px;
+    }
+}
+
+// Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
+// plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
+template <int NMAX, bool kQuad>
+__global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, const int *__restrict__ count)
+{
+    __shared__ WeakLds lds;
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * 64 + lane;
+    if (gid >= *count) {
         return;
     }
     const int W = fa.W;
-    const int center = py * W + px;
-    if (fa.weak_info[center] != APD_WEAK) {
-        return;
-    }
+    const int center = list[gid];
+    const int py = center / W, px = center - py * W;
     const int nsrc = fa.num_src;
     const short2 *nb = &fa.neighbours[(size_t)fa.neighbours_map[center] * APD_NEIGHBOUR_NUM];
+    weak_prepare_neighbours<kQuad>(fa, nb, lds, lane);
     RefPatch rp;
     ref_patch_from_global(rp, fa.ref_img, W, fa.H, px, py);
     Rng rng = rng_load(fa.rng, center);
@@ -629,13 +708,13 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int colour,
         for (int v = 0; v < nsrc; ++v) {
             const ViewConst &vc = fa.views[v];
             if (h < 9) {
-                cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, nb, px, py, pl);
+                cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
             } else if (h == 15) {
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
                 tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
             } else {
-                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, nb, px, py, pl);
+                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
                 if (vw.get(v) > 0) {
                     if (fa.geom_consistency) {
                         tc += (float)vw.get(v) * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
@@ -693,11 +772,19 @@ hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *
 template <int NMAX>
 static void launch_k910(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
+    // The list length is only known on the device: launch one wave per 16x8 tile (an upper bound of
+    // ceil(count / 64)); surplus waves retire on their first instruction.
     const int tiles = ((fa.W + 15) / 16) * ((fa.H + 7) / 8);
+    if (!fa.weak_list) {
+        return;  // no prior state was uploaded: every pixel is STRONG (APD.cpp:541-547)
+    }
+    int *count = fa.weak_list + fa.weak_list_cap;
+    (void)hipMemsetAsync(count, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_compact_weak, dim3(tiles), dim3(64), 0, s, fa, colour, fa.weak_list, count);
     if (fa.use_quads) {
-        hipLaunchKernelGGL((k910_update_weak<NMAX, true>), dim3(tiles), dim3(64), 0, s, fa, colour, iter);
+        hipLaunchKernelGGL((k910_update_weak<NMAX, true>), dim3(tiles), dim3(64), 0, s, fa, iter, fa.weak_list, count);
     } else {
-        hipLaunchKernelGGL((k910_update_weak<NMAX, false>), dim3(tiles), dim3(64), 0, s, fa, colour, iter);
+        hipLaunchKernelGGL((k910_update_weak<NMAX, false>), dim3(tiles), dim3(64), 0, s, fa, iter, fa.weak_list, count);
     }
 }
 
