@@ -443,6 +443,36 @@ __device__ __forceinline__ float quad_lerp(uint32_t t, float a, float b)
     return fmaf(b, bot - top, top);
 }
 
+// Bilinear tap position for the texel-quad image, three VALU instructions per axis:
+//   weight  = v_fract_f32(s)        == s - floor(s) for every s >= 0; for s < 0 it can differ in the last bit
+//                                      (clamped below 1), but there both taps are the same clamped edge texel,
+//                                      so the sample is bit-identical; Inf/NaN give NaN like the subtraction
+//   index   = v_cvt_flr_i32_f32(s)  == saturating (int)floor(s) (NaN -> INT_MAX; the sample is NaN anyway)
+//   clamped = v_med3_i32(index, -1, size - 1)
+// (all three checked over all 2^32 inputs by tools/valu_rates.hip)
+__device__ __forceinline__ int cvt_floor_i32(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+__device__ __forceinline__ int med3_i32(int x, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+}
+
+// byte offset of quad entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1]: qy*pitch4 + (pitch4 + 4) + 4*qx, two instructions
+__device__ __forceinline__ unsigned quad_byte_offset(int qx, int qy, int pitch4, int origin)
+{
+    int row, off;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(pitch4), "v"(origin));
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(qx), "v"(row));
+    return (unsigned)off;
+}
+
 __device__ __forceinline__ float sample_quad(global_u32_ptr quad, unsigned pitch, float wm1f, float hm1f, float sx, float sy)
 {
     float a, b;
@@ -508,7 +538,7 @@ __device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float 
 // Sample positions of one patch row (fixed x, six y) -> bilinear weights + texel-quad gathers in flight.
 template <bool kFastRecip>
 __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN],
-                                               global_u32_ptr srcq, unsigned pitch4, float wm1f, float hm1f,
+                                               global_u32_ptr srcq, unsigned pitch4, int wm1, int hm1,
                                                float (&a)[kPatchN], float (&b)[kPatchN], uint32_t (&t)[kPatchN])
 {
     float z[kPatchN], X[kPatchN], Y[kPatchN], r[kPatchN];
@@ -547,37 +577,24 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
         Y[j] *= r[j];
     }
     APD_STAGE();
-    float fx[kPatchN], fy[kPatchN];
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        fx[j] = floorf(X[j]);
-        fy[j] = floorf(Y[j]);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        a[j] = X[j] - fx[j];
-        b[j] = Y[j] - fy[j];
-        fx[j] = __builtin_amdgcn_fmed3f(fx[j], -1.0f, wm1f);
-        fy[j] = __builtin_amdgcn_fmed3f(fy[j], -1.0f, hm1f);
-    }
-    APD_STAGE();
     int qx[kPatchN], qy[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = (int)fx[j];
-        qy[j] = (int)fy[j];
-    }
-    APD_STAGE();
-    // entry (qx, qy) lives at (qy + 1) * pitch + (qx + 1): byte offset = qy*4*pitch + 4*(pitch+1) + 4*qx >= 0
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        qy[j] = __mul24(qy[j], (int)pitch4) + (int)(pitch4 + 4u);
+        a[j] = __builtin_amdgcn_fractf(X[j]);
+        b[j] = __builtin_amdgcn_fractf(Y[j]);
+        qx[j] = cvt_floor_i32(X[j]);
+        qy[j] = cvt_floor_i32(Y[j]);
     }
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = (qx[j] << 2) + qy[j];
+        qx[j] = med3_i32(qx[j], -1, wm1);
+        qy[j] = med3_i32(qy[j], -1, hm1);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        qx[j] = (int)quad_byte_offset(qx[j], qy[j], (int)pitch4, (int)(pitch4 + 4u));
     }
     APD_STAGE();
 #ifdef APD_EXPERIMENT_QUAD_SAME_ADDR  // timing experiment only (wrong results): the 4 lanes of a quad gather one address
@@ -641,7 +658,7 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
     const int W = fa.W, Hh = fa.H;
     const unsigned pitch4 = 4u * (unsigned)(W + 1);
-    const float wm1f = (float)(W - 1), hm1f = (float)(Hh - 1);
+    const int wm1 = W - 1, hm1 = Hh - 1;
     float yf[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
@@ -656,7 +673,7 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     if (kQuad) {
         const float xf = (float)(px - kPatchRadius);
         quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq, pitch4,
-                                   wm1f, hm1f, a[0], b[0], t[0]);
+                                   wm1, hm1, a[0], b[0], t[0]);
     }
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
@@ -665,7 +682,7 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
             if (i + 1 < kPatchN) {
                 const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
                 quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq,
-                                           pitch4, wm1f, hm1f, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
+                                           pitch4, wm1, hm1, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
             }
             APD_STAGE();
             quad_row_lerp(t[i & 1], a[i & 1], b[i & 1], v);
@@ -764,7 +781,7 @@ constexpr int kSubStep = 5;
 
 // Nine warped samples in lock step (same stages as quad_row_issue), reduced in the reference's order.
 // ref_rows[i] packs the three reference texels of x offset i (y offset j in byte j).
-__device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_u32_ptr srcq, unsigned pitch4, float wm1f, float hm1f,
+__device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_u32_ptr srcq, unsigned pitch4, int wm1, int hm1,
                                                     int cx, int cy, const uint32_t (&ref_rows)[kSubN], float mean_r, float var_r)
 {
     constexpr int N = kSubN * kSubN;
@@ -806,35 +823,24 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
     }
     APD_STAGE();
     float a[N], b[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        z[k] = floorf(X[k]);
-        r[k] = floorf(Y[k]);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        a[k] = X[k] - z[k];
-        b[k] = Y[k] - r[k];
-        z[k] = __builtin_amdgcn_fmed3f(z[k], -1.0f, wm1f);
-        r[k] = __builtin_amdgcn_fmed3f(r[k], -1.0f, hm1f);
-    }
-    APD_STAGE();
     int qx[N], qy[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        qx[k] = (int)z[k];
-        qy[k] = (int)r[k];
+        a[k] = __builtin_amdgcn_fractf(X[k]);
+        b[k] = __builtin_amdgcn_fractf(Y[k]);
+        qx[k] = cvt_floor_i32(X[k]);
+        qy[k] = cvt_floor_i32(Y[k]);
     }
     APD_STAGE();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        qy[k] = __mul24(qy[k], (int)pitch4) + (int)(pitch4 + 4u);
+        qx[k] = med3_i32(qx[k], -1, wm1);
+        qy[k] = med3_i32(qy[k], -1, hm1);
     }
     APD_STAGE();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        qx[k] = (qx[k] << 2) + qy[k];
+        qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)pitch4, (int)(pitch4 + 4u));
     }
     APD_STAGE();
     uint32_t t[N];

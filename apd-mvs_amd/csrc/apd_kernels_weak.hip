@@ -496,7 +496,7 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
     const float center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
     const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
     const unsigned pitch4 = 4u * (unsigned)(fa.W + 1);
-    const float wm1f = (float)(fa.W - 1), hm1f = (float)(fa.H - 1);
+    const int wm1 = fa.W - 1, hm1 = fa.H - 1;
     float strong_cost = 0.0f;
     int strong_count = 0;
 #pragma unroll 1
@@ -519,7 +519,7 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
         float c;
         if (kQuad && denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep))) {
             const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-            c = subpatch_cost_quad(H, srcq, pitch4, wm1f, hm1f, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+            c = subpatch_cost_quad(H, srcq, pitch4, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
         } else {
             c = patch_cost_generic(fa, vc, H, nbx, nby, 5, 5);
         }

@@ -189,6 +189,71 @@ static int run_ilp(int waves_per_simd, float *dout, long long *dclk)
     return 0;
 }
 
+// ---- v_cvt_flr_i32_f32 / v_fract_f32 special values, v_fma_mix_f32 rate ---------------------------------
+__device__ __forceinline__ int cvt_flr(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void cvt_flr_check(uint32_t base, unsigned long long *counts, uint32_t *examples)
+{
+    const uint32_t bits = base + blockIdx.x * 256u + threadIdx.x;
+    const float x = __uint_as_float(bits);
+    const int hw = cvt_flr(x);
+    int emu;
+    if (x != x) {
+        emu = 0;
+    } else if (x >= 2147483648.0f) {
+        emu = 0x7fffffff;
+    } else if (x < -2147483648.0f) {
+        emu = (int)0x80000000;
+    } else {
+        emu = (int)floorf(x);
+    }
+    if (hw != emu) {
+        const unsigned long long k = atomicAdd(&counts[0], 1ull);
+        if (k < 16) {
+            examples[2 * k] = bits;
+            examples[2 * k + 1] = (uint32_t)hw;
+        }
+    }
+}
+
+__global__ void special_values(float *out)
+{
+    const float inf = __builtin_inff();
+    out[0] = __builtin_amdgcn_fractf(inf);
+    out[1] = __builtin_amdgcn_fractf(-inf);
+    out[2] = __builtin_amdgcn_fractf(__builtin_nanf(""));
+    out[3] = __builtin_amdgcn_fractf(-1e-10f);
+    out[4] = __builtin_amdgcn_fractf(-0.0f);
+    out[5] = __builtin_amdgcn_fractf(3.0e38f);
+}
+
+__global__ __launch_bounds__(256) void mix_kernel(float *out, float seed, const uint32_t *h)
+{
+    float a[kChains];
+    for (int i = 0; i < kChains; ++i) {
+        a[i] = seed + (float)(threadIdx.x + i) * 1e-3f;
+    }
+    const uint32_t packed = h[threadIdx.x & 63];  // two halfs
+#pragma unroll 1
+    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < kChains; ++i) {
+            // a = a * half_hi + half_lo
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(a[i]) : "v"(a[i]), "v"(packed));
+        }
+    }
+    float s = 0.0f;
+    for (int i = 0; i < kChains; ++i) {
+        s += a[i];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int MODE>
 static int run_rate(const char *name, int ops_per_iter_per_chain, float *dout)
 {
@@ -228,6 +293,50 @@ int main()
     run_rate<9>("cvt_f32_ubyte1 + add (2-3 ops)", 2, dout);
     run_rate<11>("mul + v_fract_f32 (2 ops)", 2, dout);
 
+    {
+        uint32_t *dh, hh[64];
+        for (int i = 0; i < 64; ++i) {
+            hh[i] = 0x3c003800u;  // hi = 1.0h, lo = 0.5h
+        }
+        CHECK(hipMalloc(&dh, sizeof(hh)));
+        CHECK(hipMemcpy(dh, hh, sizeof(hh), hipMemcpyHostToDevice));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(mix_kernel, dim3(2048), dim3(256), 0, 0, dout, 1.5f, dh);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(mix_kernel, dim3(2048), dim3(256), 0, 0, dout, 1.5f, dh);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-34s %8.3f ms  %6.2f SIMD-cycles per wave-op (at 2.4 GHz)\n", "v_fma_mix_f32 (f32*f16+f16)", ms,
+               ms * 1e-3 * 2.4e9 * 1024 / (2048.0 * 4 * kIters * kChains));
+        float *dsv, hsv[6];
+        CHECK(hipMalloc(&dsv, sizeof(hsv)));
+        hipLaunchKernelGGL(special_values, dim3(1), dim3(1), 0, 0, dsv);
+        CHECK(hipMemcpy(hsv, dsv, sizeof(hsv), hipMemcpyDeviceToHost));
+        uint32_t u[6];
+        memcpy(u, hsv, sizeof(u));
+        printf("v_fract_f32: +inf -> %08x, -inf -> %08x, nan -> %08x, -1e-10 -> %08x, -0 -> %08x, 3e38 -> %08x\n", u[0], u[1], u[2], u[3], u[4], u[5]);
+        unsigned long long *dc, hc[4];
+        uint32_t *dex, hex[32];
+        CHECK(hipMalloc(&dc, sizeof(hc)));
+        CHECK(hipMalloc(&dex, sizeof(hex)));
+        CHECK(hipMemset(dc, 0, sizeof(hc)));
+        CHECK(hipMemset(dex, 0, sizeof(hex)));
+        for (uint32_t hi = 0; hi < 256; ++hi) {
+            hipLaunchKernelGGL(cvt_flr_check, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dc, dex);
+        }
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
+        printf("v_cvt_flr_i32_f32 vs saturating (int)floor(x), NaN -> 0, over all 2^32 inputs: mismatches=%llu\n", hc[0]);
+        for (int i = 0; i < 8 && (unsigned long long)i < hc[0]; ++i) {
+            printf("   x=%08x hw=%08x\n", hex[2 * i], hex[2 * i + 1]);
+        }
+    }
     long long *dclk;
     CHECK(hipMalloc(&dclk, 2 * sizeof(long long)));
     for (int w = 1; w <= 8; w = (w < 4) ? w + 1 : w * 2) {
