@@ -611,6 +611,13 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
     }
     APD_STAGE();
 #endif
+#ifdef APD_EXPERIMENT_NO_LOADS  // timing experiment only: no gathers at all
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        t[j] = (uint32_t)qx[j] * 2654435761u;
+    }
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
         t[j] = quad_fetch(srcq, (unsigned)qx[j]);

@@ -30,6 +30,16 @@ WORKLOADS = {
     "synthetic_4096x3072_8src": (4096, 3072, 8),     # tuning workload
     "small": (640, 480, 8),
 }
+# BASELINE.json configs[2] ("adaptive-patch on"): the timed sweep is the REFINE_INIT pass with use_APD, whose WEAK map
+# comes from a complete FIRST_INIT pass (K1..K15) run before the timed region; 20 % of the scene is textureless.
+APD_WORKLOADS = {"eth3d_pipes_fullres_10src_apd": "eth3d_pipes_fullres_10src", "synthetic_4096x3072_8src_apd": "synthetic_4096x3072_8src",
+                 "small_apd": "small"}
+WORKLOADS.update({k: WORKLOADS[v] for k, v in APD_WORKLOADS.items()})
+
+
+def algorithmic_bytes_per_weak_pixel(num_src):
+    """SURVEY.md 8(d), nominal: 15*N NCCNew of 108 samples + N NCCOld of 36 samples, 20 B per sample, + 176 B of state."""
+    return 33120 * num_src + 176
 
 
 def algorithmic_bytes_per_strong_pixel(num_src):
@@ -69,19 +79,47 @@ def main():
     dev = torch.device("cuda", local_rank if distributed else 0)
 
     W, H, N = WORKLOADS[args.workload]
+    apd_mode = args.workload in APD_WORKLOADS
     # every rank owns a different reference view of the same camera ring
-    sc = synth.make_scene(W, H, N, seed=0, ref_view=rank, device=dev)
+    sc = synth.make_scene(W, H, N, seed=0, ref_view=rank, device=dev, textureless=0.2 if apd_mode else 0.0)
     cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
     total_iters = args.warmup + args.steps
-    params = pkg.default_params(num_images=N + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0,
-                                state=pkg.FIRST_INIT, max_iterations=total_iters, seed=args.seed)
-    h = pkg.Handle(W, H, params, device=dev.index)
-    h.upload_views(cams, sc.images)  # device->device copies: inputs are resident in HBM before timing
+    dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
+    weak_fraction = 0.0
+    if not apd_mode:
+        params = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0,
+                                    state=pkg.FIRST_INIT, max_iterations=total_iters, seed=args.seed)
+        h = pkg.Handle(W, H, params, device=dev.index)
+        h.upload_views(cams, sc.images)  # device->device copies: inputs are resident in HBM before timing
+    else:
+        # untimed: the photometric FIRST_INIT pass of main.cpp:169-190 (3 iterations, weak_peak_radius 6) that
+        # classifies pixels, then ProcessProblem's post-processing (main.cpp:105-115)
+        p0 = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0, state=pkg.FIRST_INIT,
+                                max_iterations=3, weak_peak_radius=6, seed=args.seed)
+        h0 = pkg.Handle(W, H, p0, device=dev.index)
+        h0.upload_views(cams, sc.images)
+        h0.run()
+        planes, weak, views = h0.download()
+        h0.close()
+        bad = (planes[..., 3] < np.float32(dmin)) | (planes[..., 3] > np.float32(dmax))
+        planes[..., 3][bad] = 0
+        weak[bad] = pkg.UNKNOWN
+        params = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=1, state=pkg.REFINE_INIT,
+                                    max_iterations=total_iters, weak_peak_radius=6, rotate_time=4,
+                                    ransac_threshold=0.01 - 0.00125 * 3, seed=args.seed + 1)
+        h = pkg.Handle(W, H, params, device=dev.index)
+        h.upload_views(cams, sc.images)
+        h.upload_prior(planes, views, weak)
+        weak_fraction = h.weak_count / float(W * H)
+        del planes, weak, views
     del sc.images[:]
     torch.cuda.empty_cache()
-    # everything before the loop of APD.cu:2443 (not timed): K1, K2, K5
+    # everything before the loop of APD.cu:2443 (not timed): K1..K5
     h.run_kernel(pkg.K1)
     h.run_kernel(pkg.K2)
+    if apd_mode and h.weak_count > 0:
+        h.run_kernel(pkg.K3)
+        h.run_kernel(pkg.K4)
     h.run_kernel(pkg.K5)
     # warmup iterations
     if args.warmup > 0:
@@ -142,7 +180,8 @@ def main():
     k7 = prof.get(pkg.K7, (0.0, 0))
     launches = k6[1] + k7[1]
     avg_ms = (k6[0] + k7[0]) / max(launches, 1)
-    bytes_per_launch = (W * H / 2.0) * algorithmic_bytes_per_strong_pixel(N)
+    # K6/K7 skip WEAK pixels; the weak fraction is the one at upload time (K4 only ever lowers it)
+    bytes_per_launch = (W * H / 2.0) * (1.0 - weak_fraction) * algorithmic_bytes_per_strong_pixel(N)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, traffic_src = load_pmc_traffic(args.workload)
     roofline = {
@@ -154,6 +193,15 @@ def main():
         "bytes_per_pixel_iter": algorithmic_bytes_per_strong_pixel(N),
     }
     kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0], 3) for k, v in sorted(prof.items())}
+    weak_path = None
+    if apd_mode:
+        k9, k10 = prof.get(pkg.K9, (0.0, 0)), prof.get(pkg.K10, (0.0, 0))
+        wl = k9[1] + k10[1]
+        wms = (k9[0] + k10[0]) / max(wl, 1)
+        wbytes = (W * H / 2.0) * weak_fraction * algorithmic_bytes_per_weak_pixel(N)
+        weak_path = {"kernel": "k910_update_weak (Black/RedPixelUpdateWeak)", "weak_fraction": round(weak_fraction, 4),
+                     "avg_launch_ms": round(wms, 3), "launches": wl, "algorithmic_bytes_per_launch_nominal_max": wbytes,
+                     "achieved_GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0}
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -173,10 +221,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "width": W, "height": H, "num_src": N, "state": "FIRST_INIT",
+            "config": {"workload": args.workload, "width": W, "height": H, "num_src": N,
+                       "state": "REFINE_INIT+APD" if apd_mode else "FIRST_INIT",
                        "views_per_gpu": 1, "parallelism": "views sharded, %d rank(s)" % world},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "weak_path": weak_path,
             "kernel_ms_timed_region": kernel_ms,
             "post_loop_ms": round(post_ms, 1),
             "allgather_ms": None if allgather_ms is None else round(allgather_ms, 3),
