@@ -493,6 +493,16 @@ struct RefPatch {
     float v[kPatchN * kPatchN];  // v[i*6+j]: x offset index i (outer loop), y offset index j
     float mean;                  // sum_ref / 36
     float var;                   // sum_ref_ref/36 - mean^2
+    __device__ __forceinline__ float at(int i, int j) const { return v[i * kPatchN + j]; }
+};
+
+// Same interface with the 36 texels left in the workgroup's LDS tile (clamp-to-edge already applied when the
+// tile was staged): frees 36 VGPRs per lane for one ds_read per sample.
+template <int kPitch>
+struct RefPatchLds {
+    const float *base;  // &tile[(ly)*kPitch + lx], i.e. the texel at offset (-radius, -radius)
+    float mean, var;
+    __device__ __forceinline__ float at(int i, int j) const { return base[(kPatchStep * j) * kPitch + kPatchStep * i]; }
 };
 
 __device__ __forceinline__ void ref_patch_finish(RefPatch &rp)
@@ -657,8 +667,8 @@ __device__ __forceinline__ void quad_row_lerp(const uint32_t (&t)[kPatchN], cons
 // The 36 warped source samples of one fixed patch and their three moments (APD.cu:561-583), summed in the
 // reference's order (row partial sums, then total).  kFastRecip: every denominator is known to be in the
 // range where recip_fast is the correctly rounded reciprocal.
-template <bool kQuad, bool kFastRecip>
-__device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, const Homography &H,
+template <bool kQuad, bool kFastRecip, typename Ref>
+__device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H,
                                                   int px, int py, float &sum_s, float &sum_ss, float &sum_rs)
 {
     const global_f32_ptr src = (global_f32_ptr)vc.img;
@@ -707,12 +717,17 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
                 v[j] = sample_bilinear(src, W, Hh, sx, sy);
             }
         }
+        float ref[kPatchN];
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            ref[j] = rp.at(i, j);
+        }
         float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
 #pragma unroll
         for (int j = 0; j < kPatchN; ++j) {
             row_s += v[j];
             row_ss = fmaf(v[j], v[j], row_ss);
-            row_rs = fmaf(rp.v[i * kPatchN + j], v[j], row_rs);
+            row_rs = fmaf(ref[j], v[j], row_rs);
         }
         sum_s += row_s;
         sum_ss += row_ss;
@@ -734,8 +749,8 @@ __device__ __forceinline__ bool denominators_fast(const Homography &H, float x0,
 }
 
 // The fixed-patch cost for an already projected centre (the caller has done the bounds test of APD.cu:546).
-template <bool kQuad>
-__device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, const Homography &H,
+template <bool kQuad, typename Ref>
+__device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H,
                                                   int px, int py)
 {
     const float kMinVar = 1e-5f;
@@ -746,9 +761,9 @@ __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const Vie
                                               (float)(py + kPatchRadius));
     float sum_s, sum_ss, sum_rs;
     if (__builtin_expect(fast_recip, 1)) {
-        ncc_fixed_moments<kQuad, true>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, true, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else {
-        ncc_fixed_moments<kQuad, false>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, false, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     }
     const float inv_w = 1.0f / 36.0f;
     sum_s *= inv_w;
@@ -764,8 +779,8 @@ __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const Vie
 }
 
 // ComputeBilateralNCCOld for plane q = n/d against source view vc.  kQuad selects the texel-quad image.
-template <bool kQuad>
-__device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst &vc, const RefPatch &rp, int px, int py,
+template <bool kQuad, typename Ref>
+__device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, int px, int py,
                                            float qx, float qy, float qz)
 {
     const Homography H = make_homography(fa, vc, qx, qy, qz);
@@ -774,7 +789,7 @@ __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst 
     if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
         return 2.0f;
     }
-    return ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+    return ncc_fixed_from_h<kQuad, Ref>(fa, vc, rp, H, px, py);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -189,7 +189,7 @@ __device__ __forceinline__ bool arm_candidate(const FrameArgs &fa, int px, int p
 // One launch = one colour.  Hypotheses 0..7 are the propagation arms, 8 the current plane,
 // 9..13 the refinement set; a single loop keeps one inlined copy of the 36-sample NCC.
 #ifndef APD_K67_WAVES
-#define APD_K67_WAVES 3  // minimum waves per SIMD the register allocator must leave room for (2: 32.0 ms, 3: 28.8 ms, 4: 38.4 ms per launch at 4096x3072 N=8)
+#define APD_K67_WAVES 4  // minimum waves per SIMD the register allocator must leave room for (ms per launch at 4096x3072 N=8 -- ref patch in registers: 2: 32.0, 3: 28.3; ref patch in LDS: 3: 28.2, 4: 27.4)
 #endif
 template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArgs fa, int colour, int iter)
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
     if (fa.weak_info[center] == APD_WEAK) {
         return;
     }
+#ifdef APD_K67_REF_IN_REGS
     RefPatch rp;
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
@@ -219,6 +220,24 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
         }
     }
     ref_patch_finish(rp);
+#else
+    // the 36 reference texels stay in the LDS tile (one ds_read per sample); only their moments live in registers
+    RefPatchLds<kLdsPitch> rp;
+    rp.base = &tile[t.ly * kLdsPitch + t.lx];
+    {
+        RefPatch tmp;
+#pragma unroll
+        for (int i = 0; i < kPatchN; ++i) {
+#pragma unroll
+            for (int j = 0; j < kPatchN; ++j) {
+                tmp.v[i * kPatchN + j] = rp.at(i, j);
+            }
+        }
+        ref_patch_finish(tmp);
+        rp.mean = tmp.mean;
+        rp.var = tmp.var;
+    }
+#endif
 
     const int nsrc = fa.num_src;
     Rng rng = rng_load(fa.rng, center);
