@@ -87,6 +87,24 @@ def build_host(force=False, verbose=False):
     return HOST_BIN, HOST_LIB
 
 
+TOOLS_DIR = os.path.join(HERE, "..", "tools")
+
+
+def build_tools(force=False):
+    """tools/_build/valu_rates: issue-rate measurements and the exhaustive ISA checks of the arithmetic contract."""
+    src = os.path.join(TOOLS_DIR, "valu_rates.hip")
+    out_dir = os.path.join(TOOLS_DIR, "_build")
+    out = os.path.join(out_dir, "valu_rates")
+    os.makedirs(out_dir, exist_ok=True)
+    if force or _newer(out, [src]):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", src, "-o", out],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on tools/valu_rates.hip:\n" + r.stdout)
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
+    print(build_tools(force="--force" in sys.argv))

@@ -204,7 +204,7 @@ def main():
                      "achieved_GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0}
 
     cpu_baseline = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
         cpu_baseline = run_cpu_baseline(args, N, np)
 
     if rank == 0:

@@ -1,8 +1,9 @@
 // valu_rates.hip -- gfx950 micro-measurements behind the sample loop of ncc_fixed:
-//   (1) issue cost of v_fma_f32 / v_pk_fma_f32 / v_rcp_f32 / IEEE division / rcp+Newton
-//   (2) exhaustive check: is rcp + one FMA Newton step the correctly rounded reciprocal?
-//   (3) exhaustive check of v_fract_f32 against min(x - floor(x), 0x1.fffffep-1f)
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/valu_rates.hip -o /tmp/valu_rates
+//   (1) issue cost of v_fma_f32 / v_pk_fma_f32 / v_fma_mix_f32 / v_rcp_f32 / IEEE division / rcp+Newton, and the
+//       issue rate of one wave against occupancy and instruction-level parallelism
+//   (2) exhaustive checks (all 2^32 inputs) of the instruction identities the bit-exact contract uses:
+//       rcp + one FMA Newton step == RN(1/z); v_fract_f32; v_cvt_flr_i32_f32
+// Built by __graft_entry__.build() into tools/_build/valu_rates (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -119,9 +120,9 @@ __global__ __launch_bounds__(256) void fract_check(uint32_t base, unsigned long 
     const float hw = __builtin_amdgcn_fractf(x);
     const float sub = x - floorf(x);
     const float emu = fminf(sub, 0x1.fffffep-1f);
-    const bool same_emu = (__float_as_uint(hw) == __float_as_uint(emu)) || (hw != hw && emu != emu);
+    const bool finite = ((bits >> 23) & 0xFFu) != 255u;
     const bool same_sub = (__float_as_uint(hw) == __float_as_uint(sub)) || (hw != hw && sub != sub);
-    if (!same_emu) {
+    if (finite && __float_as_uint(hw) != __float_as_uint(emu)) {
         const unsigned long long k = atomicAdd(&counts[0], 1ull);
         if (k < 16) {
             examples[2 * k] = bits;
@@ -130,6 +131,9 @@ __global__ __launch_bounds__(256) void fract_check(uint32_t base, unsigned long 
     }
     if (!same_sub) {
         atomicAdd(&counts[1], 1ull);
+    }
+    if (!finite && hw == hw) {
+        atomicAdd(&counts[2], 1ull);  // Inf / NaN input must give NaN
     }
 }
 
@@ -218,6 +222,9 @@ __global__ __launch_bounds__(256) void cvt_flr_check(uint32_t base, unsigned lon
             examples[2 * k] = bits;
             examples[2 * k + 1] = (uint32_t)hw;
         }
+        if (x == x) {
+            atomicAdd(&counts[1], 1ull);
+        }
     }
 }
 
@@ -276,7 +283,71 @@ static int run_rate(const char *name, int ops_per_iter_per_chain, float *dout)
     return 0;
 }
 
-int main()
+static int run_checks()
+{
+    unsigned long long *dcounts, hcounts[4];
+    uint32_t *dex, hex[32];
+    CHECK(hipMalloc(&dcounts, 4 * sizeof(unsigned long long)));
+    CHECK(hipMalloc(&dex, 32 * sizeof(uint32_t)));
+    // (1) reciprocal
+    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
+    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
+    for (uint32_t hi = 0; hi < 256; ++hi) {
+        hipLaunchKernelGGL(recip_check2, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
+    }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
+    printf("recip rcp+Newton vs IEEE 1/z over all 2^32 inputs: mismatches mid-range(exp 27..227)=%llu, outer normal=%llu, "
+           "denormal/zero/inf/nan=%llu; raw v_rcp_f32 != exact in mid-range: %llu\n",
+           hcounts[0], hcounts[1], hcounts[2], hcounts[3]);
+    printf("CHECK_recip_midrange_mismatches=%llu\n", hcounts[0]);
+    for (int i = 0; i < 16 && (unsigned long long)i < hcounts[0]; ++i) {
+        float z;
+        memcpy(&z, &hex[2 * i], 4);
+        printf("   z=%08x (%g) fast=%08x exact=%a\n", hex[2 * i], z, hex[2 * i + 1], 1.0f / z);
+    }
+    // (2) fract
+    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
+    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
+    for (uint32_t hi = 0; hi < 256; ++hi) {
+        hipLaunchKernelGGL(fract_check, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
+    }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
+    printf("v_fract_f32 vs min(x-floor(x), 0x1.fffffep-1) on finite x: mismatches=%llu ; vs plain x-floor(x) (all x): %llu ; "
+           "Inf/NaN inputs not giving NaN: %llu\n", hcounts[0], hcounts[1], hcounts[2]);
+    printf("CHECK_fract_finite_mismatches=%llu\nCHECK_fract_nonfinite_not_nan=%llu\n", hcounts[0], hcounts[2]);
+    for (int i = 0; i < 16 && (unsigned long long)i < hcounts[0]; ++i) {
+        float z;
+        memcpy(&z, &hex[2 * i], 4);
+        printf("   x=%08x (%g) hw=%08x\n", hex[2 * i], z, hex[2 * i + 1]);
+    }
+    // (3) cvt_flr
+    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
+    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
+    for (uint32_t hi = 0; hi < 256; ++hi) {
+        hipLaunchKernelGGL(cvt_flr_check, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
+    }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
+    printf("v_cvt_flr_i32_f32 vs saturating (int)floor(x) with NaN -> 0: mismatches=%llu, of which x is not NaN: %llu\n", hcounts[0],
+           hcounts[1]);
+    printf("CHECK_cvt_flr_non_nan_mismatches=%llu\n", hcounts[1]);
+    float *dsv, hsv[6];
+    CHECK(hipMalloc(&dsv, sizeof(hsv)));
+    hipLaunchKernelGGL(special_values, dim3(1), dim3(1), 0, 0, dsv);
+    CHECK(hipMemcpy(hsv, dsv, sizeof(hsv), hipMemcpyDeviceToHost));
+    uint32_t u[6];
+    memcpy(u, hsv, sizeof(u));
+    printf("v_fract_f32: +inf -> %08x, -inf -> %08x, nan -> %08x, -1e-10 -> %08x, -0 -> %08x, 3e38 -> %08x\n", u[0], u[1], u[2], u[3], u[4],
+           u[5]);
+    return 0;
+}
+
+static int run_rates()
 {
     float *dout;
     CHECK(hipMalloc(&dout, 256 * 8 * 256 * sizeof(float)));
@@ -292,7 +363,6 @@ int main()
     run_rate<8>("v_med3_f32", 1, dout);
     run_rate<9>("cvt_f32_ubyte1 + add (2-3 ops)", 2, dout);
     run_rate<11>("mul + v_fract_f32 (2 ops)", 2, dout);
-
     {
         uint32_t *dh, hh[64];
         for (int i = 0; i < 64; ++i) {
@@ -313,29 +383,6 @@ int main()
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-34s %8.3f ms  %6.2f SIMD-cycles per wave-op (at 2.4 GHz)\n", "v_fma_mix_f32 (f32*f16+f16)", ms,
                ms * 1e-3 * 2.4e9 * 1024 / (2048.0 * 4 * kIters * kChains));
-        float *dsv, hsv[6];
-        CHECK(hipMalloc(&dsv, sizeof(hsv)));
-        hipLaunchKernelGGL(special_values, dim3(1), dim3(1), 0, 0, dsv);
-        CHECK(hipMemcpy(hsv, dsv, sizeof(hsv), hipMemcpyDeviceToHost));
-        uint32_t u[6];
-        memcpy(u, hsv, sizeof(u));
-        printf("v_fract_f32: +inf -> %08x, -inf -> %08x, nan -> %08x, -1e-10 -> %08x, -0 -> %08x, 3e38 -> %08x\n", u[0], u[1], u[2], u[3], u[4], u[5]);
-        unsigned long long *dc, hc[4];
-        uint32_t *dex, hex[32];
-        CHECK(hipMalloc(&dc, sizeof(hc)));
-        CHECK(hipMalloc(&dex, sizeof(hex)));
-        CHECK(hipMemset(dc, 0, sizeof(hc)));
-        CHECK(hipMemset(dex, 0, sizeof(hex)));
-        for (uint32_t hi = 0; hi < 256; ++hi) {
-            hipLaunchKernelGGL(cvt_flr_check, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dc, dex);
-        }
-        CHECK(hipDeviceSynchronize());
-        CHECK(hipMemcpy(hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
-        CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
-        printf("v_cvt_flr_i32_f32 vs saturating (int)floor(x), NaN -> 0, over all 2^32 inputs: mismatches=%llu\n", hc[0]);
-        for (int i = 0; i < 8 && (unsigned long long)i < hc[0]; ++i) {
-            printf("   x=%08x hw=%08x\n", hex[2 * i], hex[2 * i + 1]);
-        }
     }
     long long *dclk;
     CHECK(hipMalloc(&dclk, 2 * sizeof(long long)));
@@ -348,44 +395,21 @@ int main()
     for (int w = 1; w <= 8; w = (w < 4) ? w + 1 : w * 2) {
         run_ilp<8>(w, dout, dclk);
     }
-    if (getenv("VALU_RATES_SKIP_EXHAUSTIVE")) {
-        return 0;
+    return 0;
+}
+
+// usage: valu_rates            rates, then the exhaustive checks
+//        valu_rates --check    exhaustive checks only (machine-readable CHECK_* lines; tests/test_gpu_edge_cases.py)
+//        valu_rates --rates    rates only
+int main(int argc, char **argv)
+{
+    const bool only_check = argc > 1 && !strcmp(argv[1], "--check");
+    const bool only_rates = argc > 1 && !strcmp(argv[1], "--rates");
+    if (!only_check && run_rates()) {
+        return 1;
     }
-    unsigned long long *dcounts, hcounts[4];
-    uint32_t *dex, hex[32];
-    CHECK(hipMalloc(&dcounts, 4 * sizeof(unsigned long long)));
-    CHECK(hipMalloc(&dex, 32 * sizeof(uint32_t)));
-    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
-    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
-    for (uint32_t hi = 0; hi < 256; ++hi) {
-        hipLaunchKernelGGL(recip_check2, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
-    }
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
-    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
-    printf("recip rcp+Newton vs IEEE 1/z over all 2^32 inputs: mismatches mid-range(exp 27..227)=%llu, outer normal=%llu, "
-           "denormal/zero/inf/nan=%llu; raw v_rcp_f32 != exact in mid-range: %llu\n",
-           hcounts[0], hcounts[1], hcounts[2], hcounts[3]);
-    for (int i = 0; i < 16 && (unsigned long long)i < hcounts[0]; ++i) {
-        float z, f;
-        memcpy(&z, &hex[2 * i], 4);
-        memcpy(&f, &hex[2 * i + 1], 4);
-        printf("   z=%08x (%g) fast=%08x exact=%a\n", hex[2 * i], z, hex[2 * i + 1], 1.0f / z);
-    }
-    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
-    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
-    for (uint32_t hi = 0; hi < 256; ++hi) {
-        hipLaunchKernelGGL(fract_check, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
-    }
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
-    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
-    printf("v_fract_f32 vs min(x-floor(x), 0x1.fffffep-1): mismatches=%llu ; vs plain x-floor(x): mismatches=%llu\n", hcounts[0],
-           hcounts[1]);
-    for (int i = 0; i < 16 && (unsigned long long)i < hcounts[0]; ++i) {
-        float z;
-        memcpy(&z, &hex[2 * i], 4);
-        printf("   x=%08x (%g) hw=%08x\n", hex[2 * i], z, hex[2 * i + 1]);
+    if (!only_rates && run_checks()) {
+        return 1;
     }
     return 0;
 }
