@@ -51,11 +51,20 @@ __global__ __launch_bounds__(64) void k1_init_random_states(FrameArgs fa)
 // K5  RandomInitialization (APD.cu:806-835) with the initial costs of :616-693
 // ------------------------------------------------------------------------------------------------
 
+// Full-frame kernels (K5, K14, K15): a 256-lane workgroup covers a 16x16 tile and each wave64 an 8x8 block of it,
+// so the patches gathered by one wave overlap in both directions (a 32x2 strip would share rows only).
+__device__ __forceinline__ void full_frame_pixel(int &px, int &py)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+}
+
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
 {
-    const int px = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int py = blockIdx.y * 8 + (threadIdx.x >> 5);
+    int px, py;
+    full_frame_pixel(px, py);
     if (px >= fa.W || py >= fa.H) {
         return;
     }
@@ -489,8 +498,8 @@ __device__ __forceinline__ int baseline_and_weight(const FrameArgs &fa, uint32_t
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
 {
-    const int px = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int py = blockIdx.y * 8 + (threadIdx.x >> 5);
+    int px, py;
+    full_frame_pixel(px, py);
     if (px >= fa.W || py >= fa.H) {
         return;
     }
@@ -570,8 +579,8 @@ __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
 {
-    const int px = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int py = blockIdx.y * 8 + (threadIdx.x >> 5);
+    int px, py;
+    full_frame_pixel(px, py);
     if (px >= fa.W || py >= fa.H) {
         return;
     }
@@ -664,7 +673,7 @@ hipError_t launch_pack_quads(const float *img, int W, int H, uint32_t *quad, hip
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
 
-static inline dim3 grid_32x8(const FrameArgs &fa) { return dim3((fa.W + 31) / 32, (fa.H + 7) / 8); }
+static inline dim3 grid_16x16(const FrameArgs &fa) { return dim3((fa.W + 15) / 16, (fa.H + 15) / 16); }
 static inline int checkerboard_tiles(const FrameArgs &fa) { return ((fa.W + kTileW - 1) / kTileW) * ((fa.H + kTileH - 1) / kTileH); }
 
 template <int NMAX>
@@ -687,9 +696,9 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
     }
     case APD_K5_RANDOM_INITIALIZATION:
         if (fa.use_quads) {
-            hipLaunchKernelGGL(k5_random_initialization<true>, grid_32x8(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k5_random_initialization<true>, grid_16x16(fa), dim3(256), 0, s, fa);
         } else {
-            hipLaunchKernelGGL(k5_random_initialization<false>, grid_32x8(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k5_random_initialization<false>, grid_16x16(fa), dim3(256), 0, s, fa);
         }
         break;
     case APD_K6_BLACK_UPDATE_STRONG:
@@ -714,16 +723,16 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
         break;
     case APD_K14_DEPTH_TO_WEAK:
         if (fa.use_quads) {
-            hipLaunchKernelGGL(k14_depth_to_weak<true>, grid_32x8(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k14_depth_to_weak<true>, grid_16x16(fa), dim3(256), 0, s, fa);
         } else {
-            hipLaunchKernelGGL(k14_depth_to_weak<false>, grid_32x8(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k14_depth_to_weak<false>, grid_16x16(fa), dim3(256), 0, s, fa);
         }
         break;
     case APD_K15_LOCAL_REFINE:
         if (fa.use_quads) {
-            hipLaunchKernelGGL(k15_local_refine<true>, grid_32x8(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k15_local_refine<true>, grid_16x16(fa), dim3(256), 0, s, fa);
         } else {
-            hipLaunchKernelGGL(k15_local_refine<false>, grid_32x8(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k15_local_refine<false>, grid_16x16(fa), dim3(256), 0, s, fa);
         }
         break;
     default:
