@@ -865,6 +865,13 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
         qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)pitch4, (int)(pitch4 + 4u));
     }
     APD_STAGE();
+#ifdef APD_EXPERIMENT_SUB_ADDR_ZERO  // timing experiment only: every sub-patch gather hits the same L1 line
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        qx[k] = qx[k] & 0x7c;
+    }
+    APD_STAGE();
+#endif
     uint32_t t[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {

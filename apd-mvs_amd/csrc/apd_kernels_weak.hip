@@ -493,12 +493,19 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
         return 2.0f;
     }
     // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above)
+#ifdef APD_EXPERIMENT_WEAK_NO_CENTRE  // timing experiment only: sub-patches alone
+    const float center_cost = 0.5f;
+#else
     const float center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+#endif
     const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
     const unsigned pitch4 = 4u * (unsigned)(fa.W + 1);
     const int wm1 = fa.W - 1, hm1 = fa.H - 1;
     float strong_cost = 0.0f;
     int strong_count = 0;
+#ifdef APD_EXPERIMENT_WEAK_NO_SUB  // timing experiment only: centre patch alone
+    return center_cost;
+#endif
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
         const int packed = lds.nb[k][lane];
@@ -562,8 +569,11 @@ __global__ __launch_bounds__(64) void k_compact_weak(FrameArgs fa, int colour, i
 
 // Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
 // plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
+#ifndef APD_K910_WAVES
+#define APD_K910_WAVES 2
+#endif
 template <int NMAX, bool kQuad>
-__global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, const int *__restrict__ count)
+__global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, const int *__restrict__ count)
 {
     __shared__ WeakLds lds;
     const int lane = threadIdx.x;
@@ -601,20 +611,35 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int iter, c
     float4 ref_normals[5];
     bool skip_refine = false;
 
+    // ---- candidates: the eight reliable neighbours' planes (must still be STRONG, :1354) + the current plane ----
+    for (int h = 0; h < 8; ++h) {
+        const short2 q = nb[h + 1];
+        if (q.x == -1 || q.y == -1 || fa.weak_info[q.x + q.y * W] != APD_STRONG) {
+            continue;
+        }
+        flags |= 1u << h;
+        cand[h] = fa.planes[q.x + q.y * W];
+    }
+    // Costs of hypotheses 0..8.  View-major order: every hypothesis of a pixel projects a neighbour's sub-patch
+    // to nearly the same place in one source image, so the nine evaluations per view reuse the lines the
+    // first one brought in (the reference's hypothesis-major order cycles through all N images in between).
 #pragma unroll 1
-    for (int h = 0; h < 16; ++h) {
-        float4 pl;
-        if (h < 8) {
-            const short2 q = nb[h + 1];
-            if (q.x == -1 || q.y == -1 || fa.weak_info[q.x + q.y * W] != APD_STRONG) {
+    for (int v = 0; v < nsrc; ++v) {
+        const ViewConst &vc = fa.views[v];
+#pragma unroll 1
+        for (int h = 0; h < 9; ++h) {
+            if (h < 8 && !(flags & (1u << h))) {
                 continue;
             }
-            flags |= 1u << h;
-            pl = fa.planes[q.x + q.y * W];
-            cand[h] = pl;
-        } else if (h == 8) {
-            pl = plane_now;
-        } else if (h == 9) {
+            const float4 pl = (h < 8) ? cand[h] : plane_now;
+            cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
+        }
+    }
+
+#pragma unroll 1
+    for (int h = 9; h < 16; ++h) {
+        float4 pl;
+        if (h == 9) {
             // ---- joint view selection (:1365-1434), adopt (:1436-1485) ----
             float priors[NMAX];
             for (int j = 0; j < NMAX; ++j) {
@@ -700,16 +725,14 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int iter, c
             pl = ref_normals[h - 10];
             pl.w = distance_to_origin(fa, px, py, ref_depths[h - 10], pl.x, pl.y, pl.z);
         }
-        if (h >= 9 && h <= 14 && skip_refine) {
+        if (h <= 14 && skip_refine) {
             continue;
         }
         float tc = 0.0f;
 #pragma unroll 1
         for (int v = 0; v < nsrc; ++v) {
             const ViewConst &vc = fa.views[v];
-            if (h < 9) {
-                cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
-            } else if (h == 15) {
+            if (h == 15) {
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
                 tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
@@ -724,7 +747,7 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int iter, c
                 }
             }
         }
-        if (h >= 9 && h <= 14) {
+        if (h <= 14) {
             tc /= weight_norm;
             const float d = depth_from_plane(fa, pl, px, py);
             if (d >= fa.depth_min && d <= fa.depth_max && tc < cost_now) {
@@ -732,7 +755,7 @@ __global__ __launch_bounds__(64) void k910_update_weak(FrameArgs fa, int iter, c
                 plane_now = pl;
                 cost_now = tc;
             }
-        } else if (h == 15) {
+        } else {
             fa.costs[center] = tc / weight_norm;
             fa.planes[center] = plane_final;
         }
