@@ -1,0 +1,267 @@
+"""In-memory multi-view, multi-scale pass scheduler for the PatchMatch path, sharded over ranks.
+
+Mirrors the reference's driver (main.cpp:140-217): `round_num` pyramid levels x (1 photometric + 3 geometric)
+passes over every reference view, with the per-pass parameters of main.cpp:171-212 and the level handling of
+APD::InuputInitialization (APD.cpp:464-581).  Two things differ from the reference, both by design:
+
+* state between passes (depth, normal, weak map, selected views per view) stays in memory instead of travelling
+  through depths.dmb / normals.dmb / weak.bin / selected_views.bin; decoded and rescaled images are cached per level
+  instead of being re-read for every (view, pass);
+* views are sharded round-robin over the ranks of a torch.distributed group (one process per GPU).  After every
+  pass the ranks all-gather the depth maps (the geometric term of the next pass reads the sources' depth maps,
+  APD.cpp:492-509, APD.cu:760-772) and, after the last pass, depth + normal + weak maps (what fusion consumes).
+
+With one rank the order of evaluation is the reference's (Gauss-Seidel over views inside a pass: later views read the
+depth maps earlier views have just written) and the results are bit-identical to the drop-in binary
+(tests/test_gpu_dropin_binary.py).  With G ranks a view sees this pass's maps of the views its own rank has already
+processed and the previous pass's maps of everybody else's.
+
+The compute backend is injected: `HipBackend` (the product) drives the C ABI; the CPU tests plug the oracle in.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import sharding
+
+
+@dataclass
+class MvsScene:
+    """cameras[i] (full resolution, `apd_camera`), images[i] (float32 [H, W]), pairs[i] = source view ids of view i."""
+    cameras: list
+    images: list
+    pairs: list
+
+    @property
+    def num_views(self):
+        return len(self.images)
+
+
+@dataclass
+class PassSpec:
+    """One pass over all views (main.cpp:169-215)."""
+    round_index: int
+    iteration_index: int
+    scale_size: int
+    params: dict = field(default_factory=dict)
+
+
+@dataclass
+class ViewState:
+    depth: np.ndarray      # float32 [H, W], 0 = invalid (main.cpp:109-112)
+    normal: np.ndarray     # float32 [H, W, 3], world frame
+    weak: np.ndarray       # uint8 [H, W]
+    views: np.ndarray      # uint32 [H, W] selected-view bitmask
+
+
+def compute_round_num(width, height):
+    """main.cpp:72-88: halve until max(W, H) <= 1000."""
+    max_size = max(width, height)
+    round_num = 1
+    while max_size > 1000:
+        max_size //= 2
+        round_num += 1
+    return round_num
+
+
+def pass_schedule(round_num, iters=3, single_level=False):
+    """Per-pass parameters of main.cpp:168-215."""
+    out = []
+    it = 0
+    for i in range(round_num):
+        scale = 1 if single_level else int(2 ** (round_num - 1 - i))
+        apd = dict(use_APD=0) if i == 0 else dict(use_APD=1, ransac_threshold=float(np.float32(0.01 - i * 0.00125)),
+                                                  rotate_time=min(int(2 ** i), 4))
+        p = dict(state=0 if i == 0 else 1, geom_consistency=0, max_iterations=iters, weak_peak_radius=6)
+        p.update(apd)
+        out.append(PassSpec(i, it, scale, p))
+        it += 1
+        for j in range(3):
+            p = dict(state=2, geom_consistency=1, max_iterations=iters, weak_peak_radius=max(4 - 2 * j, 2))
+            p.update(apd)
+            out.append(PassSpec(i, it, scale, p))
+            it += 1
+    return out
+
+
+def resize_linear(src, new_cols, new_rows):
+    """cv::resize(..., INTER_LINEAR) on a float image as the C++ host does it (host/APD.cpp ResizeLinear):
+    fx = (dx + 0.5) * (src/dst) - 0.5 in double, taps floor(fx), floor(fx)+1 clamped, float weights, rows after columns."""
+    src = np.ascontiguousarray(src, np.float32)
+    rows, cols = src.shape
+
+    def taps(n_new, n_old):
+        f = ((np.arange(n_new, dtype=np.float64) + 0.5) * (float(n_old) / n_new) - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        a = (f - i.astype(np.float32)).astype(np.float32)
+        lo = i < 0
+        i[lo], a[lo] = 0, 0
+        hi = i >= n_old - 1
+        i[hi], a[hi] = n_old - 1, 0
+        return i, np.minimum(i + 1, n_old - 1), a
+
+    x0, x1, ax = taps(new_cols, cols)
+    y0, y1, ay = taps(new_rows, rows)
+    one = np.float32(1.0)
+    r0, r1 = src[y0], src[y1]
+    top = r0[:, x0] * (one - ax) + r0[:, x1] * ax
+    bot = r1[:, x0] * (one - ax) + r1[:, x1] * ax
+    ay = ay[:, None]
+    return (top * (one - ay) + bot * ay).astype(np.float32)
+
+
+def rescale_nearest(src, target_width, target_height):
+    """RescaleMatToTargetSize (APD.cpp:752-774) including its swapped factors: row / scale_x, column / scale_y."""
+    rows, cols = src.shape[:2]
+    if cols == target_width and rows == target_height:
+        return src
+    scale_x = np.float32(target_width) / np.float32(cols)
+    scale_y = np.float32(target_height) / np.float32(rows)
+    o_r = (np.arange(target_height, dtype=np.float32) / scale_x).astype(np.int64)
+    o_c = (np.arange(target_width, dtype=np.float32) / scale_y).astype(np.int64)
+    out = np.zeros((target_height, target_width) + src.shape[2:], src.dtype)
+    ok_r, ok_c = o_r < rows, o_c < cols
+    out[np.ix_(ok_r, ok_c)] = src[np.ix_(o_r[ok_r], o_c[ok_c])]
+    return out
+
+
+def level_inputs(scene, scale_size, camera_type):
+    """Scaled images and intrinsics of one pyramid level (APD.cpp:464-488): every image by its own rounded size."""
+    cams, imgs = [], []
+    for cam, img in zip(scene.cameras, scene.images):
+        c = camera_type.from_buffer_copy(cam)
+        rows, cols = img.shape
+        c.width, c.height = cols, rows
+        if scale_size != 1:
+            factor = np.float32(1.0) / np.float32(scale_size)
+            new_cols = int(math.floor(float(np.float32(cols) * factor) + 0.5))   # std::round of a positive float
+            new_rows = int(math.floor(float(np.float32(rows) * factor) + 0.5))
+            sx = np.float32(new_cols) / np.float32(cols)
+            sy = np.float32(new_rows) / np.float32(rows)
+            img = resize_linear(img, new_cols, new_rows)
+            c.K[0] = float(np.float32(c.K[0]) * sx)
+            c.K[2] = float(np.float32(c.K[2]) * sx)
+            c.K[4] = float(np.float32(c.K[4]) * sy)
+            c.K[5] = float(np.float32(c.K[5]) * sy)
+            c.width, c.height = new_cols, new_rows
+        cams.append(c)
+        imgs.append(np.ascontiguousarray(img, np.float32))
+    return cams, imgs
+
+
+class HipBackend:
+    """One (view, pass) on the MI355X through the C ABI (== ProcessProblem, main.cpp:91-115)."""
+
+    def __init__(self, pkg, device=0):
+        self.pkg = pkg
+        self.device = device
+
+    @property
+    def camera_type(self):
+        return self.pkg.Camera
+
+    def run_pass(self, width, height, params, cameras, images, depths, prior):
+        pkg = self.pkg
+        h = pkg.Handle(width, height, pkg.default_params(**params), device=self.device)
+        try:
+            h.upload_views(cameras, images, depths)
+            if prior is not None:
+                h.upload_prior(*prior)
+            h.run()
+            return h.download()
+        finally:
+            h.close()
+
+
+def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=None, max_rounds=None, max_passes=None, log=None):
+    """Runs every pass of the schedule on this rank's views; returns {view: ViewState} for ALL views on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    V = scene.num_views
+    mine = sharding.shard_views(V, world, rank)
+    h0, w0 = scene.images[0].shape
+    round_num = 1 if single_level else compute_round_num(w0, h0)
+    if max_rounds is not None:
+        round_num = min(round_num, max_rounds)
+    schedule = pass_schedule(round_num, iters, single_level)
+    if max_passes is not None:
+        schedule = schedule[:max_passes]
+    state = {}        # own views: ViewState at the level they were last written
+    depth_store = {}  # every view's depth map as this rank knows it
+    device = torch.device("cuda", backend.device) if getattr(backend, "device", None) is not None and torch.cuda.is_available() \
+        else torch.device("cpu")
+    level_cache = {}
+    for spec in schedule:
+        if spec.scale_size not in level_cache:
+            level_cache.clear()
+            level_cache[spec.scale_size] = level_inputs(scene, spec.scale_size, backend.camera_type)
+        cams, imgs = level_cache[spec.scale_size]
+        for idx in mine:
+            order = [idx] + list(scene.pairs[idx])
+            W, H = cams[idx].width, cams[idx].height
+            p = dict(spec.params)
+            p["num_images"] = len(order)
+            p["depth_min"] = float(np.float32(cams[idx].depth_min) * np.float32(0.6))   # APD.cpp:454-455
+            p["depth_max"] = float(np.float32(cams[idx].depth_max) * np.float32(1.2))
+            p["seed"] = seed + spec.iteration_index * 7919 + idx
+            depths = None
+            if p["geom_consistency"]:
+                depths = [np.ascontiguousarray(rescale_nearest(depth_store[j], W, H)) for j in order]
+            prior = None
+            if p["state"] != 0:
+                st = state[idx]
+                depth = rescale_nearest(st.depth, W, H)
+                normal = rescale_nearest(st.normal, W, H)
+                views = rescale_nearest(st.views, W, H)
+                weak = rescale_nearest(st.weak, W, H) if p["use_APD"] else None
+                prior = (np.ascontiguousarray(np.concatenate([normal, depth[..., None]], -1)), np.ascontiguousarray(views),
+                         None if weak is None else np.ascontiguousarray(weak))
+            planes, weak, views = backend.run_pass(W, H, p, [cams[j] for j in order], [imgs[j] for j in order], depths, prior)
+            d = planes[..., 3].copy()
+            bad = (d < np.float32(p["depth_min"])) | (d > np.float32(p["depth_max"]))   # main.cpp:109-112
+            d[bad] = 0
+            weak = weak.copy()
+            weak[bad] = 2
+            state[idx] = ViewState(d, np.ascontiguousarray(planes[..., :3]), weak, views.copy())
+            depth_store[idx] = d
+            if log:
+                log("pass %d (round %d, scale %d) view %d done on rank %d" % (spec.iteration_index, spec.round_index, spec.scale_size, idx, rank))
+        if world > 1:
+            local = {v: torch.from_numpy(state[v].depth[..., None]).to(device) for v in mine}
+            gathered = sharding.allgather_maps(local, V, group=group)
+            g = gathered.cpu().numpy()
+            for v in range(V):
+                if v not in state:
+                    depth_store[v] = g[v, ..., 0]
+    # before fusion: everybody gets every view's depth + normal + weak (+ selected views)
+    if world > 1:
+        packed = {}
+        for v in mine:
+            st = state[v]
+            packed[v] = torch.from_numpy(np.concatenate([st.depth[..., None], st.normal, st.weak[..., None].astype(np.float32),
+                                                         st.views[..., None].view(np.float32)], -1)).to(device)
+        g = sharding.allgather_maps(packed, V, group=group).cpu().numpy()
+        out = {}
+        for v in range(V):
+            out[v] = ViewState(np.ascontiguousarray(g[v, ..., 0]), np.ascontiguousarray(g[v, ..., 1:4]),
+                               g[v, ..., 4].astype(np.uint8), np.ascontiguousarray(g[v, ..., 5]).view(np.uint32))
+        return out
+    return state
+
+
+def synthetic_ring(synth, width, height, num_views, num_src, camera_factory, seed=0, textureless=0.0):
+    """`num_views` reference views on the generator's camera ring, each paired with its `num_src` nearest neighbours.
+    camera_factory(K, R, t, W, H, depth_min, depth_max) builds the backend's camera struct."""
+    sc = synth.make_scene(width, height, num_views - 1, seed=seed, textureless=textureless)
+    imgs = sc.images_numpy()
+    cams = [camera_factory(sc.K[i], sc.R[i], sc.t[i], width, height, sc.depth_min, sc.depth_max) for i in range(num_views)]
+    pairs = []
+    for i in range(num_views):
+        others = sorted((j for j in range(num_views) if j != i), key=lambda j: (abs(j - i), j))
+        pairs.append(others[:num_src])
+    return MvsScene(cams, [np.ascontiguousarray(im, np.float32) for im in imgs], pairs)

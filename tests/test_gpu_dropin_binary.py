@@ -127,3 +127,28 @@ def test_binary_usage_and_bad_device(gpu_pkg, tmp_path):
     (tmp_path / "pair.txt").write_text("0\n")
     r = subprocess.run([APD_BIN, str(tmp_path), "99"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode != 0 and "found" in r.stdout
+
+
+@pytest.mark.parametrize("W,H,levels", [(80, 60, 1), (1032, 48, 2)])
+def test_in_memory_pipeline_matches_binary(gpu_pkg, synth, tmp_path, W, H, levels):
+    """apd-mvs_amd/pipeline.py on one rank (state kept in memory, images cached per level) == the file-based drop-in
+    binary, bit for bit, including a two-level pyramid: image / intrinsics downscaling, nearest-neighbour upsampling of
+    the prior state with the reference's swapped factors, REFINE_INIT + APD on the finer level."""
+    from apd_mvs_amd import pipeline
+    nviews, seed, iters = 3, 31, 1
+    _write_dense_folder(tmp_path, synth, W, H, nviews)
+    r = subprocess.run([APD_BIN, str(tmp_path), "0", "--seed", str(seed), "--iters", str(iters)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert ("Round nums: %d" % levels) in r.stdout
+    cams = [_read_cam(tmp_path / "cams" / ("%08d_cam.txt" % i), gpu_pkg, W, H) for i in range(nviews)]
+    imgs = [_read_image(tmp_path, i, False) for i in range(nviews)]
+    scene = pipeline.MvsScene(cams, imgs, [[j for j in range(nviews) if j != i] for i in range(nviews)])
+    out = pipeline.run_pipeline(scene, pipeline.HipBackend(gpu_pkg, device=0), iters=iters, seed=seed)
+    for idx in range(nviews):
+        d = tmp_path / "APD" / ("%08d" % idx)
+        assert np.array_equal(_read_dmb(d / "depths.dmb").view(np.uint32), out[idx].depth.view(np.uint32)), idx
+        assert np.array_equal(_read_dmb(d / "normals.dmb").view(np.uint32), out[idx].normal.view(np.uint32)), idx
+        assert np.array_equal(_read_dmb(d / "weak.bin"), out[idx].weak), idx
+        assert np.array_equal(_read_dmb(d / "selected_views.bin"), out[idx].views), idx
+    assert (out[0].depth > 0).mean() > 0.5
