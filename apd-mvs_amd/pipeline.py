@@ -265,3 +265,85 @@ def synthetic_ring(synth, width, height, num_views, num_src, camera_factory, see
         others = sorted((j for j in range(num_views) if j != i), key=lambda j: (abs(j - i), j))
         pairs.append(others[:num_src])
     return MvsScene(cams, [np.ascontiguousarray(im, np.float32) for im in imgs], pairs)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dense-folder I/O (the reference's on-disk contract) through the C++ host library
+# ------------------------------------------------------------------------------------------------------------------
+
+_host = None
+
+
+def host_lib():
+    """libapd_host.so: ReadCamera / ReadGrayImage / ReadBinMat / WriteBinMat of the drop-in host (host/APD.cpp)."""
+    global _host
+    if _host is None:
+        import ctypes as C
+        import os
+        from . import lib as product_lib, LIB_PATH
+        product_lib()  # libapd_host.so links against libapd_mi355x.so
+        L = C.CDLL(os.path.join(os.path.dirname(LIB_PATH), "libapd_host.so"))
+        ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
+        L.apdhost_read_camera.argtypes = [C.c_char_p, C.c_void_p]
+        L.apdhost_read_gray_image.argtypes = [C.c_char_p, ip, ip, fp, C.c_size_t]
+        L.apdhost_write_bin_mat.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _host = L
+    return _host
+
+
+def load_dense_folder(folder, camera_type):
+    """pair.txt (main.cpp:6-49: sources with score <= 0 dropped), cams/%08d_cam.txt, images/%08d.{jpg,pgm}.
+    View i of the returned scene is the i-th entry of pair.txt; `ids` maps it back to the image id."""
+    import ctypes as C
+    import os
+    L = host_lib()
+    tok = open(os.path.join(folder, "pair.txt")).read().split()
+    n = int(tok[0])
+    pos = 1
+    ids, src_ids = [], []
+    for _ in range(n):
+        ids.append(int(tok[pos]))
+        m = int(tok[pos + 1])
+        pos += 2
+        srcs = []
+        for _ in range(m):
+            sid, score = int(tok[pos]), float(tok[pos + 1])
+            pos += 2
+            if score > 0.0:
+                srcs.append(sid)
+        src_ids.append(srcs)
+    index_of = {v: i for i, v in enumerate(ids)}
+    cams, imgs = [], []
+    for v in ids:
+        cam = camera_type()
+        if L.apdhost_read_camera(os.path.join(folder, "cams", "%08d_cam.txt" % v).encode(), C.byref(cam)) != 0:
+            raise IOError("cannot read camera %d" % v)
+        rows, cols = C.c_int(), C.c_int()
+        stem = os.path.join(folder, "images", "%08d" % v).encode()
+        if L.apdhost_read_gray_image(stem, C.byref(rows), C.byref(cols), None, 0) != 0:
+            raise IOError("cannot read image %d" % v)
+        img = np.empty((rows.value, cols.value), np.float32)
+        L.apdhost_read_gray_image(stem, C.byref(rows), C.byref(cols), img.ctypes.data_as(C.POINTER(C.c_float)), img.size)
+        cam.width, cam.height = cols.value, rows.value
+        cams.append(cam)
+        imgs.append(img)
+    scene = MvsScene(cams, imgs, [[index_of[s] for s in srcs if s in index_of] for srcs in src_ids])
+    scene.ids = ids
+    return scene
+
+
+def save_results(folder, scene, results):
+    """<dense>/APD/<%08d>/{depths.dmb, normals.dmb, weak.bin, selected_views.bin} as ProcessProblem writes them
+    (main.cpp:117-124), for the fusion step."""
+    import os
+    L = host_lib()
+    ids = getattr(scene, "ids", list(range(scene.num_views)))
+    for v, st in results.items():
+        d = os.path.join(folder, "APD", "%08d" % ids[v])
+        os.makedirs(d, exist_ok=True)
+        rows, cols = st.depth.shape
+        for name, code, arr in (("depths.dmb", 5, st.depth), ("normals.dmb", 21, st.normal), ("weak.bin", 0, st.weak),
+                                ("selected_views.bin", 4, st.views)):
+            a = np.ascontiguousarray(arr)
+            if L.apdhost_write_bin_mat(os.path.join(d, name).encode(), rows, cols, code, a.ctypes.data) != 0:
+                raise IOError("cannot write " + os.path.join(d, name))

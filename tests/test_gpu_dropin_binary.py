@@ -152,3 +152,24 @@ def test_in_memory_pipeline_matches_binary(gpu_pkg, synth, tmp_path, W, H, level
         assert np.array_equal(_read_dmb(d / "weak.bin"), out[idx].weak), idx
         assert np.array_equal(_read_dmb(d / "selected_views.bin"), out[idx].views), idx
     assert (out[0].depth > 0).mean() > 0.5
+
+
+def test_pipeline_cli_writes_the_binarys_files(gpu_pkg, synth, tmp_path):
+    """tools/mvs_pipeline.py (dense-folder loader + in-memory pipeline + .dmb writer) against the drop-in binary."""
+    import shutil
+    import sys
+    W, H, nviews, seed = 72, 56, 3, 9
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    _write_dense_folder(a, synth, W, H, nviews, jpeg=True)
+    shutil.copytree(a, b)
+    r = subprocess.run([APD_BIN, str(a), "0", "--seed", str(seed), "--iters", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mvs_pipeline.py"), str(b), "--seed", str(seed), "--iters", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    for idx in range(nviews):
+        for name in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
+            fa, fb = a / "APD" / ("%08d" % idx) / name, b / "APD" / ("%08d" % idx) / name
+            assert fa.read_bytes() == fb.read_bytes(), (idx, name)
