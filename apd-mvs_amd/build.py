@@ -60,7 +60,7 @@ def build_library(force=False, verbose=False, extra_flags=()):
 HOST_DIR = os.path.join(HERE, "host")
 HOST_BIN = os.path.join(OUT_DIR, "APD")
 HOST_LIB = os.path.join(OUT_DIR, "libapd_host.so")
-HOST_SOURCES = ["APD.cpp", "jpeg_gray.cpp"]
+HOST_SOURCES = ["APD.cpp", "jpeg_gray.cpp", "fusion.cpp"]
 
 
 def build_host(force=False, verbose=False):

@@ -133,6 +133,9 @@ bool ReadGrayImage(const path &image_path_without_ext, Mat &image_float);
 // cv::resize(float, INTER_LINEAR) restated (APD.cpp:474)
 void ResizeLinear(const Mat &src, Mat &dst, int new_cols, int new_rows);
 
+// APD.h:34 -- consistency check + merge of the final depth maps into <dense>/APD/APD.ply (host CPU, host/fusion.cpp)
+void RunFusion(const path &dense_folder, const std::vector<Problem> &problems);
+
 class APD {
 public:
     APD(const Problem &problem);

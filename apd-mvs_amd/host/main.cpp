@@ -1,11 +1,11 @@
 // main.cpp -- drop-in driver for the PatchMatch path: `APD dense_folder [gpu_index] [--seed S]
-// [--iters K] [--single-level]`.
+// [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]`.
 //
 // Mirrors the reference's CLI and per-pass parameter schedule (main.cpp:140-233): pair.txt ->
 // Problems -> round_num pyramid levels x (1 photometric + 3 geometric) passes, state exchanged through
-// depths.dmb / normals.dmb / weak.bin / selected_views.bin in <dense>/APD/<%08d>/.
-// Out of scope here: RunFusion / APD.ply and the debug JPEGs; the four state files are
-// therefore left in place for a fusion tool instead of being deleted (main.cpp:220-230).
+// depths.dmb / normals.dmb / weak.bin / selected_views.bin in <dense>/APD/<%08d>/, then RunFusion ->
+// APD/APD.ply and removal of the four state files (main.cpp:219-230; --keep-maps leaves them in place).
+// Not built: the debug JPEGs of show_medium_result.
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -113,7 +113,7 @@ void ProcessProblem(const Problem &problem)
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        std::cerr << "USAGE: APD dense_folder [gpu_index] [--seed S] [--iters K] [--single-level]\n";
+        std::cerr << "USAGE: APD dense_folder [gpu_index] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]\n";
         return EXIT_FAILURE;
     }
     const path dense_folder(argv[1]);
@@ -121,7 +121,8 @@ int main(int argc, char **argv)
     int gpu_index = 0;
     uint64_t seed = 12345;
     int iters = 3;
-    bool single_level = false;
+    bool single_level = false, keep_maps = false, no_fusion = false;
+    int max_src = 0;
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) {
             seed = strtoull(argv[++i], nullptr, 10);
@@ -129,6 +130,12 @@ int main(int argc, char **argv)
             iters = atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--single-level")) {
             single_level = true;
+        } else if (!strcmp(argv[i], "--max-src") && i + 1 < argc) {
+            max_src = atoi(argv[++i]);  // additive knob: keep only the first N sources of pair.txt (best scores first)
+        } else if (!strcmp(argv[i], "--keep-maps")) {
+            keep_maps = true;
+        } else if (!strcmp(argv[i], "--no-fusion")) {
+            no_fusion = true;
         } else if (i == 2) {
             gpu_index = atoi(argv[i]);  // main.cpp:149-153
         }
@@ -143,6 +150,13 @@ int main(int argc, char **argv)
     if (problems.empty()) {
         std::cerr << "Images may error, check it!\n";
         return EXIT_FAILURE;
+    }
+    if (max_src > 0) {
+        for (auto &problem : problems) {
+            if ((int)problem.src_image_ids.size() > max_src) {
+                problem.src_image_ids.resize(max_src);
+            }
+        }
     }
     std::cout << "There are " << problems.size() << " problems needed to be processed!" << std::endl;
     const int round_num = single_level ? 1 : ComputeRoundNum(problems);
@@ -194,7 +208,17 @@ int main(int argc, char **argv)
         }
         std::cout << "Round: " << i << " done\n";
     }
-    std::cout << "PatchMatch passes done; depth/normal/weak/selected-view maps are in " << (dense_folder / path("APD")) << "\n";
-    std::cout << "(fusion into APD.ply is outside this build's scope)\n";
+    if (!no_fusion) {
+        RunFusion(dense_folder, problems);  // main.cpp:219
+    }
+    if (!keep_maps && !no_fusion) {  // main.cpp:220-230
+        for (const auto &problem : problems) {
+            std::filesystem::remove(problem.result_folder / path("weak.bin"));
+            std::filesystem::remove(problem.result_folder / path("depths.dmb"));
+            std::filesystem::remove(problem.result_folder / path("normals.dmb"));
+            std::filesystem::remove(problem.result_folder / path("selected_views.bin"));
+        }
+    }
+    std::cout << "All done\n";
     return EXIT_SUCCESS;
 }

@@ -287,6 +287,7 @@ def host_lib():
         L.apdhost_read_camera.argtypes = [C.c_char_p, C.c_void_p]
         L.apdhost_read_gray_image.argtypes = [C.c_char_p, ip, ip, fp, C.c_size_t]
         L.apdhost_write_bin_mat.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.apdhost_fuse.restype = C.c_longlong
         _host = L
     return _host
 
@@ -347,3 +348,48 @@ def save_results(folder, scene, results):
             a = np.ascontiguousarray(arr)
             if L.apdhost_write_bin_mat(os.path.join(d, name).encode(), rows, cols, code, a.ctypes.data) != 0:
                 raise IOError("cannot write " + os.path.join(d, name))
+
+
+def fuse(scene, results, ply_path):
+    """RunFusion (APD.cpp:826-977) on the gathered maps: consistency check and merge into a binary PLY, on the host CPU
+    like the reference (host/fusion.cpp).  Every view must be at one resolution per view; images are resampled to the
+    depth-map size if it differs (RescaleImageAndCamera, APD.cpp:729-750).  Returns the number of points."""
+    import ctypes as C
+    L = host_lib()
+    V = scene.num_views
+    cam_t = type(scene.cameras[0])
+    cams = (cam_t * V)()
+    imgs, deps, nors, weaks = [], [], [], []
+    rows, cols = (C.c_int * V)(), (C.c_int * V)()
+    for v in range(V):
+        st = results[v]
+        h, w = st.depth.shape
+        cam = cam_t.from_buffer_copy(scene.cameras[v])
+        img = scene.images[v]
+        if img.shape != (h, w):
+            sx = np.float32(w) / np.float32(img.shape[1])
+            sy = np.float32(h) / np.float32(img.shape[0])
+            img = np.rint(resize_linear(img, w, h)).astype(np.float32)
+            cam.K[0] = float(np.float32(cam.K[0]) * sx)
+            cam.K[2] = float(np.float32(cam.K[2]) * sx)
+            cam.K[4] = float(np.float32(cam.K[4]) * sy)
+            cam.K[5] = float(np.float32(cam.K[5]) * sy)
+        cams[v] = cam
+        rows[v], cols[v] = h, w
+        imgs.append(np.ascontiguousarray(img, np.float32))
+        deps.append(np.ascontiguousarray(st.depth, np.float32))
+        nors.append(np.ascontiguousarray(st.normal, np.float32))
+        weaks.append(np.ascontiguousarray(rescale_nearest(st.weak, w, h), np.uint8))
+    offs = (C.c_int * (V + 1))()
+    flat = []
+    for v in range(V):
+        offs[v] = len(flat)
+        flat += list(scene.pairs[v])
+    offs[V] = len(flat)
+    idx = (C.c_int * max(len(flat), 1))(*flat)
+
+    def ptrs(arrs):
+        return (C.c_void_p * V)(*[a.ctypes.data for a in arrs])
+
+    n = L.apdhost_fuse(V, C.byref(cams), ptrs(imgs), ptrs(deps), ptrs(nors), ptrs(weaks), rows, cols, offs, idx, str(ply_path).encode())
+    return int(n)

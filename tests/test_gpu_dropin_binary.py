@@ -84,7 +84,7 @@ def test_binary_matches_c_abi_schedule(gpu_pkg, synth, tmp_path, jpeg):
     assert os.path.exists(APD_BIN), "run __graft_entry__.build() first"
     W, H, nviews, seed, iters = 80, 60, 3, 77, 2
     _write_dense_folder(tmp_path, synth, W, H, nviews, jpeg=jpeg)
-    r = subprocess.run([APD_BIN, str(tmp_path), "0", "--seed", str(seed), "--iters", str(iters)], stdout=subprocess.PIPE,
+    r = subprocess.run([APD_BIN, str(tmp_path), "0", "--seed", str(seed), "--iters", str(iters), "--keep-maps"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "Round nums: 1" in r.stdout  # max(W,H) <= 1000 -> one pyramid level (main.cpp:83-86)
@@ -137,7 +137,7 @@ def test_in_memory_pipeline_matches_binary(gpu_pkg, synth, tmp_path, W, H, level
     from apd_mvs_amd import pipeline
     nviews, seed, iters = 3, 31, 1
     _write_dense_folder(tmp_path, synth, W, H, nviews)
-    r = subprocess.run([APD_BIN, str(tmp_path), "0", "--seed", str(seed), "--iters", str(iters)], stdout=subprocess.PIPE,
+    r = subprocess.run([APD_BIN, str(tmp_path), "0", "--seed", str(seed), "--iters", str(iters), "--keep-maps"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
     assert ("Round nums: %d" % levels) in r.stdout
@@ -163,7 +163,7 @@ def test_pipeline_cli_writes_the_binarys_files(gpu_pkg, synth, tmp_path):
     a.mkdir()
     _write_dense_folder(a, synth, W, H, nviews, jpeg=True)
     shutil.copytree(a, b)
-    r = subprocess.run([APD_BIN, str(a), "0", "--seed", str(seed), "--iters", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+    r = subprocess.run([APD_BIN, str(a), "0", "--seed", str(seed), "--iters", "1", "--keep-maps"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mvs_pipeline.py"), str(b), "--seed", str(seed), "--iters", "1"],
@@ -173,3 +173,49 @@ def test_pipeline_cli_writes_the_binarys_files(gpu_pkg, synth, tmp_path):
         for name in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
             fa, fb = a / "APD" / ("%08d" % idx) / name, b / "APD" / ("%08d" % idx) / name
             assert fa.read_bytes() == fb.read_bytes(), (idx, name)
+
+
+def _read_ply(path):
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().split("\n")
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0"
+    n = int([l for l in lines if l.startswith("element vertex")][0].split()[2])
+    props = [l for l in lines if l.startswith("property")]
+    assert props == ["property float x", "property float y", "property float z", "property uchar diffuse_blue",
+                     "property uchar diffuse_green", "property uchar diffuse_red"]
+    assert len(body) == 15 * n
+    rec = np.frombuffer(body, np.dtype([("xyz", "<f4", 3), ("bgr", "u1", 3)]))
+    return rec["xyz"], rec["bgr"]
+
+
+def test_fusion_writes_a_consistent_point_cloud(gpu_pkg, synth, tmp_path):
+    """End of the drop-in run (main.cpp:219-230): APD/APD.ply in the reference's binary layout, the four state files removed;
+    the fused points lie on the synthetic scene's surfaces; the in-memory pipeline fuses to the identical file."""
+    import shutil
+    import sys
+    W, H, nviews, seed = 96, 72, 4, 21
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    sc = _write_dense_folder(a, synth, W, H, nviews)
+    shutil.copytree(a, b)
+    r = subprocess.run([APD_BIN, str(a), "0", "--seed", str(seed), "--iters", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "All done" in r.stdout, r.stdout[-2000:]
+    assert not (a / "APD" / "00000000" / "depths.dmb").exists()
+    xyz, bgr = _read_ply(a / "APD" / "APD.ply")
+    assert len(xyz) > 0.5 * W * H, len(xyz)
+    assert (bgr[:, 0] == bgr[:, 1]).all() and (bgr[:, 1] == bgr[:, 2]).all()
+    # world points -> view 0 -> compare with the rendered ground-truth depth
+    R, t, K = sc.R[0].reshape(3, 3).astype(np.float64), sc.t[0].astype(np.float64), sc.K[0].reshape(3, 3).astype(np.float64)
+    cam = xyz.astype(np.float64) @ R.T + t
+    uv = cam @ K.T
+    u, v = uv[:, 0] / uv[:, 2], uv[:, 1] / uv[:, 2]
+    inside = (u >= 0) & (u <= W - 1) & (v >= 0) & (v <= H - 1)
+    gt = sc.gt_depth.numpy()[np.clip(np.rint(v[inside]).astype(int), 0, H - 1), np.clip(np.rint(u[inside]).astype(int), 0, W - 1)]
+    rel = np.abs(cam[inside, 2] - gt) / gt
+    assert inside.mean() > 0.5 and np.median(rel) < 0.01 and (rel < 0.05).mean() > 0.9
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mvs_pipeline.py"), str(b), "--seed", str(seed), "--iters", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert (a / "APD" / "APD.ply").read_bytes() == (b / "APD" / "APD.ply").read_bytes()

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--single-level", action="store_true")
+    ap.add_argument("--max-src", type=int, default=0, help="keep only the first N source views of pair.txt")
+    ap.add_argument("--no-fusion", action="store_true")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -36,6 +38,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     scene = pipeline.load_dense_folder(args.dense_folder, pkg.Camera)
+    if args.max_src > 0:
+        scene.pairs = [p[:args.max_src] for p in scene.pairs]
     if rank == 0:
         print("%d views, %dx%d, %d rank(s)" % (scene.num_views, scene.images[0].shape[1], scene.images[0].shape[0], world), flush=True)
     t0 = time.time()
@@ -43,6 +47,9 @@ def main():
                                     single_level=args.single_level, log=(print if rank == 0 else None))
     if rank == 0:
         pipeline.save_results(args.dense_folder, scene, results)
+        if not args.no_fusion:
+            n = pipeline.fuse(scene, results, os.path.join(args.dense_folder, "APD", "APD.ply"))
+            print("fused %d points into APD/APD.ply" % n, flush=True)
         print("PatchMatch passes done in %.1f s; maps written under %s" % (time.time() - t0, os.path.join(args.dense_folder, "APD")), flush=True)
     if world > 1:
         dist.barrier()
