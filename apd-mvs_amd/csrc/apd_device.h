@@ -684,25 +684,33 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     sum_s = 0.0f;
     sum_ss = 0.0f;
     sum_rs = 0.0f;
-    // software pipeline over the six rows: row i+1's gathers are in flight while row i is reduced
-    float a[2][kPatchN], b[2][kPatchN];
-    uint32_t t[2][kPatchN];
+    // software pipeline over the six rows: the gathers of the next APD_ROW_PREFETCH rows are in flight while row i
+    // is reduced
+#ifndef APD_ROW_PREFETCH
+#define APD_ROW_PREFETCH 1
+#endif
+    constexpr int kDepth = APD_ROW_PREFETCH, kBuf = kDepth + 1;
+    float a[kBuf][kPatchN], b[kBuf][kPatchN];
+    uint32_t t[kBuf][kPatchN];
     if (kQuad) {
-        const float xf = (float)(px - kPatchRadius);
-        quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq, pitch4,
-                                   wm1, hm1, a[0], b[0], t[0]);
+#pragma unroll
+        for (int r = 0; r < kDepth; ++r) {
+            const float xf = (float)(px + kPatchStep * r - kPatchRadius);
+            quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq, pitch4,
+                                       wm1, hm1, a[r], b[r], t[r]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
         float v[kPatchN];
         if (kQuad) {
-            if (i + 1 < kPatchN) {
-                const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
+            if (i + kDepth < kPatchN) {
+                const float xf = (float)(px + kPatchStep * (i + kDepth) - kPatchRadius);
                 quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq,
-                                           pitch4, wm1, hm1, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
+                                           pitch4, wm1, hm1, a[(i + kDepth) % kBuf], b[(i + kDepth) % kBuf], t[(i + kDepth) % kBuf]);
             }
             APD_STAGE();
-            quad_row_lerp(t[i & 1], a[i & 1], b[i & 1], v);
+            quad_row_lerp(t[i % kBuf], a[i % kBuf], b[i % kBuf], v);
         } else {
             const float xf = (float)(px + kPatchStep * i - kPatchRadius);
             const float bx = fmaf(H.h[0], xf, H.h[2]);
