@@ -60,17 +60,47 @@ __device__ __forceinline__ void full_frame_pixel(int &px, int &py)
     py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
 }
 
+constexpr int kFullTile = 16;
+constexpr int kFullLds = kFullTile + 2 * kPatchRadius;  // 26
+constexpr int kFullPitch = kFullLds + 1;                // 27
+
+// Stages the workgroup's 16x16 reference tile + 5 px halo (clamp-to-edge) and returns this lane's patch accessor; the 36
+// texels stay in LDS, only their two moments live in registers.  Every thread of the block must call it.
+__device__ __forceinline__ RefPatchLds<kFullPitch> stage_full_frame_ref(const FrameArgs &fa, float *tile, int px, int py)
+{
+    const int x0 = blockIdx.x * kFullTile - kPatchRadius, y0 = blockIdx.y * kFullTile - kPatchRadius;
+    for (int idx = threadIdx.x; idx < kFullLds * kFullLds; idx += 256) {
+        const int r = idx / kFullLds, c = idx - r * kFullLds;
+        tile[r * kFullPitch + c] = fetch_texel(fa.ref_img, fa.W, fa.H, x0 + c, y0 + r);
+    }
+    __syncthreads();
+    RefPatchLds<kFullPitch> rp;
+    rp.base = &tile[(py - y0 - kPatchRadius) * kFullPitch + (px - x0 - kPatchRadius)];
+    RefPatch tmp;
+#pragma unroll
+    for (int i = 0; i < kPatchN; ++i) {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            tmp.v[i * kPatchN + j] = rp.at(i, j);
+        }
+    }
+    ref_patch_finish(tmp);
+    rp.mean = tmp.mean;
+    rp.var = tmp.var;
+    return rp;
+}
+
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
 {
+    __shared__ float tile[kFullLds * kFullPitch];
     int px, py;
     full_frame_pixel(px, py);
+    const RefPatchLds<kFullPitch> rp = stage_full_frame_ref(fa, tile, px, py);
     if (px >= fa.W || py >= fa.H) {
         return;
     }
     const int center = py * fa.W + px;
-    RefPatch rp;
-    ref_patch_from_global(rp, fa.ref_img, fa.W, fa.H, px, py);
     if (fa.state == APD_FIRST_INIT) {
         Rng rng = rng_load(fa.rng, center);
         const float4 pl = random_plane(fa, px, py, rng);
@@ -441,8 +471,8 @@ __global__ __launch_bounds__(256) void k1213_filter_strong(FrameArgs fa, int col
 // Weighted cost of one depth sample along the pixel's ray over the selected views.
 //   kLocalRefine == false: sum_sel (ncc + gf*geom) * w           (:2070-2080, :2031-2035)
 //   kLocalRefine == true : sum_sel ncc*w (+ gf*geom*w)            (:2217-2220)
-template <bool kLocalRefine, bool kQuad>
-__device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, const RefPatch &rp, int px, int py, const float4 origin,
+template <bool kLocalRefine, bool kQuad, typename Ref>
+__device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, const Ref &rp, int px, int py, const float4 origin,
                                                        float depth, uint32_t sel, const ViewWeights<32> &vw)
 {
     float4 pl = origin;
@@ -498,8 +528,10 @@ __device__ __forceinline__ int baseline_and_weight(const FrameArgs &fa, uint32_t
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
 {
+    __shared__ float tile[kFullLds * kFullPitch];
     int px, py;
     full_frame_pixel(px, py);
+    const RefPatchLds<kFullPitch> rp = stage_full_frame_ref(fa, tile, px, py);
     if (px >= fa.W || py >= fa.H) {
         return;
     }
@@ -528,8 +560,6 @@ __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
     // cost_now of :2022-2051 is computed by the reference but never used by K14's classification
     base_line /= (float)valid;
     const float disp = fa.K[0] * base_line / origin_depth;
-    RefPatch rp;
-    ref_patch_from_global(rp, fa.ref_img, W, H, px, py);
     constexpr int RADIUS = 30, NP = 2 * RADIUS + 1;
     float pc[NP];
 #pragma unroll 1
@@ -579,8 +609,10 @@ __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
 {
+    __shared__ float tile[kFullLds * kFullPitch];
     int px, py;
     full_frame_pixel(px, py);
+    const RefPatchLds<kFullPitch> rp = stage_full_frame_ref(fa, tile, px, py);
     if (px >= fa.W || py >= fa.H) {
         return;
     }
@@ -601,8 +633,6 @@ __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
     }
     base_line /= (float)valid;
     const float disp = fa.K[0] * base_line / origin_depth;
-    RefPatch rp;
-    ref_patch_from_global(rp, fa.ref_img, W, H, px, py);
     const int radius = 5;
     float cost_now = 0.0f;
     float min_cost = 2.0f;
