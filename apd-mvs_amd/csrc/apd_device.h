@@ -413,22 +413,9 @@ typedef const __attribute__((address_space(1))) float *global_f32_ptr;
 
 // Same fetch from the texel-quad image: one dword gather instead of four.  Bit-identical to
 // sample_bilinear on 8-bit data (the taps are the same floats, the lerp is the same three fmaf).
-// Index math: floor -> v_med3_f32 clamp to [-1, W-1] -> cvt; a NaN/Inf coordinate gives a NaN weight,
-// so the sample is NaN whatever texel is read and the clamp only has to keep the address in range
-// (v_med3_f32 returns min3 of its inputs when one is NaN, i.e. -1).
-// Split in two so a caller can put several gathers in flight before consuming the first one.
-__device__ __forceinline__ unsigned quad_offset(unsigned pitch4, float wm1f, float hm1f, float sx, float sy, float &a, float &b)
-{
-    const float fx = floorf(sx), fy = floorf(sy);
-    a = sx - fx;
-    b = sy - fy;
-    const int qx = (int)__builtin_amdgcn_fmed3f(fx, -1.0f, wm1f);
-    const int qy = (int)__builtin_amdgcn_fmed3f(fy, -1.0f, hm1f);
-    // entry (qx, qy) lives at (qy + 1) * pitch + (qx + 1): byte offset = qy*4*pitch + 4*(pitch+1) + 4*qx >= 0
-    const int row4 = __mul24(qy, (int)pitch4) + (int)(pitch4 + 4u);
-    return (unsigned)((qx << 2) + row4);
-}
-
+// A NaN/Inf coordinate gives a NaN weight, so the sample is NaN whatever texel is read and the index clamp only
+// has to keep the address in range.  Fetch and interpolation are separate so a caller can put several gathers
+// in flight before consuming the first one (quad_row_issue / quad_row_lerp, subpatch_cost_quad).
 __device__ __forceinline__ uint32_t quad_fetch(global_u32_ptr quad, unsigned off)
 {
     return *(global_u32_ptr)((const __attribute__((address_space(1))) char *)quad + off);
@@ -471,13 +458,6 @@ __device__ __forceinline__ unsigned quad_byte_offset(int qx, int qy, int pitch4,
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(pitch4), "v"(origin));
     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(qx), "v"(row));
     return (unsigned)off;
-}
-
-__device__ __forceinline__ float sample_quad(global_u32_ptr quad, unsigned pitch, float wm1f, float hm1f, float sx, float sy)
-{
-    float a, b;
-    const unsigned off = quad_offset(4u * pitch, wm1f, hm1f, sx, sy, a, b);
-    return quad_lerp(quad_fetch(quad, off), a, b);
 }
 
 // ------------------------------------------------------------------------------------------------
