@@ -6,6 +6,8 @@
 
 #include <float.h>
 
+#include <type_traits>
+
 namespace apd {
 
 // ------------------------------------------------------------------------------------------------
@@ -442,7 +444,34 @@ struct WeakLds {
     uint32_t ref[8][kSubN][64];
     float mean[8][64];
     float var[8][64];
+    uint32_t centre[kPatchN * kPatchN / 4][64];  // texel-quad mode: the pixel's own 36 reference texels as bytes
 };
+
+// The pixel's own 6x6 reference patch kept as bytes in LDS (texel-quad mode: every texel is an integer 0..255):
+// frees 36 VGPRs per lane in the register-hungry weak kernel.  Same interface as RefPatch / RefPatchLds.
+struct RefPatchBytes {
+    const uint32_t *base;  // &lds.centre[0][lane]
+    float mean, var;
+    __device__ __forceinline__ float at(int i, int j) const
+    {
+        const int idx = i * kPatchN + j;
+        return (float)((base[(idx >> 2) * 64] >> (8 * (idx & 3))) & 0xFFu);
+    }
+};
+
+__device__ __forceinline__ RefPatchBytes ref_patch_to_lds(const RefPatch &rp, WeakLds &lds, int lane)
+{
+#pragma unroll
+    for (int w = 0; w < kPatchN * kPatchN / 4; ++w) {
+        lds.centre[w][lane] = (uint32_t)rp.v[4 * w] | ((uint32_t)rp.v[4 * w + 1] << 8) | ((uint32_t)rp.v[4 * w + 2] << 16) |
+                              ((uint32_t)rp.v[4 * w + 3] << 24);
+    }
+    RefPatchBytes out;
+    out.base = &lds.centre[0][lane];
+    out.mean = rp.mean;
+    out.var = rp.var;
+    return out;
+}
 
 template <bool kQuad>
 __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, const short2 *nb, WeakLds &lds, int lane)
@@ -480,8 +509,8 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
     }
 }
 
-template <bool kQuad>
-__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const RefPatch &rp, const WeakLds &lds,
+template <bool kQuad, typename Ref>
+__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLds &lds,
                                               int lane, int px, int py, const float4 pl)
 {
     float qx, qy, qz;
@@ -587,8 +616,15 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
     const int nsrc = fa.num_src;
     const short2 *nb = &fa.neighbours[(size_t)fa.neighbours_map[center] * APD_NEIGHBOUR_NUM];
     weak_prepare_neighbours<kQuad>(fa, nb, lds, lane);
-    RefPatch rp;
-    ref_patch_from_global(rp, fa.ref_img, W, fa.H, px, py);
+    RefPatch rp_regs;
+    ref_patch_from_global(rp_regs, fa.ref_img, W, fa.H, px, py);
+    // texel-quad mode: the 36 texels move to LDS as bytes; otherwise (float images) they stay in registers
+    typename std::conditional<kQuad, RefPatchBytes, RefPatch>::type rp;
+    if constexpr (kQuad) {
+        rp = ref_patch_to_lds(rp_regs, lds, lane);
+    } else {
+        rp = rp_regs;
+    }
     Rng rng = rng_load(fa.rng, center);
 
     float cost_array[9][NMAX];
