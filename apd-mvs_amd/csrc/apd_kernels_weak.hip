@@ -605,6 +605,12 @@ template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, const int *__restrict__ count)
 {
     __shared__ WeakLds lds;
+#ifdef APD_EXPERIMENT_K910_LDS_PAD  // timing experiment only: KiB of unused LDS per wave to cap the waves per CU
+    __shared__ char lds_pad[APD_EXPERIMENT_K910_LDS_PAD * 1024];
+    if (blockIdx.x == 0x7fffffff) {
+        lds_pad[threadIdx.x] = 1;
+    }
+#endif
     const int lane = threadIdx.x;
     const int gid = blockIdx.x * 64 + lane;
     if (gid >= *count) {
