@@ -2,7 +2,8 @@
 """bench.py -- Mpix*iterations/s of the PatchMatch sweep (BASELINE.json metric) on 1..8 MI355X.
 
 One "step" = one iteration of the loop body APD.cu:2443-2457 (K6 black + K7 red strong update,
-K8 fit-plane, K9/K10 weak update when WEAK pixels exist) over one reference view.  N=1 workload =
+K8 fit-plane, K9/K10 weak update when WEAK pixels exist) over one reference view.  The K timed steps are iterations
+0..K-1 of a freshly initialised pass (the warm-up iterations run first, then the state is reset with the same seed).  N=1 workload =
 BASELINE.json configs[1]: ETH3D-office-shaped stand-in, 6200x4130, 8 source views (datasets are not
 in the image: SURVEY.md 8d synthetic generator).  With --gpus N each rank sweeps its own reference
 view (views shard, no collective in the data path: weak scaling) and the final depth/normal maps are
@@ -83,7 +84,7 @@ def main():
     # every rank owns a different reference view of the same camera ring
     sc = synth.make_scene(W, H, N, seed=0, ref_view=rank, device=dev, textureless=0.2 if apd_mode else 0.0)
     cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
-    total_iters = args.warmup + args.steps
+    total_iters = max(args.warmup, args.steps)
     dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
     weak_fraction = 0.0
     if not apd_mode:
@@ -109,21 +110,31 @@ def main():
                                     ransac_threshold=0.01 - 0.00125 * 3, seed=args.seed + 1)
         h = pkg.Handle(W, H, params, device=dev.index)
         h.upload_views(cams, sc.images)
-        h.upload_prior(planes, views, weak)
-        weak_fraction = h.weak_count / float(W * H)
-        del planes, weak, views
+        prior = (planes, views, weak)
     del sc.images[:]
     torch.cuda.empty_cache()
-    # everything before the loop of APD.cu:2443 (not timed): K1..K5
-    h.run_kernel(pkg.K1)
-    h.run_kernel(pkg.K2)
-    if apd_mode and h.weak_count > 0:
-        h.run_kernel(pkg.K3)
-        h.run_kernel(pkg.K4)
-    h.run_kernel(pkg.K5)
-    # warmup iterations
+
+    def init_pass():
+        """Everything before the loop of APD.cu:2443 (not timed): prior state, K1..K5."""
+        if apd_mode:
+            h.upload_prior(*prior)
+        h.run_kernel(pkg.K1)
+        h.run_kernel(pkg.K2)
+        if apd_mode and h.weak_count > 0:
+            h.run_kernel(pkg.K3)
+            h.run_kernel(pkg.K4)
+        h.run_kernel(pkg.K5)
+
+    init_pass()
+    if apd_mode:
+        weak_fraction = h.weak_count / float(W * H)
+    # Warm-up: W iterations of the same sweep (clocks, caches, code objects).  Then the state is re-initialised with the
+    # same seed (K1 + K5 again, untimed) so that the timed region is exactly what the config names: the first K
+    # iterations of a pass, INCLUDING iteration 0, whose random planes scatter the gathers over the whole source images
+    # and which costs about twice a later iteration.
     if args.warmup > 0:
         h.run_sweeps(0, args.warmup)
+        init_pass()
     h.profile_enable(True)
     h.profile_reset()
 
@@ -135,17 +146,22 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    h.run_sweeps(args.warmup, args.steps, sync=False)
+    h.run_sweeps(0, 1, sync=False)
     h.synchronize()
+    t_first = time.perf_counter()
+    if args.steps > 1:
+        h.run_sweeps(1, args.steps - 1, sync=False)
+        h.synchronize()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    first_iter_s = t_first - t0
     if distributed:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, first_iter_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, first_iter_s = float(tt[0].item()), float(tt[1].item())
     prof = h.profile()
     h.profile_enable(False)
 
@@ -227,6 +243,10 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "weak_path": weak_path,
+            "iterations": {"first_ms": round(first_iter_s * 1e3, 3),
+                           "later_ms_per_step": round((elapsed - first_iter_s) / max(args.steps - 1, 1) * 1e3, 3) if args.steps > 1 else None,
+                           "later_value": round(world * mpix * (args.steps - 1) / (elapsed - first_iter_s), 4) if args.steps > 1 else None,
+                           "note": "timed region = iterations 0..K-1 of a freshly initialised pass; iteration 0 starts from random planes"},
             "kernel_ms_timed_region": kernel_ms,
             "post_loop_ms": round(post_ms, 1),
             "allgather_ms": None if allgather_ms is None else round(allgather_ms, 3),
