@@ -18,7 +18,7 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
 hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
 hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s);
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s);
-hipError_t launch_pack_quads(const float *img, int W, int H, uint32_t *quad, hipStream_t s);
+hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipStream_t s);
 }  // namespace apd
 
 using apd::FrameArgs;
@@ -58,7 +58,7 @@ struct apd_context {
     // device memory
     std::vector<float *> images;
     std::vector<float *> depths;
-    std::vector<uint32_t *> quads;
+    std::vector<apd::quad_t *> quads;
     int *flag_dev = nullptr;
     bool use_quads = false;
     ViewConst *views_dev = nullptr;
@@ -268,7 +268,7 @@ int apd_destroy(apd_handle c)
     for (float *p : c->depths) {
         hipFree(p);
     }
-    for (uint32_t *p : c->quads) {
+    for (apd::quad_t *p : c->quads) {
         hipFree(p);
     }
     hipFree(c->flag_dev);
@@ -333,7 +333,7 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     for (float *p : c->depths) {
         hipFree(p);
     }
-    for (uint32_t *p : c->quads) {
+    for (apd::quad_t *p : c->quads) {
         hipFree(p);
     }
     c->images.assign(num_images, nullptr);
@@ -370,7 +370,7 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     if (c->use_quads) {
         const size_t qn = (size_t)(c->W + 1) * (c->H + 1);
         for (int i = 1; i < num_images; ++i) {
-            HIP_TRY(hipMalloc(&c->quads[i], qn * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&c->quads[i], qn * sizeof(apd::quad_t)));
             hipError_t e = apd::launch_pack_quads(c->images[i], c->W, c->H, c->quads[i], c->stream);
             if (e != hipSuccess) {
                 return fail(APD_ERR_HIP, "k_pack_quads failed: %s", hipGetErrorString(e));

@@ -17,6 +17,21 @@ namespace apd {
 // data model
 // ------------------------------------------------------------------------------------------------
 
+// One texel-quad entry = everything one bilinear fetch needs, gathered with one load.
+//   APD_QUAD_F16 (8 B): four binary16 values {t00, t10 - t00} {t01, t11 - t01}.  Integers up to 255 and their
+//     differences are exact in binary16 and v_fma_mix_f32 widens them inside the FMA, so the two horizontal
+//     lerps cost one instruction each (no byte -> float conversions, no subtractions).
+//   otherwise (4 B): the four taps as bytes {t00, t10, t01, t11}.
+// Both give bit-identical samples (same taps, same three fmaf as the float sampler).
+#ifdef APD_QUAD_F16
+typedef uint32_t quad_t __attribute__((ext_vector_type(2)));
+constexpr int kQuadShift = 3;
+#else
+typedef uint32_t quad_t;
+constexpr int kQuadShift = 2;
+#endif
+constexpr unsigned kQuadBytes = 1u << kQuadShift;
+
 // Per source view constants.  Rr/tr are the plane-independent part of ComputeHomography
 // (APD.cu:305-331) hoisted to the host once per (reference, source) pair; the kernels read them
 // through wave-uniform (scalar) loads.
@@ -32,9 +47,9 @@ struct ViewConst {
     const float *img;    // W*H floats
     const float *depth;  // W*H floats or nullptr
     // Texel-quad image (only when every pixel of every view is an integer 0..255, i.e. 8-bit input at
-    // scale 1): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], packs the four clamped taps
-    // {I(qx,qy), I(qx+1,qy), I(qx,qy+1), I(qx+1,qy+1)} of one bilinear fetch into one dword.
-    const uint32_t *quad;  // (H+1)*(W+1) dwords or nullptr
+    // scale 1): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], holds the four clamped taps
+    // {I(qx,qy), I(qx+1,qy), I(qx,qy+1), I(qx+1,qy+1)} of one bilinear fetch (quad_t below).
+    const quad_t *quad;  // (H+1)*(W+1) entries or nullptr
 };
 
 struct FrameArgs {
@@ -408,20 +423,36 @@ __device__ __forceinline__ float sample_bilinear(Ptr img, int W, int H, float sx
 
 // Pointers into HBM as the compiler should see them: global address space (a pointer loaded from a
 // struct would otherwise be "generic" and cost flat_load + 64-bit address arithmetic per gather).
-typedef const __attribute__((address_space(1))) uint32_t *global_u32_ptr;
+typedef const __attribute__((address_space(1))) quad_t *global_quad_ptr;
 typedef const __attribute__((address_space(1))) float *global_f32_ptr;
 
-// Same fetch from the texel-quad image: one dword gather instead of four.  Bit-identical to
+// Same fetch from the texel-quad image: one gather instead of four.  Bit-identical to
 // sample_bilinear on 8-bit data (the taps are the same floats, the lerp is the same three fmaf).
 // A NaN/Inf coordinate gives a NaN weight, so the sample is NaN whatever texel is read and the index clamp only
 // has to keep the address in range.  Fetch and interpolation are separate so a caller can put several gathers
 // in flight before consuming the first one (quad_row_issue / quad_row_lerp, subpatch_cost_quad).
-__device__ __forceinline__ uint32_t quad_fetch(global_u32_ptr quad, unsigned off)
+__device__ __forceinline__ quad_t quad_fetch(global_quad_ptr quad, unsigned off)
 {
-    return *(global_u32_ptr)((const __attribute__((address_space(1))) char *)quad + off);
+    return *(global_quad_ptr)((const __attribute__((address_space(1))) char *)quad + off);
 }
 
-__device__ __forceinline__ float quad_lerp(uint32_t t, float a, float b)
+#ifdef APD_QUAD_F16
+// fmaf(a, (float)hi16(p), (float)lo16(p)) in one instruction: p = {binary16 base, binary16 delta}
+__device__ __forceinline__ float lerp_f16_pair(float a, uint32_t p)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(p));
+    return r;
+}
+
+__device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
+{
+    const float top = lerp_f16_pair(a, t.x);
+    const float bot = lerp_f16_pair(a, t.y);
+    return fmaf(b, bot - top, top);
+}
+#else
+__device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
 {
     const float t00 = (float)(t & 0xFFu), t10 = (float)((t >> 8) & 0xFFu);
     const float t01 = (float)((t >> 16) & 0xFFu), t11 = (float)(t >> 24);
@@ -429,6 +460,7 @@ __device__ __forceinline__ float quad_lerp(uint32_t t, float a, float b)
     const float bot = fmaf(a, t11 - t01, t01);
     return fmaf(b, bot - top, top);
 }
+#endif
 
 // Bilinear tap position for the texel-quad image, three VALU instructions per axis:
 //   weight  = v_fract_f32(s)        == s - floor(s) for every s >= 0; for s < 0 it can differ in the last bit
@@ -451,12 +483,13 @@ __device__ __forceinline__ int med3_i32(int x, int lo, int hi)
     return r;
 }
 
-// byte offset of quad entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1]: qy*pitch4 + (pitch4 + 4) + 4*qx, two instructions
-__device__ __forceinline__ unsigned quad_byte_offset(int qx, int qy, int pitch4, int origin)
+// byte offset of quad entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1]: qy*pitch + (pitch + entry) + entry*qx with
+// pitch = (W+1)*entry bytes, two instructions
+__device__ __forceinline__ unsigned quad_byte_offset(int qx, int qy, int pitch, int origin)
 {
     int row, off;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(pitch4), "v"(origin));
-    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(qx), "v"(row));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(pitch), "v"(origin));
+    asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(off) : "v"(qx), "v"(row), "n"(kQuadShift));
     return (unsigned)off;
 }
 
@@ -528,8 +561,8 @@ __device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float 
 // Sample positions of one patch row (fixed x, six y) -> bilinear weights + texel-quad gathers in flight.
 template <bool kFastRecip>
 __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN],
-                                               global_u32_ptr srcq, unsigned pitch4, int wm1, int hm1,
-                                               float (&a)[kPatchN], float (&b)[kPatchN], uint32_t (&t)[kPatchN])
+                                               global_quad_ptr srcq, unsigned pitch, int wm1, int hm1,
+                                               float (&a)[kPatchN], float (&b)[kPatchN], quad_t (&t)[kPatchN])
 {
     float z[kPatchN], X[kPatchN], Y[kPatchN], r[kPatchN];
 #pragma unroll
@@ -584,7 +617,7 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = (int)quad_byte_offset(qx[j], qy[j], (int)pitch4, (int)(pitch4 + 4u));
+        qx[j] = (int)quad_byte_offset(qx[j], qy[j], (int)pitch, (int)(pitch + kQuadBytes));
     }
     APD_STAGE();
 #ifdef APD_EXPERIMENT_QUAD_SAME_ADDR  // timing experiment only (wrong results): the 4 lanes of a quad gather one address
@@ -597,14 +630,19 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
 #ifdef APD_EXPERIMENT_ADDR_ZERO  // timing experiment only: every gather hits the same L1 line
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = qx[j] & 0x7c;
+        qx[j] = qx[j] & (0x80 - (int)kQuadBytes);
     }
     APD_STAGE();
 #endif
 #ifdef APD_EXPERIMENT_NO_LOADS  // timing experiment only: no gathers at all
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        t[j] = (uint32_t)qx[j] * 2654435761u;
+        const uint32_t fake = (uint32_t)qx[j] * 2654435761u;
+#ifdef APD_QUAD_F16
+        t[j] = quad_t{fake & 0x3fff3fffu, (fake >> 1) & 0x3fff3fffu};
+#else
+        t[j] = fake;
+#endif
     }
     return;
 #endif
@@ -615,10 +653,18 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
 }
 
 // Gathered quads + weights of one row -> six bilinear values (same three fmaf per sample as quad_lerp).
-__device__ __forceinline__ void quad_row_lerp(const uint32_t (&t)[kPatchN], const float (&a)[kPatchN], const float (&b)[kPatchN],
+__device__ __forceinline__ void quad_row_lerp(const quad_t (&t)[kPatchN], const float (&a)[kPatchN], const float (&b)[kPatchN],
                                               float (&v)[kPatchN])
 {
-    float t00[kPatchN], t01[kPatchN], d0[kPatchN], d1[kPatchN];
+    float t00[kPatchN], t01[kPatchN];
+#ifdef APD_QUAD_F16
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        t00[j] = lerp_f16_pair(a[j], t[j].x);
+        t01[j] = lerp_f16_pair(a[j], t[j].y);
+    }
+#else
+    float d0[kPatchN], d1[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
         t00[j] = (float)(t[j] & 0xFFu);
@@ -632,6 +678,7 @@ __device__ __forceinline__ void quad_row_lerp(const uint32_t (&t)[kPatchN], cons
         t00[j] = fmaf(a[j], d0[j], t00[j]);
         t01[j] = fmaf(a[j], d1[j], t01[j]);
     }
+#endif
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
@@ -648,13 +695,23 @@ __device__ __forceinline__ void quad_row_lerp(const uint32_t (&t)[kPatchN], cons
 // reference's order (row partial sums, then total).  kFastRecip: every denominator is known to be in the
 // range where recip_fast is the correctly rounded reciprocal.
 template <bool kQuad, bool kFastRecip, typename Ref>
-__device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H,
-                                                  int px, int py, float &sum_s, float &sum_ss, float &sum_rs)
+__device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H_in,
+                                                  int px_in, int py_in, float &sum_s, float &sum_ss, float &sum_rs)
 {
+#ifdef APD_EXPERIMENT_TRANSPOSE  // timing experiment only (summation order differs from the contract): batches of fixed y, six x
+    Homography H;
+    H.h[0] = H_in.h[1], H.h[1] = H_in.h[0], H.h[2] = H_in.h[2];
+    H.h[3] = H_in.h[4], H.h[4] = H_in.h[3], H.h[5] = H_in.h[5];
+    H.h[6] = H_in.h[7], H.h[7] = H_in.h[6], H.h[8] = H_in.h[8];
+    const int px = py_in, py = px_in;
+#else
+    const Homography &H = H_in;
+    const int px = px_in, py = py_in;
+#endif
     const global_f32_ptr src = (global_f32_ptr)vc.img;
-    const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
+    const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
     const int W = fa.W, Hh = fa.H;
-    const unsigned pitch4 = 4u * (unsigned)(W + 1);
+    const unsigned qpitch = kQuadBytes * (unsigned)(W + 1);
     const int wm1 = W - 1, hm1 = Hh - 1;
     float yf[kPatchN];
 #pragma unroll
@@ -671,12 +728,12 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
 #endif
     constexpr int kDepth = APD_ROW_PREFETCH, kBuf = kDepth + 1;
     float a[kBuf][kPatchN], b[kBuf][kPatchN];
-    uint32_t t[kBuf][kPatchN];
+    quad_t t[kBuf][kPatchN];
     if (kQuad) {
 #pragma unroll
         for (int r = 0; r < kDepth; ++r) {
             const float xf = (float)(px + kPatchStep * r - kPatchRadius);
-            quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq, pitch4,
+            quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq, qpitch,
                                        wm1, hm1, a[r], b[r], t[r]);
         }
     }
@@ -687,7 +744,7 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
             if (i + kDepth < kPatchN) {
                 const float xf = (float)(px + kPatchStep * (i + kDepth) - kPatchRadius);
                 quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq,
-                                           pitch4, wm1, hm1, a[(i + kDepth) % kBuf], b[(i + kDepth) % kBuf], t[(i + kDepth) % kBuf]);
+                                           qpitch, wm1, hm1, a[(i + kDepth) % kBuf], b[(i + kDepth) % kBuf], t[(i + kDepth) % kBuf]);
             }
             APD_STAGE();
             quad_row_lerp(t[i % kBuf], a[i % kBuf], b[i % kBuf], v);
@@ -791,7 +848,7 @@ constexpr int kSubStep = 5;
 
 // Nine warped samples in lock step (same stages as quad_row_issue), reduced in the reference's order.
 // ref_rows[i] packs the three reference texels of x offset i (y offset j in byte j).
-__device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_u32_ptr srcq, unsigned pitch4, int wm1, int hm1,
+__device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_quad_ptr srcq, unsigned qpitch, int wm1, int hm1,
                                                     int cx, int cy, const uint32_t (&ref_rows)[kSubN], float mean_r, float var_r)
 {
     constexpr int N = kSubN * kSubN;
@@ -850,17 +907,17 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
     APD_STAGE();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)pitch4, (int)(pitch4 + 4u));
+        qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)qpitch, (int)(qpitch + kQuadBytes));
     }
     APD_STAGE();
 #ifdef APD_EXPERIMENT_SUB_ADDR_ZERO  // timing experiment only: every sub-patch gather hits the same L1 line
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        qx[k] = qx[k] & 0x7c;
+        qx[k] = qx[k] & (0x80 - (int)kQuadBytes);
     }
     APD_STAGE();
 #endif
-    uint32_t t[N];
+    quad_t t[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         t[k] = quad_fetch(srcq, (unsigned)qx[k]);

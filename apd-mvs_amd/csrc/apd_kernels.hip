@@ -51,26 +51,31 @@ __global__ __launch_bounds__(64) void k1_init_random_states(FrameArgs fa)
 // K5  RandomInitialization (APD.cu:806-835) with the initial costs of :616-693
 // ------------------------------------------------------------------------------------------------
 
-// Full-frame kernels (K5, K14, K15): a 256-lane workgroup covers a 16x16 tile and each wave64 an 8x8 block of it,
-// so the patches gathered by one wave overlap in both directions (a 32x2 strip would share rows only).
+// Full-frame kernels (K5, K14, K15): a wave64 covers a (64 / APD_FF_ROWS) x APD_FF_ROWS block of pixels, four waves a
+// workgroup tile (same trade-off as APD_CB_ROWS in apd_sweep.h).
+#ifndef APD_FF_ROWS
+#define APD_FF_ROWS 8
+#endif
+constexpr int kFfWaveH = APD_FF_ROWS, kFfWaveW = 64 / kFfWaveH;
+constexpr int kFfWavesX = (kFfWaveH == 8) ? 2 : 1, kFfWavesY = 4 / kFfWavesX;
+constexpr int kFullTileW = kFfWaveW * kFfWavesX, kFullTileH = kFfWaveH * kFfWavesY;  // 16x16 (rows 8, 4) or 32x8 (rows 2)
+constexpr int kFullLdsW = kFullTileW + 2 * kPatchRadius, kFullLdsH = kFullTileH + 2 * kPatchRadius;
+constexpr int kFullPitch = kFullLdsW | 1;
+
 __device__ __forceinline__ void full_frame_pixel(int &px, int &py)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    px = blockIdx.x * kFullTileW + (wave % kFfWavesX) * kFfWaveW + lane % kFfWaveW;
+    py = blockIdx.y * kFullTileH + (wave / kFfWavesX) * kFfWaveH + lane / kFfWaveW;
 }
 
-constexpr int kFullTile = 16;
-constexpr int kFullLds = kFullTile + 2 * kPatchRadius;  // 26
-constexpr int kFullPitch = kFullLds + 1;                // 27
-
-// Stages the workgroup's 16x16 reference tile + 5 px halo (clamp-to-edge) and returns this lane's patch accessor; the 36
+// Stages the workgroup's reference tile + 5 px halo (clamp-to-edge) and returns this lane's patch accessor; the 36
 // texels stay in LDS, only their two moments live in registers.  Every thread of the block must call it.
 __device__ __forceinline__ RefPatchLds<kFullPitch> stage_full_frame_ref(const FrameArgs &fa, float *tile, int px, int py)
 {
-    const int x0 = blockIdx.x * kFullTile - kPatchRadius, y0 = blockIdx.y * kFullTile - kPatchRadius;
-    for (int idx = threadIdx.x; idx < kFullLds * kFullLds; idx += 256) {
-        const int r = idx / kFullLds, c = idx - r * kFullLds;
+    const int x0 = blockIdx.x * kFullTileW - kPatchRadius, y0 = blockIdx.y * kFullTileH - kPatchRadius;
+    for (int idx = threadIdx.x; idx < kFullLdsW * kFullLdsH; idx += 256) {
+        const int r = idx / kFullLdsW, c = idx - r * kFullLdsW;
         tile[r * kFullPitch + c] = fetch_texel(fa.ref_img, fa.W, fa.H, x0 + c, y0 + r);
     }
     __syncthreads();
@@ -93,7 +98,7 @@ __device__ __forceinline__ RefPatchLds<kFullPitch> stage_full_frame_ref(const Fr
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
 {
-    __shared__ float tile[kFullLds * kFullPitch];
+    __shared__ float tile[kFullLdsH * kFullPitch];
     int px, py;
     full_frame_pixel(px, py);
     const RefPatchLds<kFullPitch> rp = stage_full_frame_ref(fa, tile, px, py);
@@ -375,14 +380,15 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
         float tc = 0.0f;
 #pragma unroll 1
         for (int v = 0; v < nsrc; ++v) {
+            const uint32_t wv = vw.get(v);
+            if (h >= 9 && wv == 0) {
+                continue;  // a refinement hypothesis only ever uses the costs of the selected views (:876-880)
+            }
             const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
             if (h < 9) {
                 cost_array[h][v] = c;
             } else {
-                const uint32_t wv = vw.get(v);
-                if (wv > 0) {
-                    tc += (float)wv * c;
-                }
+                tc += (float)wv * c;
             }
         }
         if (h >= 9) {  // PlaneHypothesisRefinementStrong accept test (:881-888)
@@ -528,7 +534,7 @@ __device__ __forceinline__ int baseline_and_weight(const FrameArgs &fa, uint32_t
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
 {
-    __shared__ float tile[kFullLds * kFullPitch];
+    __shared__ float tile[kFullLdsH * kFullPitch];
     int px, py;
     full_frame_pixel(px, py);
     const RefPatchLds<kFullPitch> rp = stage_full_frame_ref(fa, tile, px, py);
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(256) void k14_depth_to_weak(FrameArgs fa)
 template <bool kQuad>
 __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
 {
-    __shared__ float tile[kFullLds * kFullPitch];
+    __shared__ float tile[kFullLdsH * kFullPitch];
     int px, py;
     full_frame_pixel(px, py);
     const RefPatchLds<kFullPitch> rp = stage_full_frame_ref(fa, tile, px, py);
@@ -675,16 +681,29 @@ __global__ __launch_bounds__(256) void k_check_u8(const float *__restrict__ img,
     }
 }
 
-__global__ __launch_bounds__(256) void k_pack_quads(const float *__restrict__ img, int W, int H, uint32_t *__restrict__ quad)
+// bits of the binary16 value of an integer |v| <= 2048 (exact)
+__device__ __forceinline__ uint32_t f16_bits(float v)
+{
+    const _Float16 h = (_Float16)v;
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+
+__global__ __launch_bounds__(256) void k_pack_quads(const float *__restrict__ img, int W, int H, quad_t *__restrict__ quad)
 {
     const int qx = blockIdx.x * 32 + (threadIdx.x & 31);  // 0..W  <-> image x = qx - 1
     const int qy = blockIdx.y * 8 + (threadIdx.x >> 5);   // 0..H
     if (qx > W || qy > H) {
         return;
     }
+#ifdef APD_QUAD_F16
+    const float t00 = fetch_texel(img, W, H, qx - 1, qy - 1), t10 = fetch_texel(img, W, H, qx, qy - 1);
+    const float t01 = fetch_texel(img, W, H, qx - 1, qy), t11 = fetch_texel(img, W, H, qx, qy);
+    quad[(size_t)qy * (W + 1) + qx] = quad_t{f16_bits(t00) | (f16_bits(t10 - t00) << 16), f16_bits(t01) | (f16_bits(t11 - t01) << 16)};
+#else
     const uint32_t t00 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy - 1), t10 = (uint32_t)fetch_texel(img, W, H, qx, qy - 1);
     const uint32_t t01 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy), t11 = (uint32_t)fetch_texel(img, W, H, qx, qy);
     quad[(size_t)qy * (W + 1) + qx] = t00 | (t10 << 8) | (t01 << 16) | (t11 << 24);
+#endif
 }
 
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s)
@@ -693,7 +712,7 @@ hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pack_quads(const float *img, int W, int H, uint32_t *quad, hipStream_t s)
+hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipStream_t s)
 {
     hipLaunchKernelGGL(k_pack_quads, dim3((W + 1 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, quad);
     return hipGetLastError();
@@ -703,7 +722,7 @@ hipError_t launch_pack_quads(const float *img, int W, int H, uint32_t *quad, hip
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
 
-static inline dim3 grid_16x16(const FrameArgs &fa) { return dim3((fa.W + 15) / 16, (fa.H + 15) / 16); }
+static inline dim3 grid_full_frame(const FrameArgs &fa) { return dim3((fa.W + kFullTileW - 1) / kFullTileW, (fa.H + kFullTileH - 1) / kFullTileH); }
 static inline int checkerboard_tiles(const FrameArgs &fa) { return ((fa.W + kTileW - 1) / kTileW) * ((fa.H + kTileH - 1) / kTileH); }
 
 template <int NMAX>
@@ -726,9 +745,9 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
     }
     case APD_K5_RANDOM_INITIALIZATION:
         if (fa.use_quads) {
-            hipLaunchKernelGGL(k5_random_initialization<true>, grid_16x16(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k5_random_initialization<true>, grid_full_frame(fa), dim3(256), 0, s, fa);
         } else {
-            hipLaunchKernelGGL(k5_random_initialization<false>, grid_16x16(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k5_random_initialization<false>, grid_full_frame(fa), dim3(256), 0, s, fa);
         }
         break;
     case APD_K6_BLACK_UPDATE_STRONG:
@@ -753,16 +772,16 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
         break;
     case APD_K14_DEPTH_TO_WEAK:
         if (fa.use_quads) {
-            hipLaunchKernelGGL(k14_depth_to_weak<true>, grid_16x16(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k14_depth_to_weak<true>, grid_full_frame(fa), dim3(256), 0, s, fa);
         } else {
-            hipLaunchKernelGGL(k14_depth_to_weak<false>, grid_16x16(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k14_depth_to_weak<false>, grid_full_frame(fa), dim3(256), 0, s, fa);
         }
         break;
     case APD_K15_LOCAL_REFINE:
         if (fa.use_quads) {
-            hipLaunchKernelGGL(k15_local_refine<true>, grid_16x16(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k15_local_refine<true>, grid_full_frame(fa), dim3(256), 0, s, fa);
         } else {
-            hipLaunchKernelGGL(k15_local_refine<false>, grid_16x16(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL(k15_local_refine<false>, grid_full_frame(fa), dim3(256), 0, s, fa);
         }
         break;
     default:

@@ -527,8 +527,8 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
 #else
     const float center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
 #endif
-    const global_u32_ptr srcq = (global_u32_ptr)vc.quad;
-    const unsigned pitch4 = 4u * (unsigned)(fa.W + 1);
+    const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
+    const unsigned qpitch = kQuadBytes * (unsigned)(fa.W + 1);
     const int wm1 = fa.W - 1, hm1 = fa.H - 1;
     float strong_cost = 0.0f;
     int strong_count = 0;
@@ -555,7 +555,7 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
         float c;
         if (kQuad && denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep))) {
             const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-            c = subpatch_cost_quad(H, srcq, pitch4, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+            c = subpatch_cost_quad(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
         } else {
             c = patch_cost_generic(fa, vc, H, nbx, nby, 5, 5);
         }
@@ -774,13 +774,18 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
 #pragma unroll 1
         for (int v = 0; v < nsrc; ++v) {
             const ViewConst &vc = fa.views[v];
+            if (vw.get(v) == 0) {
+                // the cost of an unselected view is never used (:966-972); in the re-score it is multiplied by a zero
+                // weight (:1503) and, being a finite value in [0, 2], adds exactly +0
+                continue;
+            }
             if (h == 15) {
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
                 tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
             } else {
                 const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
-                if (vw.get(v) > 0) {
+                {
                     if (fa.geom_consistency) {
                         tc += (float)vw.get(v) * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
                     } else {

@@ -24,10 +24,19 @@ __device__ __forceinline__ void sort_ascending(float *d, int n)  // APD.cu:3-12
 // checkerboard tiling shared by K6/K7, K9/K10, K12/K13
 // ------------------------------------------------------------------------------------------------
 
-constexpr int kTileW = 32, kTileH = 16, kHalo = kPatchRadius;
-constexpr int kLdsW = kTileW + 2 * kHalo;      // 42
-constexpr int kLdsH = kTileH + 2 * kHalo;      // 26
-constexpr int kLdsPitch = kLdsW + 1;           // 43: odd pitch spreads the column reads over banks
+// A wave64 owns the 64 same-colour pixels of a (128 / APD_CB_ROWS) x APD_CB_ROWS footprint; four waves make the
+// workgroup tile.  The footprint shape trades two things: a wide, flat footprint makes one wave-level gather touch
+// fewer 128-B lines of the row-major source image (the L1 looks lines up one per cycle), a square one keeps the
+// patch halo, i.e. the L1 working set, small.
+#ifndef APD_CB_ROWS
+#define APD_CB_ROWS 4
+#endif
+constexpr int kWaveH = APD_CB_ROWS, kWaveLanesX = 64 / kWaveH, kWaveW = 2 * kWaveLanesX;
+constexpr int kWavesX = (kWaveH == 8) ? 2 : 1, kWavesY = 4 / kWavesX;
+constexpr int kTileW = kWaveW * kWavesX, kTileH = kWaveH * kWavesY, kHalo = kPatchRadius;  // 32x16 (rows 8, 4) or 64x8 (rows 2)
+constexpr int kLdsW = kTileW + 2 * kHalo;
+constexpr int kLdsH = kTileH + 2 * kHalo;
+constexpr int kLdsPitch = kLdsW | 1;           // odd pitch spreads the column reads over banks
 
 struct TilePixel {
     int tx0, ty0;  // tile origin
@@ -35,7 +44,7 @@ struct TilePixel {
     int px, py;
 };
 
-// colour 0 = black ((x + y) even), 1 = red; wave w covers the 16x8 sub-tile (w&1, w>>1).
+// colour 0 = black ((x + y) even), 1 = red; wave w covers sub-tile (w % kWavesX, w / kWavesX).
 __device__ __forceinline__ TilePixel checkerboard_pixel(const FrameArgs &fa, int colour)
 {
     const int tiles_x = (fa.W + kTileW - 1) / kTileW;
@@ -45,8 +54,8 @@ __device__ __forceinline__ TilePixel checkerboard_pixel(const FrameArgs &fa, int
     t.ty0 = (tile / tiles_x) * kTileH;
     t.tx0 = (tile - (tile / tiles_x) * tiles_x) * kTileW;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    t.ly = (wave >> 1) * 8 + (lane >> 3);
-    t.lx = (wave & 1) * 16 + 2 * (lane & 7) + ((t.ly + colour) & 1);
+    t.ly = (wave / kWavesX) * kWaveH + lane / kWaveLanesX;
+    t.lx = (wave % kWavesX) * kWaveW + 2 * (lane % kWaveLanesX) + ((t.ly + colour) & 1);
     t.px = t.tx0 + t.lx;
     t.py = t.ty0 + t.ly;
     return t;

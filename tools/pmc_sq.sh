@@ -23,4 +23,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_R
   python tools/pmc_summary.py $OUT/g$i $OUT/g${i}_summary.csv > /dev/null
 done
 find $OUT -type f -size +1M -delete
-grep -h k67 $OUT/g*_summary.csv | cut -d, -f3-7 | sed 's/"//g' | cut -c1-160
+grep -h k67 $OUT/g*_summary.csv | python -c "
+import csv,sys
+for r in csv.reader(sys.stdin):
+    print('%-34s n=%s mean=%.4g  [%s]' % (r[1], r[2], float(r[3]), r[-1]))"

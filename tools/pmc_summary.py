@@ -25,7 +25,8 @@ def main():
                 meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"], r["SGPR_Count"])
         for (k, c), v in sorted(agg.items()):
             tail = v[2:] if len(v) > 2 else v  # drop the warm-up iteration's two launches (bench --warmup 1)
-            rows_out.append([k, c, len(v), sum(v) / len(v), min(v), max(v)] + list(meta[k]) + [sum(tail) / len(tail)])
+            rows_out.append([k, c, len(v), sum(v) / len(v), min(v), max(v)] + list(meta[k]) + [sum(tail) / len(tail)] +
+                            [" ".join("%.4g" % x for x in v[:16]) if "k67" in k or "k910" in k else ""])
     for path in sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)):
         agg = collections.defaultdict(list)
         with open(path) as f:
@@ -36,10 +37,11 @@ def main():
                 agg[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
         for k, v in sorted(agg.items()):
             tail = v[2:] if len(v) > 2 else v
-            rows_out.append([k, "duration_ns", len(v), sum(v) / len(v), min(v), max(v), "", "", "", "", "", "", sum(tail) / len(tail)])
+            rows_out.append([k, "duration_ns", len(v), sum(v) / len(v), min(v), max(v), "", "", "", "", "", "", sum(tail) / len(tail),
+                             " ".join("%.4g" % x for x in v[:16]) if "k67" in k or "k910" in k else ""])
     with open(dst, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "counter", "dispatches", "mean", "min", "max", "grid", "workgroup", "lds", "scratch", "vgpr", "sgpr", "mean_after_warmup"])
+        w.writerow(["kernel", "counter", "dispatches", "mean", "min", "max", "grid", "workgroup", "lds", "scratch", "vgpr", "sgpr", "mean_after_warmup", "per_dispatch"])
         w.writerows(rows_out)
     print("wrote", dst, len(rows_out), "rows")
 
