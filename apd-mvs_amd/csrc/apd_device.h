@@ -436,7 +436,6 @@ __device__ __forceinline__ quad_t quad_fetch(global_quad_ptr quad, unsigned off)
     return *(global_quad_ptr)((const __attribute__((address_space(1))) char *)quad + off);
 }
 
-#ifdef APD_QUAD_F16
 // fmaf(a, (float)hi16(p), (float)lo16(p)) in one instruction: p = {binary16 base, binary16 delta}
 __device__ __forceinline__ float lerp_f16_pair(float a, uint32_t p)
 {
@@ -445,6 +444,7 @@ __device__ __forceinline__ float lerp_f16_pair(float a, uint32_t p)
     return r;
 }
 
+#ifdef APD_QUAD_F16
 __device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
 {
     const float top = lerp_f16_pair(a, t.x);

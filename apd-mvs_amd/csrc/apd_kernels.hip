@@ -8,6 +8,7 @@
 #include "apd_sweep.h"
 
 #include <float.h>
+#include <stdlib.h>
 #include <rocrand/rocrand_xorwow.h>
 
 namespace apd {
@@ -725,6 +726,22 @@ hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipSt
 static inline dim3 grid_full_frame(const FrameArgs &fa) { return dim3((fa.W + kFullTileW - 1) / kFullTileW, (fa.H + kFullTileH - 1) / kFullTileH); }
 static inline int checkerboard_tiles(const FrameArgs &fa) { return ((fa.W + kTileW - 1) / kTileW) * ((fa.H + kTileH - 1) / kTileH); }
 
+hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStream_t s);  // apd_kernels_k67w.hip
+
+// APD_K67_WINDOW=0 in the environment selects the kernel without the LDS source windows (A/B timing, same results)
+static bool k67_window_enabled()
+{
+#ifdef APD_QUAD_F16
+    return false;
+#else
+    static const bool on = [] {
+        const char *e = getenv("APD_K67_WINDOW");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+#endif
+}
+
 template <int NMAX>
 static void launch_k67(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
@@ -753,6 +770,9 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
     case APD_K6_BLACK_UPDATE_STRONG:
     case APD_K7_RED_UPDATE_STRONG: {
         const int colour = (kernel_id == APD_K6_BLACK_UPDATE_STRONG) ? 0 : 1;
+        if (fa.use_quads && k67_window_enabled()) {
+            return launch_k67_windowed(fa, colour, iter, s);
+        }
         if (fa.num_src <= 8) {
             launch_k67<8>(fa, colour, iter, s);
         } else if (fa.num_src <= 16) {
