@@ -250,6 +250,14 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
         float v[kPatchN];
+        // LDS returns in order: the reference texels of this row are requested before the window entries of the next
+        // one, so the reduction below only waits for reads that were issued a whole row of arithmetic ago
+        float ref[kPatchN];
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            ref[j] = rp.at(i, j);
+        }
+        APD_STAGE();
         if (i + 1 < kPatchN) {
             const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
             win_row_issue(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[(i + 1) & 1],
@@ -257,11 +265,6 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
         }
         APD_STAGE();
         win_row_lerp(t[i & 1], a[i & 1], b[i & 1], v);
-        float ref[kPatchN];
-#pragma unroll
-        for (int j = 0; j < kPatchN; ++j) {
-            ref[j] = rp.at(i, j);
-        }
         float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
 #pragma unroll
         for (int j = 0; j < kPatchN; ++j) {
