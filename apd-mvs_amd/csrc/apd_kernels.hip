@@ -728,17 +728,15 @@ static inline int checkerboard_tiles(const FrameArgs &fa) { return ((fa.W + kTil
 
 hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStream_t s);  // apd_kernels_k67w.hip
 
-// APD_K67_WINDOW=0 in the environment selects the kernel without the LDS source windows (A/B timing, same results)
+// APD_K67_WINDOW=0 in the environment selects the kernel without the LDS source windows (A/B timing and the
+// window-vs-global parity test; same results).  Read at every launch: a getenv per 25 ms kernel is free.
 static bool k67_window_enabled()
 {
 #ifdef APD_QUAD_F16
     return false;
 #else
-    static const bool on = [] {
-        const char *e = getenv("APD_K67_WINDOW");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+    const char *e = getenv("APD_K67_WINDOW");
+    return !(e && e[0] == '0');
 #endif
 }
 

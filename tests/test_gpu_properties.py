@@ -88,3 +88,29 @@ def test_red_black_independence(gpu_pkg, ob, synth):
     common.assert_state_equal(gpu_pkg, h, o, "416x304 one sweep", skip=("fit",))
     h.close()
     o.close()
+
+
+def test_window_and_global_kernels_agree(gpu_pkg, synth, monkeypatch):
+    """K6/K7 with per-wave LDS source windows (apd_kernels_k67w.hip, default) against the kernel that gathers every
+    sample from HBM (APD_K67_WINDOW=0): all state bit-identical after every iteration at a size where, from the second
+    iteration on, most NCCs read the windows (the oracle is too slow for this size)."""
+    W, H, N, iters = 1536, 1152, 5, 4
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("APD_K67_WINDOW", mode)
+        sc = synth.make_scene(W, H, N, seed=2, device="cuda", textureless=0.1)
+        cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+        p = gpu_pkg.default_params(num_images=N + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0,
+                                   state=gpu_pkg.FIRST_INIT, max_iterations=iters, seed=31)
+        h = gpu_pkg.Handle(W, H, p, device=0)
+        h.upload_views(cams, sc.images)
+        for k in (1, 2, 5):
+            h.run_kernel(k)
+        digests = []
+        for it in range(iters):
+            h.run_sweeps(it, 1)
+            digests.append(_digest([h.state(gpu_pkg.STATE_PLANES), h.state(gpu_pkg.STATE_COSTS), h.state(gpu_pkg.STATE_SELECTED_VIEWS),
+                                    h.state(gpu_pkg.STATE_VIEW_WEIGHT), h.state(gpu_pkg.STATE_RNG)]))
+        runs[mode] = digests
+        h.close()
+    assert runs["1"] == runs["0"]
