@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB_PATH = os.path.join(OUT_DIR, "libapd_mi355x.so")
-SOURCES = ["apd_kernels.hip", "apd_kernels_k67w.hip", "apd_kernels_weak.hip", "apd_capi.hip"]
-HEADERS = ["apd_device.h", "apd_sweep.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
+SOURCES = ["apd_kernels.hip", "apd_kernels_k67w.hip", "apd_kernels_k1415w.hip", "apd_kernels_weak.hip", "apd_capi.hip"]
+HEADERS = ["apd_device.h", "apd_sweep.h", "apd_window.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
@@ -48,7 +48,7 @@ def build_library(force=False, verbose=False, extra_flags=()):
         return r.stdout
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=4) as ex:
+        with ThreadPoolExecutor(max_workers=5) as ex:
             for out in ex.map(run, jobs):
                 if verbose and out.strip():
                     print(out)

@@ -740,6 +740,20 @@ static bool k67_window_enabled()
 #endif
 }
 
+hipError_t launch_k14_windowed(const FrameArgs &fa, hipStream_t s);  // apd_kernels_k1415w.hip
+hipError_t launch_k15_windowed(const FrameArgs &fa, hipStream_t s);
+
+// APD_K1415_WINDOW=0: K14/K15 without LDS source windows (same results)
+static bool k1415_window_enabled()
+{
+#ifdef APD_QUAD_F16
+    return false;
+#else
+    const char *e = getenv("APD_K1415_WINDOW");
+    return !(e && e[0] == '0');
+#endif
+}
+
 template <int NMAX>
 static void launch_k67(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
@@ -789,6 +803,9 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
                            (kernel_id == APD_K12_BLACK_FILTER) ? 0 : 1);
         break;
     case APD_K14_DEPTH_TO_WEAK:
+        if (fa.use_quads && k1415_window_enabled()) {
+            return launch_k14_windowed(fa, s);
+        }
         if (fa.use_quads) {
             hipLaunchKernelGGL(k14_depth_to_weak<true>, grid_full_frame(fa), dim3(256), 0, s, fa);
         } else {
@@ -796,6 +813,9 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
         }
         break;
     case APD_K15_LOCAL_REFINE:
+        if (fa.use_quads && k1415_window_enabled()) {
+            return launch_k15_windowed(fa, s);
+        }
         if (fa.use_quads) {
             hipLaunchKernelGGL(k15_local_refine<true>, grid_full_frame(fa), dim3(256), 0, s, fa);
         } else {

@@ -1,0 +1,397 @@
+// apd_kernels_k1415w.hip -- K14 DepthToWeak (APD.cu:1990-2144) and K15 LocalRefine (:2146-2232) with the source-image
+// gathers served from per-wave LDS windows (apd_window.h).
+//
+// Both kernels score depth samples along the pixel's ray, one pixel of disparity apart (61 for K14, 12 for K15),
+// against every selected view: under one view the patch slides along the epipolar line by about b_view / b_mean texels
+// per step.  The evaluation is therefore view-major (the reference's is sample-major, :2056 / :2196): per view, the
+// samples are walked in chunks, the wave stages one window around the projections of its 8x8 pixels at the middle
+// sample of the chunk, and every NCC whose 36 samples provably fall inside reads LDS with the four-instruction lerp;
+// anything else takes the global path.  The per-sample costs are accumulated over the views in view order, exactly as
+// the sample-major loop does, so the result is bit-identical.
+#include "apd_device.h"
+#include "apd_sweep.h"
+#include "apd_window.h"
+
+#ifndef APD_QUAD_F16
+
+namespace apd {
+
+constexpr int kFwTile = 16;                                // workgroup tile: 16x16 pixels, wave64 = 8x8
+constexpr int kFwLds = kFwTile + 2 * kPatchRadius;         // 26
+constexpr int kFwPitch = kFwLds + 1;                       // 27
+#ifndef APD_K14_WIN_H
+#define APD_K14_WIN_H 32  // rows of fetch positions: 8 + 2 * (patch radius 5 + 7 texels of slack)
+#endif
+constexpr int kK14WinH = APD_K14_WIN_H;
+#ifndef APD_K14_CHUNK
+#define APD_K14_CHUNK 8  // depth samples per staged window (K14 ms at 4096x3072, 8 views: 4: 144.7, 6: 138.8, 8: 135.6, 16: 140.6, 31: 161.1)
+#endif
+
+__device__ __forceinline__ void fw_pixel(int &px, int &py)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    px = blockIdx.x * kFwTile + (wave & 1) * 8 + (lane & 7);
+    py = blockIdx.y * kFwTile + (wave >> 1) * 8 + (lane >> 3);
+}
+
+// Stages the workgroup's reference tile + 5 px halo (clamp-to-edge); the 36 texels of a lane's patch stay in LDS.
+__device__ __forceinline__ RefPatchLds<kFwPitch> fw_stage_ref(const FrameArgs &fa, float *tile, int px, int py)
+{
+    const int x0 = blockIdx.x * kFwTile - kPatchRadius, y0 = blockIdx.y * kFwTile - kPatchRadius;
+    for (int idx = threadIdx.x; idx < kFwLds * kFwLds; idx += 256) {
+        const int r = idx / kFwLds, c = idx - r * kFwLds;
+        tile[r * kFwPitch + c] = fetch_texel(fa.ref_img, fa.W, fa.H, x0 + c, y0 + r);
+    }
+    __syncthreads();
+    RefPatchLds<kFwPitch> rp;
+    rp.base = &tile[(py - y0 - kPatchRadius) * kFwPitch + (px - x0 - kPatchRadius)];
+    RefPatch tmp;
+#pragma unroll
+    for (int i = 0; i < kPatchN; ++i) {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            tmp.v[i * kPatchN + j] = rp.at(i, j);
+        }
+    }
+    ref_patch_finish(tmp);
+    rp.mean = tmp.mean;
+    rp.var = tmp.var;
+    return rp;
+}
+
+// baseline + weight sum over the selected views (:2036-2044); no image access
+__device__ __forceinline__ int fw_baseline_and_weight(const FrameArgs &fa, uint32_t sel, const ViewWeights<32> &vw, float &base_line,
+                                                      float &weight_normal)
+{
+    float bl = 0, wn = 0.0f;
+    int valid = 0;
+    for (int v = 0; v < fa.num_src; ++v) {
+        if (bit_test(sel, (unsigned)v)) {
+            const ViewConst &vc = fa.views[v];
+            wn += (float)vw.get(v);
+            const float d0 = fa.c[0] - vc.c[0];
+            const float d1 = fa.c[1] - vc.c[1];
+            const float d2 = fa.c[2] - vc.c[2];
+            const double tv = (double)(d0 * d0 + d1 * d1 + d2 * d2);
+            bl += sqrtf((float)tv);
+            valid++;
+        }
+    }
+    base_line = bl;
+    weight_normal = wn;
+    return valid;
+}
+
+// Window of view vc around where the pixels of the wave land when their planes are (origin normal, distance w).
+__device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, bool use, int px, int py,
+                                              const float4 origin, float w)
+{
+    float cx = 0.0f, cy = 0.0f;
+    bool ok = false;
+    if (use) {
+        float4 pl = origin;
+        pl.w = w;
+        float qx, qy, qz;
+        plane_q(pl, qx, qy, qz);
+        const Homography H = make_homography(fa, vc, qx, qy, qz);
+        correspond(H, (float)px, (float)py, cx, cy);
+        ok = cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf;  // false for NaN
+    }
+    return stage_window_around<kK14WinH>(fa, vc, win, ok, cx, cy);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K14
+// ------------------------------------------------------------------------------------------------
+
+#ifndef APD_K14W_WAVES
+#define APD_K14W_WAVES 4  // ms at 4096x3072, 8 views: 4 waves/SIMD (128 VGPRs, 18 spilled) 140.6, 3 waves 150.1
+#endif
+#ifndef APD_K15W_WAVES
+#define APD_K15W_WAVES 3  // 4 waves/SIMD (100 VGPRs spilled) 30.5, 3 waves 27.1
+#endif
+__global__ __launch_bounds__(256, APD_K14W_WAVES) void k14w_depth_to_weak(FrameArgs fa)
+{
+    __shared__ float tile[kFwLds * kFwPitch];
+    __shared__ uint32_t windows[4][window_entries(kK14WinH)];
+    int px, py;
+    fw_pixel(px, py);
+    const RefPatchLds<kFwPitch> rp = fw_stage_ref(fa, tile, px, py);
+    uint32_t *win = windows[threadIdx.x >> 6];
+    const int W = fa.W, H = fa.H;
+    const int min_margin = 6;
+    const int center = px + py * W;
+    constexpr int RADIUS = 30, NP = 2 * RADIUS + 1;
+
+    // lanes without depth samples to score stay in the wave: every lane helps to stage the windows
+    bool alive = px < W && py < H;
+    float4 origin = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
+    uint32_t sel = 0;
+    ViewWeights<32> vw;
+    vw.clear();
+    float weight_normal = 1.0f;
+    float pw[NP];   // plane distance of depth sample i; NaN-free marker for "outside [depth_min, depth_max]": in_range bit
+    float pc[NP];   // accumulated cost of depth sample i
+    uint64_t in_range = 0;
+    if (alive) {
+        if (px < min_margin || py < min_margin || px >= W - min_margin || py >= H - min_margin) {
+            fa.weak_info[center] = APD_UNKNOWN;
+            alive = false;
+        }
+    }
+    if (alive) {
+        origin = normal_world_to_cam(fa, fa.planes[center]);
+        if (origin.w == 0) {
+            fa.weak_info[center] = APD_UNKNOWN;
+            alive = false;
+        }
+    }
+    if (alive) {
+        sel = fa.selected_views[center];
+        vw.load(fa, center);
+        float base_line;
+        const int valid = fw_baseline_and_weight(fa, sel, vw, base_line, weight_normal);
+        if (valid == 0) {
+            fa.weak_info[center] = APD_UNKNOWN;
+            alive = false;
+        } else {
+            // cost_now of :2022-2051 is computed by the reference but never used by K14's classification
+            base_line /= (float)valid;
+            const float disp = fa.K[0] * base_line / origin.w;
+#pragma unroll 1
+            for (int i = 0; i < NP; ++i) {
+                const float p_depth = fa.K[0] * base_line / (disp + (float)(i - RADIUS));
+                pc[i] = 0.0f;
+                pw[i] = 1.0f;
+                if (!(p_depth < fa.depth_min || p_depth > fa.depth_max)) {
+                    in_range |= 1ull << i;
+                    pw[i] = distance_to_origin(fa, px, py, p_depth, origin.x, origin.y, origin.z);
+                }
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(alive && in_range != 0) == 0) {
+        if (alive) {  // every sample out of range: all costs are 2, no minimum
+            fa.weak_info[center] = APD_WEAK;  // abs(0 - 30) > weak_peak_radius or pc[0] = 2 > 0.5 (:2120)
+        }
+        return;
+    }
+
+#pragma unroll 1
+    for (int v = 0; v < fa.num_src; ++v) {
+        const bool use = alive && bit_test(sel, (unsigned)v) != 0;
+        if (__builtin_amdgcn_ballot_w64(use) == 0) {
+            continue;
+        }
+        const ViewConst &vc = fa.views[v];
+        const float wv = (float)vw.get(v);
+#pragma unroll 1
+        for (int c0 = 0; c0 < NP; c0 += APD_K14_CHUNK) {
+            const int c1 = min(c0 + APD_K14_CHUNK, NP);
+            if (__builtin_amdgcn_ballot_w64(use && ((in_range >> c0) & ((1ull << (c1 - c0)) - 1ull)) != 0) == 0) {
+                continue;  // nobody has a sample to score in this chunk
+            }
+            const int mid = (c0 + c1) >> 1;
+            const SrcWindow w = fw_stage(fa, vc, win, use && ((in_range >> mid) & 1ull) != 0, px, py, origin, pw[mid]);
+#pragma unroll 1
+            for (int i = c0; i < c1; ++i) {
+                if (use && ((in_range >> i) & 1ull)) {
+                    float4 pl = origin;
+                    pl.w = pw[i];
+                    float qx, qy, qz;
+                    plane_q(pl, qx, qy, qz);
+                    float tc = 0.0f;
+                    tc += ncc_fixed_windowed(fa, vc, w, rp, px, py, qx, qy, qz);
+                    if (fa.geom_consistency) {
+                        tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
+                    }
+                    pc[i] += tc * wv;
+                }
+            }
+        }
+    }
+    if (!alive) {
+        return;
+    }
+#pragma unroll 1
+    for (int i = 0; i < NP; ++i) {
+        if ((in_range >> i) & 1ull) {
+            const float p_cost = pc[i] / weight_normal;
+            pc[i] = (2.0f > p_cost) ? p_cost : 2.0f;  // MIN(2.0f, p_cost): NaN -> 2
+        } else {
+            pc[i] = 2.0f;
+        }
+    }
+    uint64_t peaks = 0;
+    int peak_count = 0, min_peak = 0;
+    float min_cost = 2.0f;
+    for (int i = 2; i < NP - 2; ++i) {
+        if (pc[i - 1] > pc[i] && pc[i + 1] > pc[i]) {
+            peaks |= 1ull << i;
+            peak_count++;
+            if (pc[i] < min_cost) {
+                min_peak = i;
+                min_cost = pc[i];
+            }
+        }
+    }
+    if (abs(min_peak - RADIUS) > fa.weak_peak_radius || pc[min_peak] > 0.5f) {
+        fa.weak_info[center] = APD_WEAK;
+        return;
+    }
+    if (peak_count == 1) {
+        fa.weak_info[center] = (pc[min_peak] <= 0.15f) ? APD_STRONG : APD_WEAK;
+        return;
+    }
+    float var = 0.0f;
+    for (int i = 2; i < NP - 2; ++i) {
+        if (((peaks >> i) & 1ull) && i != min_peak) {
+            const float dist = pc[i] - min_cost;
+            var += dist * dist;
+        }
+    }
+    var = sqrtf(var);
+    var /= (float)(peak_count - 1);
+    fa.weak_info[center] = (var > 0.2f) ? APD_STRONG : APD_WEAK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K15
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256, APD_K15W_WAVES) void k15w_local_refine(FrameArgs fa)
+{
+    __shared__ float tile[kFwLds * kFwPitch];
+    __shared__ uint32_t windows[4][window_entries(kK14WinH)];
+    int px, py;
+    fw_pixel(px, py);
+    const RefPatchLds<kFwPitch> rp = fw_stage_ref(fa, tile, px, py);
+    uint32_t *win = windows[threadIdx.x >> 6];
+    const int W = fa.W, H = fa.H;
+    const int center = px + py * W;
+    constexpr int RADIUS = 5, NP = 2 * RADIUS + 1;
+
+    bool alive = px < W && py < H;
+    float4 origin = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
+    uint32_t sel = 0;
+    ViewWeights<32> vw;
+    vw.clear();
+    float weight_normal = 1.0f, w_now = 1.0f, acc_now = 0.0f;
+    float pw[NP], pd_depth[NP], acc[NP];
+    uint32_t in_range = 0;
+    if (alive) {
+        origin = normal_world_to_cam(fa, fa.planes[center]);
+        if (origin.w == 0) {
+            alive = false;
+        }
+    }
+    if (alive) {
+        sel = fa.selected_views[center];
+        vw.load(fa, center);
+        float base_line;
+        const int valid = fw_baseline_and_weight(fa, sel, vw, base_line, weight_normal);
+        if (weight_normal == 0 || valid == 0) {
+            alive = false;
+        } else {
+            base_line /= (float)valid;
+            const float disp = fa.K[0] * base_line / origin.w;
+            w_now = distance_to_origin(fa, px, py, origin.w, origin.x, origin.y, origin.z);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const float p_depth = fa.K[0] * base_line / (disp + (float)(i - RADIUS));
+                acc[i] = 0.0f;
+                pw[i] = 1.0f;
+                pd_depth[i] = p_depth;
+                if (!(p_depth < fa.depth_min || p_depth > fa.depth_max)) {
+                    in_range |= 1u << i;
+                    pw[i] = distance_to_origin(fa, px, py, p_depth, origin.x, origin.y, origin.z);
+                }
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(alive) == 0) {
+        return;
+    }
+#pragma unroll 1
+    for (int v = 0; v < fa.num_src; ++v) {
+        const bool use = alive && bit_test(sel, (unsigned)v) != 0;
+        if (__builtin_amdgcn_ballot_w64(use) == 0) {
+            continue;
+        }
+        const ViewConst &vc = fa.views[v];
+        const float wv = (float)vw.get(v);
+        const SrcWindow w = fw_stage(fa, vc, win, use, px, py, origin, w_now);
+        // sample -1: the current depth with K14's cost form (:2173-2183); samples 0..10: LocalRefine's (:2217-2220)
+#pragma unroll 1
+        for (int i = -1; i < NP; ++i) {
+            if (use && (i < 0 || ((in_range >> i) & 1u))) {
+                float4 pl = origin;
+                pl.w = (i < 0) ? w_now : pw[i];
+                float qx, qy, qz;
+                plane_q(pl, qx, qy, qz);
+                const float c = ncc_fixed_windowed(fa, vc, w, rp, px, py, qx, qy, qz);
+                if (i < 0) {
+                    float tc = 0.0f;
+                    tc += c;
+                    if (fa.geom_consistency) {
+                        tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
+                    }
+                    acc_now += tc * wv;
+                } else {
+                    float a = acc[i];
+                    a += c * wv;
+                    if (fa.geom_consistency) {
+                        a += fa.geom_factor * geom_cost(fa, vc, px, py, pl) * wv;
+                    }
+                    acc[i] = a;
+                }
+            }
+        }
+    }
+    if (!alive) {
+        return;
+    }
+    const float cost_now = acc_now / weight_normal;
+    float min_cost = 2.0f;
+    float best_depth = origin.w;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if ((in_range >> i) & 1u) {
+            const float tc = acc[i] / weight_normal;
+            if (tc < min_cost) {
+                min_cost = tc;
+                best_depth = pd_depth[i];
+            }
+        }
+    }
+    if ((double)(cost_now - min_cost) > 0.1) {
+        fa.planes[center].w = best_depth;
+    }
+}
+
+hipError_t launch_k14_windowed(const FrameArgs &fa, hipStream_t s)
+{
+    hipLaunchKernelGGL(k14w_depth_to_weak, dim3((fa.W + kFwTile - 1) / kFwTile, (fa.H + kFwTile - 1) / kFwTile), dim3(256), 0, s, fa);
+    return hipGetLastError();
+}
+
+hipError_t launch_k15_windowed(const FrameArgs &fa, hipStream_t s)
+{
+    hipLaunchKernelGGL(k15w_local_refine, dim3((fa.W + kFwTile - 1) / kFwTile, (fa.H + kFwTile - 1) / kFwTile), dim3(256), 0, s, fa);
+    return hipGetLastError();
+}
+
+}  // namespace apd
+
+#else
+
+namespace apd {
+hipError_t launch_k14_windowed(const FrameArgs &, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_k15_windowed(const FrameArgs &, hipStream_t) { return hipErrorNotSupported; }
+}  // namespace apd
+
+#endif
+
+#if defined(APD_EXPERIMENT_WIN_STATS) && !defined(APD_QUAD_F16)
+APD_WIN_STATS_ACCESSOR(apd_debug_win_stats_k1415)
+#endif

@@ -17,86 +17,22 @@
 // before the first of them is tested (:855-867), so the order of evaluation is not observable.
 #include "apd_device.h"
 #include "apd_sweep.h"
+#include "apd_window.h"
 
 #ifndef APD_QUAD_F16  // the window holds 4-byte entries
 
 namespace apd {
 
-// Window geometry.  One entry per texel (qx, qy): the binary16 pair {I(qx,qy), I(qx+1,qy) - I(qx,qy)} (integers up to 255 and
-// their differences are exact in binary16).  A bilinear fetch at (qx, qy) reads the entries (qx, qy) and (qx, qy + 1) with one
-// two-address LDS read and lerps each pair with one v_fma_mix_f32: 4 VALU instructions instead of the 10 of the byte quads,
-// same taps, same three fused multiply-adds.  The pitch is the wave size, so lane l stages column l of every row.
-constexpr int kWinW = 64;
 #ifndef APD_WIN_H
 #define APD_WIN_H (kWaveH + 16)   // rows of fetch positions: footprint + 2 * (patch radius 5 + 3 texels of slack)
 #endif
-constexpr int kWinH = APD_WIN_H, kWinRows = kWinH + 1;  // + the row below the last fetch row
-constexpr int kWinEntries = kWinW * kWinRows;
-static_assert(kQuadShift == 2, "the window is staged from 4-byte quad entries");
+constexpr int kWinH = APD_WIN_H;
 
-typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
-
-// LDS byte address <-> pointer (32-bit in the local address space; the host pass only has to parse this)
-__device__ __forceinline__ int lds_address(uint32_t *p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (int)(uintptr_t)(lds_u32_ptr)p;
-#else
-    return 0;
-#endif
-}
-
-// entries (qx, qy) and (qx, qy + 1)
-__device__ __forceinline__ uint2 lds_read_pair(int addr)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(uint32_t)addr;
-    return make_uint2(p[0], p[kWinW]);
-#else
-    return make_uint2(0, 0);
-#endif
-}
-
-#ifdef APD_EXPERIMENT_WIN_STATS  // diagnostic build only: [0] NCCs through the window, [1] global fast, [2] global slow,
-                                 // [3] wave-level NCC calls, [4] of those with both window and global lanes, [5] windows staged
-__device__ unsigned long long g_k67w_stats[8];
-#define APD_WIN_COUNT(i, n) atomicAdd(&g_k67w_stats[i], (unsigned long long)(n))
-#else
-#define APD_WIN_COUNT(i, n) ((void)0)
-#endif
-
-struct SrcWindow {
-    int valid;        // wave-uniform: a window is staged
-    int wx0, wy0;     // quad coordinates of window entry (0, 0) (wave-uniform)
-    float lo_x, hi_x, lo_y, hi_y;  // a patch whose four corner samples lie in [lo, hi) reads the window only
-    int addr0;        // LDS byte address of entry (0, 0) minus the byte offset of quad (wx0, wy0): address(qx, qy) =
-                      // qy * 4 * kWinW + 4 * qx + addr0
-};
-
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        v = fminf(v, __shfl_xor(v, m));
-    }
-    return v;
-}
-
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        v = fmaxf(v, __shfl_xor(v, m));
-    }
-    return v;
-}
-
-// Every lane of the wave calls this (no divergence): places the window around the projections of the live pixels'
-// centres under their current planes and copies it from the quad image.  `win` is this wave's LDS region.
+// Places the window around the projections of the live pixels' centres under their current planes and stages it.
+// Every lane of the wave calls this (no divergence).
 __device__ __forceinline__ SrcWindow stage_window(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, bool alive, int px, int py,
                                                   const float4 plane)
 {
-    SrcWindow w;
     float cx = 0.0f, cy = 0.0f;
     bool ok = false;
     if (alive) {
@@ -106,251 +42,7 @@ __device__ __forceinline__ SrcWindow stage_window(const FrameArgs &fa, const Vie
         correspond(H, (float)px, (float)py, cx, cy);
         ok = cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf;  // false for NaN
     }
-    const float big = 3.0e38f;
-    const float x_lo = wave_min(ok ? cx : big), x_hi = wave_max(ok ? cx : -big);
-    const float y_lo = wave_min(ok ? cy : big), y_hi = wave_max(ok ? cy : -big);
-    if (!(x_lo <= x_hi)) {  // no live pixel projects into this view
-        w.valid = 0;
-        w.wx0 = w.wy0 = w.addr0 = 0;
-        w.lo_x = w.lo_y = big;
-        w.hi_x = w.hi_y = -big;
-        return w;
-    }
-    // centre the window on the bounding box of the projected centres (all values are wave-uniform)
-    const int wx0 = __builtin_amdgcn_readfirstlane((int)floorf(0.5f * (x_lo + x_hi)) - kWinW / 2);
-    const int wy0 = __builtin_amdgcn_readfirstlane((int)floorf(0.5f * (y_lo + y_hi)) - kWinH / 2);
-    const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
-    const int lane = threadIdx.x & 63;
-    const int qp = fa.W + 1;
-    // entries outside the image replicate the edge entry, exactly like the clamp of the global path
-    const int col = med3_i32(wx0 + lane, -1, fa.W - 1) + 1;
-    uint32_t tmp[kWinRows];
-#pragma unroll
-    for (int k = 0; k < kWinRows; ++k) {
-        const int gy = min(max(wy0 + k, -1), fa.H - 1);  // wave-uniform
-        tmp[k] = srcq[(unsigned)((gy + 1) * qp + col)];
-    }
-#pragma unroll
-    for (int k = 0; k < kWinRows; ++k) {
-        const float t0 = (float)(tmp[k] & 0xFFu);
-        const float dx = (float)((tmp[k] >> 8) & 0xFFu) - t0;
-        win[k * kWinW + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, dx));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if ((threadIdx.x & 63) == 0) {
-        APD_WIN_COUNT(5, 1);
-    }
-    w.valid = 1;
-    w.wx0 = wx0;
-    w.wy0 = wy0;
-    // one entry of margin on every side absorbs the rounding of the samples between the corners
-    w.lo_x = (float)(wx0 + 1);
-    w.hi_x = (float)(wx0 + kWinW - 1);
-    w.lo_y = (float)(wy0 + 1);
-    w.hi_y = (float)(wy0 + kWinH - 1);
-    w.addr0 = __builtin_amdgcn_readfirstlane(lds_address(win) - 4 * (wy0 * kWinW + wx0));
-    return w;
-}
-
-// quad_row_issue for samples known to lie inside the window: no clamps, LDS addresses.
-__device__ __forceinline__ void win_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN], int addr0,
-                                              float (&a)[kPatchN], float (&b)[kPatchN], uint2 (&t)[kPatchN])
-{
-    float z[kPatchN], X[kPatchN], Y[kPatchN], r[kPatchN];
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        z[j] = fmaf(H.h[7], yf[j], bz);
-        X[j] = fmaf(H.h[1], yf[j], bx);
-        Y[j] = fmaf(H.h[4], yf[j], by);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        r[j] = __builtin_amdgcn_rcpf(z[j]);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        z[j] = fmaf(-z[j], r[j], 1.0f);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        r[j] = fmaf(z[j], r[j], r[j]);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        X[j] *= r[j];
-        Y[j] *= r[j];
-    }
-    APD_STAGE();
-    int qx[kPatchN], qy[kPatchN];
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        a[j] = __builtin_amdgcn_fractf(X[j]);
-        b[j] = __builtin_amdgcn_fractf(Y[j]);
-        qx[j] = cvt_floor_i32(X[j]);
-        qy[j] = cvt_floor_i32(Y[j]);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = (int)quad_byte_offset(qx[j], qy[j], 4 * kWinW, addr0);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        t[j] = lds_read_pair(qx[j]);
-    }
-}
-
-// Pairs + weights of one row -> six bilinear values: fmaf(a, t10 - t00, t00), fmaf(a, t11 - t01, t01), fmaf(b, bot - top, top).
-__device__ __forceinline__ void win_row_lerp(const uint2 (&t)[kPatchN], const float (&a)[kPatchN], const float (&b)[kPatchN],
-                                             float (&v)[kPatchN])
-{
-    float top[kPatchN], bot[kPatchN];
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        top[j] = lerp_f16_pair(a[j], t[j].x);
-        bot[j] = lerp_f16_pair(a[j], t[j].y);
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        bot[j] -= top[j];
-    }
-    APD_STAGE();
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        v[j] = fmaf(b[j], bot[j], top[j]);
-    }
-}
-
-// ncc_fixed_moments (quad mode, fast reciprocal) reading the window.
-template <typename Ref>
-__device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homography &H, int px, int py, int addr0, float &sum_s,
-                                                   float &sum_ss, float &sum_rs)
-{
-    float yf[kPatchN];
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        yf[j] = (float)(py + kPatchStep * j - kPatchRadius);
-    }
-    sum_s = 0.0f;
-    sum_ss = 0.0f;
-    sum_rs = 0.0f;
-    float a[2][kPatchN], b[2][kPatchN];
-    uint2 t[2][kPatchN];
-    {
-        const float xf = (float)(px - kPatchRadius);
-        win_row_issue(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[0], b[0], t[0]);
-    }
-#pragma unroll
-    for (int i = 0; i < kPatchN; ++i) {
-        float v[kPatchN];
-        // LDS returns in order: the reference texels of this row are requested before the window entries of the next
-        // one, so the reduction below only waits for reads that were issued a whole row of arithmetic ago
-        float ref[kPatchN];
-#pragma unroll
-        for (int j = 0; j < kPatchN; ++j) {
-            ref[j] = rp.at(i, j);
-        }
-        APD_STAGE();
-        if (i + 1 < kPatchN) {
-            const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
-            win_row_issue(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[(i + 1) & 1],
-                          b[(i + 1) & 1], t[(i + 1) & 1]);
-        }
-        APD_STAGE();
-        win_row_lerp(t[i & 1], a[i & 1], b[i & 1], v);
-        float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kPatchN; ++j) {
-            row_s += v[j];
-            row_ss = fmaf(v[j], v[j], row_ss);
-            row_rs = fmaf(ref[j], v[j], row_rs);
-        }
-        sum_s += row_s;
-        sum_ss += row_ss;
-        sum_rs += row_rs;
-    }
-}
-
-// Sample position of patch corner (xf, yf), computed exactly like the samples themselves (fast reciprocal).
-__device__ __forceinline__ void corner_position(const Homography &H, float xf, float yf, float &X, float &Y)
-{
-    const float z = fmaf(H.h[7], yf, fmaf(H.h[6], xf, H.h[8]));
-    const float r = recip_fast(z);
-    X = fmaf(H.h[1], yf, fmaf(H.h[0], xf, H.h[2])) * r;
-    Y = fmaf(H.h[4], yf, fmaf(H.h[3], xf, H.h[5])) * r;
-}
-
-// ComputeBilateralNCCOld (APD.cu:530-614) for plane q = n/d against source view vc, window first.
-template <typename Ref>
-__device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const ViewConst &vc, const SrcWindow &w, const Ref &rp, int px,
-                                                    int py, float qx, float qy, float qz)
-{
-    const Homography H = make_homography(fa, vc, qx, qy, qz);
-    float cx, cy;
-    correspond(H, (float)px, (float)py, cx, cy);
-    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
-        return 2.0f;
-    }
-    const float kMinVar = 1e-5f;
-    if (rp.var < kMinVar) {
-        return 2.0f;
-    }
-    const float x0 = (float)(px - kPatchRadius), x1 = (float)(px + kPatchRadius);
-    const float y0 = (float)(py - kPatchRadius), y1 = (float)(py + kPatchRadius);
-    const bool fast_recip = denominators_fast(H, x0, x1, y0, y1);
-    bool in_window = false;
-    if (fast_recip && w.valid) {
-        // x/z and y/z are monotone along every row and every column of the sample grid while z keeps its sign, so the
-        // four corner samples bound all 36
-        float X00, Y00, X01, Y01, X10, Y10, X11, Y11;
-        corner_position(H, x0, y0, X00, Y00);
-        corner_position(H, x0, y1, X01, Y01);
-        corner_position(H, x1, y0, X10, Y10);
-        corner_position(H, x1, y1, X11, Y11);
-        const float xl = fminf(fminf(X00, X01), fminf(X10, X11)), xh = fmaxf(fmaxf(X00, X01), fmaxf(X10, X11));
-        const float yl = fminf(fminf(Y00, Y01), fminf(Y10, Y11)), yh = fmaxf(fmaxf(Y00, Y01), fmaxf(Y10, Y11));
-        in_window = xl >= w.lo_x && xh < w.hi_x && yl >= w.lo_y && yh < w.hi_y;
-    }
-#ifdef APD_EXPERIMENT_WIN_STATS
-    {
-        const unsigned long long m_all = __builtin_amdgcn_ballot_w64(true), m_in = __builtin_amdgcn_ballot_w64(in_window);
-        if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_all)) {
-            APD_WIN_COUNT(3, 1);
-            APD_WIN_COUNT(4, (m_in != 0 && m_in != m_all) ? 1 : 0);
-        }
-        APD_WIN_COUNT(in_window ? 0 : (fast_recip ? 1 : 2), 1);
-    }
-#endif
-#ifndef APD_WIN_DIVERGENT
-    // one path per wave and NCC: lanes inside and outside the window would otherwise run both 36-sample bodies in turn
-    in_window = in_window && __builtin_amdgcn_ballot_w64(!in_window) == 0;
-#endif
-    float sum_s, sum_ss, sum_rs;
-    if (in_window) {
-        ncc_window_moments(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
-    } else if (__builtin_expect(fast_recip, 1)) {
-        ncc_fixed_moments<true, true, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
-    } else {
-        ncc_fixed_moments<true, false, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
-    }
-    const float inv_w = 1.0f / 36.0f;
-    sum_s *= inv_w;
-    sum_ss *= inv_w;
-    sum_rs *= inv_w;
-    const float var_s = fmaf(-sum_s, sum_s, sum_ss);
-    if (var_s < kMinVar) {
-        return 2.0f;
-    }
-    const float covar = fmaf(-rp.mean, sum_s, sum_rs);
-    const float denom = sqrtf(rp.var * var_s);
-    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+    return stage_window_around<kWinH>(fa, vc, win, ok, cx, cy);
 }
 
 // Cheapest candidate of propagation arm `arm` (order of APD.cu:1020: near/far x up,down,left,right).
@@ -413,7 +105,7 @@ template <int NMAX>
 __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameArgs fa, int colour, int iter)
 {
     __shared__ float tile[kLdsH * kLdsPitch];
-    __shared__ uint32_t windows[4][kWinEntries];
+    __shared__ uint32_t windows[4][window_entries(kWinH)];
     const TilePixel t = checkerboard_pixel(fa, colour);
     // stage the reference tile + 5 px halo (clamp-to-edge, as the texture unit would)
     for (int idx = threadIdx.x; idx < kLdsW * kLdsH; idx += 256) {
@@ -610,18 +302,6 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
     }
 }
 
-#ifdef APD_EXPERIMENT_WIN_STATS
-extern "C" int apd_debug_win_stats(unsigned long long *out, int reset)
-{
-    hipDeviceSynchronize();
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k67w_stats), sizeof(g_k67w_stats));
-    if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_k67w_stats), z, sizeof(z));
-    }
-    return (int)e;
-}
-#endif
 
 hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
@@ -644,4 +324,8 @@ namespace apd {
 hipError_t launch_k67_windowed(const FrameArgs &, int, int, hipStream_t) { return hipErrorNotSupported; }
 }  // namespace apd
 
+#endif
+
+#if defined(APD_EXPERIMENT_WIN_STATS) && !defined(APD_QUAD_F16)
+APD_WIN_STATS_ACCESSOR(apd_debug_win_stats)
 #endif

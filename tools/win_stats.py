@@ -26,3 +26,15 @@ for it in range(iters):
     lane = max(s[0] + s[1] + s[2], 1)
     print("iter %d: lane-NCCs %.3g  window %.1f%%  global fast %.1f%%  global slow %.2f%% | wave-NCCs %.3g, mixed %.1f%% | windows staged %d"
           % (it, lane, 100.0 * s[0] / lane, 100.0 * s[1] / lane, 100.0 * s[2] / lane, s[3], 100.0 * s[4] / max(s[3], 1), s[5]))
+
+# post-loop kernels of the same pass: K11..K13, then K14 and K15 with their own counters
+for k in (pkg.K11, pkg.K12, pkg.K13):
+    h.run_kernel(k)
+L.apd_debug_win_stats_k1415(out, 1)
+for name, k in (("K14", pkg.K14), ("K15", pkg.K15)):
+    h.run_kernel(k)
+    L.apd_debug_win_stats_k1415(out, 1)
+    s = list(out)
+    lane = max(s[0] + s[1] + s[2], 1)
+    print("%s: lane-NCCs %.3g  window %.1f%%  global fast %.1f%%  global slow %.2f%% | wave-NCCs %.3g, mixed %.1f%% | windows staged %d"
+          % (name, lane, 100.0 * s[0] / lane, 100.0 * s[1] / lane, 100.0 * s[2] / lane, s[3], 100.0 * s[4] / max(s[3], 1), s[5]))
