@@ -199,14 +199,17 @@ def main():
     # K6/K7 skip WEAK pixels; the weak fraction is the one at upload time (K4 only ever lowers it)
     bytes_per_launch = (W * H / 2.0) * (1.0 - weak_fraction) * algorithmic_bytes_per_strong_pixel(N)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, traffic_src = load_pmc_traffic(args.workload)
+    traffic, traffic_src, valu = load_pmc_traffic(args.workload)
     roofline = {
-        "bound": "hbm", "kernel": "k67_update_strong (Black/RedPixelUpdateStrong)", "achieved": round(achieved, 1),
+        "bound": "hbm", "kernel": "k67w_update_strong (Black/RedPixelUpdateStrong, LDS source windows)", "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
         "traffic_source": traffic_src,
         "avg_launch_ms": round(avg_ms, 3), "launches": launches,
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "bytes_per_pixel_iter": algorithmic_bytes_per_strong_pixel(N),
+        # what actually limits the kernel: wave64 VALU instructions per launch and the fraction of the launch
+        # the 16-lane VALU pipes are busy with them, from the SQ pass of the same committed profile
+        "valu": valu,
     }
     kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0], 3) for k, v in sorted(prof.items())}
     weak_path = None
@@ -264,7 +267,7 @@ def load_pmc_traffic(workload):
     as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this process, so the
     field is null when no such profile exists."""
     import glob
-    best = (None, None)
+    best = (None, None, None)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
         try:
             with open(path) as f:
@@ -272,7 +275,10 @@ def load_pmc_traffic(workload):
         except (OSError, ValueError):
             continue
         if rec.get("workload") == workload and rec.get("hbm_bytes_per_launch"):
-            best = (rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
+            valu = None
+            if rec.get("valu_insts_per_launch"):
+                valu = {"insts_per_launch": rec["valu_insts_per_launch"], "pipe_busy_frac": round(rec.get("valu_pipe_busy_frac", 0.0), 3)}
+            best = (rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), valu)
     return best
 
 

@@ -46,7 +46,7 @@ def main():
     print("wrote", dst, len(rows_out), "rows")
 
 
-def traffic_json(fetch_csv, write_csv, workload, dst, kernel_substr="k67_update_strong"):
+def traffic_json(fetch_csv, write_csv, workload, dst, sq_csv=None, kernel_substr="k67"):
     """FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so the read
     side is doubled (MI355X_MICROARCH.md, HBM section).  Steady state = minimum over the dispatches (the
     first launches run on random planes and scatter more)."""
@@ -64,6 +64,13 @@ def traffic_json(fetch_csv, write_csv, workload, dst, kernel_substr="k67_update_
            "write_bytes_mean": wr[0] * 1024, "write_bytes_min": wr[1] * 1024,
            "hbm_bytes_per_launch": fe[0] * 1024 * 2 + wr[0] * 1024,
            "note": "FETCH_SIZE x2 (gfx950), WRITE_SIZE uncorrected; mean over the timed-region dispatches (warm-up launches dropped); separate --pmc passes"}
+    if sq_csv and os.path.exists(sq_csv):  # VALU issue accounting of the same kernel (its own --pmc pass)
+        iv, du = pick(sq_csv, "SQ_INSTS_VALU"), pick(sq_csv, "duration_ns")
+        if iv and du:
+            rec["valu_insts_per_launch"] = iv[0]
+            rec["sq_pass_launch_ns"] = du[0]
+            # 1024 SIMDs; a wave64 VALU instruction occupies its SIMD's 16-lane pipe for 4 cycles (2.4 GHz)
+            rec["valu_pipe_busy_frac"] = iv[0] * 4.0 / (1024 * 2.4 * du[0])
     with open(dst, "w") as f:
         json.dump(rec, f, indent=1)
     print("wrote", dst)
@@ -71,6 +78,6 @@ def traffic_json(fetch_csv, write_csv, workload, dst, kernel_substr="k67_update_
 
 if __name__ == "__main__":
     if sys.argv[1] == "--traffic":
-        traffic_json(*sys.argv[2:6])
+        traffic_json(*sys.argv[2:7])
     else:
         main()

@@ -13,7 +13,7 @@ echo "== pmc FETCH_SIZE"; timeout 300 rocprofv3 --kernel-trace --output-format c
 echo "== pmc WRITE_SIZE"; timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python bench.py $ARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 echo "== pmc SQ"; timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- python bench.py $ARGS > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.err
 for d in pmc_fetch pmc_write pmc_sq trace; do python tools/pmc_summary.py $OUT/$d $OUT/${d}_summary.csv; done
-python tools/pmc_summary.py --traffic $OUT/pmc_fetch_summary.csv $OUT/pmc_write_summary.csv eth3d_office_fullres_8src $OUT/pmc_traffic.json
+python tools/pmc_summary.py --traffic $OUT/pmc_fetch_summary.csv $OUT/pmc_write_summary.csv eth3d_office_fullres_8src $OUT/pmc_traffic.json $OUT/pmc_sq_summary.csv
 find $OUT -type f -size +1M -print -delete
 find $OUT -type f | xargs ls -la | head -60
 du -sh $OUT
