@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB_PATH = os.path.join(OUT_DIR, "libapd_mi355x.so")
-SOURCES = ["apd_kernels.hip", "apd_kernels_k67w.hip", "apd_kernels_k1415w.hip", "apd_kernels_weak.hip", "apd_capi.hip"]
-HEADERS = ["apd_device.h", "apd_sweep.h", "apd_window.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
+SOURCES = ["apd_kernels.hip", "apd_kernels_k67w.hip", "apd_kernels_k1415w.hip", "apd_kernels_weak.hip", "apd_fusion.hip", "apd_capi.hip"]
+HEADERS = ["apd_device.h", "apd_sweep.h", "apd_window.h", "apd_fusion_math.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
@@ -48,7 +48,7 @@ def build_library(force=False, verbose=False, extra_flags=()):
         return r.stdout
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=5) as ex:
+        with ThreadPoolExecutor(max_workers=6) as ex:
             for out in ex.map(run, jobs):
                 if verbose and out.strip():
                     print(out)
@@ -68,9 +68,9 @@ def build_host(force=False, verbose=False):
     build_library()
     cxx = os.environ.get("CXX", "g++")
     srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
-    deps = srcs + [os.path.join(HOST_DIR, "APD.h"), os.path.join(HOST_DIR, "main.cpp"), os.path.join(HOST_DIR, "host_capi.cpp"),
+    deps = srcs + [os.path.join(CSRC, "apd_fusion_math.h"), os.path.join(HOST_DIR, "APD.h"), os.path.join(HOST_DIR, "main.cpp"), os.path.join(HOST_DIR, "host_capi.cpp"),
                    os.path.join(HERE, "..", "include", "apd_mi355x.h"), LIB_PATH]
-    common = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+    common = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result"]  # contract C9: no FMA contraction in the fusion arithmetic
     link = ["-L" + OUT_DIR, "-lapd_mi355x", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + OUT_DIR]
 
     def run(cmd):

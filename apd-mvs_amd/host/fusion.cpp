@@ -1,25 +1,31 @@
 // fusion.cpp -- depth-map fusion of the drop-in host: what the reference's RunFusion (ETH variant, APD.cpp:826-977) and
 // ExportPointCloud (APD.cpp:214-254) produce, i.e. <dense>/APD/APD.ply.
 //
-// Like the reference's, this step runs on the host CPU, once, after every PatchMatch pass.  It is order dependent by
-// definition: views in problem order, pixels in raster order, and a source pixel that supported an accepted point is
-// consumed (never a reference pixel, never a supporter again).  The arithmetic keeps the reference's evaluation order
-// and types (float geometry, double pow/sqrt for the reprojection error, float exp) so that identical depth maps give
-// an identical point list.
+// The product path fuses on the GPU (apd_fuse_views, csrc/apd_fusion.hip).  This file holds the drop-in entry point
+// RunFusion (reads the maps, calls the device fusion) and the reference's sequential host loop, kept as the checker of
+// the device fusion and selectable with APD_FUSION=cpu.  Fusion is order dependent by definition: views in problem order,
+// pixels in raster order, and a source pixel that supported an accepted point is consumed (never a reference pixel,
+// never a supporter again).  The per-pixel arithmetic (csrc/apd_fusion_math.h, compiled into both) keeps the
+// reference's evaluation order and types (float geometry, double pow/sqrt for the reprojection error, float exp), so
+// identical depth maps give an identical point list on either side.
 //
 // Outside the PatchMatch path proper.  One deviation: colours.  The reference re-reads the images in
 // colour (cv::imread(IMREAD_COLOR), APD.cpp:859); the only decoder in this build returns the luma plane, so blue, green
 // and red of a point all carry the grey value (identical to the reference for grey input images).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
 #include <unordered_map>
 
 #include "APD.h"
+#include "../csrc/apd_fusion_math.h"
 
 namespace {
+
+int g_fusion_device = 0;
 
 struct V3 {
     float x, y, z;
@@ -27,51 +33,26 @@ struct V3 {
 
 struct FusionView {
     Camera cam;
+    apd_fusion::View geo;  // the camera as the shared per-pixel arithmetic wants it (csrc/apd_fusion_math.h)
     Mat grey;      // float, 0..255
     Mat depth;     // float, <= 0: no estimate
     Mat normal;    // 3 x float, world frame
     Mat weak;      // uint8 PixelState
     Mat consumed;  // uint8, 1 = already merged into a point (the reference's `masks`)
-    V3 centre;     // -R^T t in float, as Get3DPointonWorld recomputes it per call (APD.cpp:795-798)
 };
 
-V3 camera_centre(const Camera &c)
-{
-    return V3{-(c.R[0] * c.t[0] + c.R[3] * c.t[1] + c.R[6] * c.t[2]), -(c.R[1] * c.t[0] + c.R[4] * c.t[1] + c.R[7] * c.t[2]),
-              -(c.R[2] * c.t[0] + c.R[5] * c.t[1] + c.R[8] * c.t[2])};
-}
-
-// pixel + depth -> world point (APD.cpp:776-803)
-V3 lift(const FusionView &v, int x, int y, float depth)
+void set_geometry(FusionView &v)
 {
     const Camera &c = v.cam;
-    const float X = depth * (x - c.K[2]) / c.K[0];
-    const float Y = depth * (y - c.K[5]) / c.K[4];
-    const float Z = depth;
-    const float wx = c.R[0] * X + c.R[3] * Y + c.R[6] * Z;
-    const float wy = c.R[1] * X + c.R[4] * Y + c.R[7] * Z;
-    const float wz = c.R[2] * X + c.R[5] * Y + c.R[8] * Z;
-    return V3{wx + v.centre.x, wy + v.centre.y, wz + v.centre.z};
-}
-
-// world point -> pixel coordinates and depth in a view (APD.cpp:805-815)
-void drop(const FusionView &v, const V3 &P, float &u, float &w, float &depth)
-{
-    const Camera &c = v.cam;
-    const float cx = c.R[0] * P.x + c.R[1] * P.y + c.R[2] * P.z + c.t[0];
-    const float cy = c.R[3] * P.x + c.R[4] * P.y + c.R[5] * P.z + c.t[1];
-    const float cz = c.R[6] * P.x + c.R[7] * P.y + c.R[8] * P.z + c.t[2];
-    depth = c.K[6] * cx + c.K[7] * cy + c.K[8] * cz;
-    u = (c.K[0] * cx + c.K[1] * cy + c.K[2] * cz) / depth;
-    w = (c.K[3] * cx + c.K[4] * cy + c.K[5] * cz) / depth;
-}
-
-// angle between two unit normals; acos of a dot product just above 1 is NaN and counts as 0 (APD.cpp:817-824)
-float normal_angle(const Vec3f &a, const Vec3f &b)
-{
-    const float d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
-    const float angle = acosf(d);
-    return (angle != angle) ? 0.0f : angle;
+    memcpy(v.geo.K, c.K, sizeof(v.geo.K));
+    memcpy(v.geo.R, c.R, sizeof(v.geo.R));
+    memcpy(v.geo.t, c.t, sizeof(v.geo.t));
+    // -R^T t in float, as Get3DPointonWorld recomputes it per call (APD.cpp:795-798)
+    v.geo.centre[0] = -(c.R[0] * c.t[0] + c.R[3] * c.t[1] + c.R[6] * c.t[2]);
+    v.geo.centre[1] = -(c.R[1] * c.t[0] + c.R[4] * c.t[1] + c.R[7] * c.t[2]);
+    v.geo.centre[2] = -(c.R[2] * c.t[0] + c.R[5] * c.t[1] + c.R[8] * c.t[2]);
+    v.geo.rows = v.depth.rows;
+    v.geo.cols = v.depth.cols;
 }
 
 struct Support {
@@ -79,15 +60,12 @@ struct Support {
 };
 
 // One source view's vote for reference pixel (c, r) with world point P: forward projection, nearest source pixel,
-// backward reprojection; thresholds 2 px, 1 % depth, 10 degrees (APD.cpp:905-925).  `score` is the exponent of the weight.
-bool vote(const FusionView &ref, const FusionView &src, int c, int r, float ref_depth, const Vec3f &ref_normal, const V3 &P, Support &s,
-          float &score)
+// backward reprojection; thresholds 2 px, 1 % depth, 10 degrees (APD.cpp:896-925).  `weight` is exp(-score).
+bool vote(const FusionView &ref, const FusionView &src, int c, int r, float ref_depth, const Vec3f &ref_normal, const float P[3],
+          Support &s, float &weight)
 {
-    float u, w, d;
-    drop(src, P, u, w, d);
-    const int sr = int(w + 0.5f);
-    const int sc = int(u + 0.5f);
-    if (!(sc >= 0 && sc < src.depth.cols && sr >= 0 && sr < src.depth.rows)) {
+    int sc, sr;
+    if (!apd_fusion::vote_target(src.geo, P, sc, sr)) {
         return false;
     }
     if (src.consumed.at<uint8_t>(sr, sc) == 1) {
@@ -97,18 +75,12 @@ bool vote(const FusionView &ref, const FusionView &src, int c, int r, float ref_
     if (src_depth <= 0.0) {
         return false;
     }
-    const V3 Q = lift(src, sc, sr, src_depth);
-    float bu, bw, back_depth;
-    drop(ref, Q, bu, bw, back_depth);
-    const float reproj_error = sqrt(pow(c - bu, 2) + pow(r - bw, 2));  // float differences, double pow and sqrt
-    const float relative_depth_diff = fabs(back_depth - ref_depth) / ref_depth;
-    const float angle = normal_angle(ref_normal, src.normal.at<Vec3f>(sr, sc));
-    if (!(reproj_error < 2.0f && relative_depth_diff < 0.01f && angle < 0.174533f)) {
+    const Vec3f &sn = src.normal.at<Vec3f>(sr, sc);
+    if (!apd_fusion::vote_check(ref.geo, src.geo, c, r, ref_depth, ref_normal.v, sc, sr, src_depth, sn.v, weight)) {
         return false;
     }
     s.col = sc;
     s.row = sr;
-    score = reproj_error + 200 * relative_depth_diff + angle * 10;
     return true;
 }
 
@@ -145,7 +117,7 @@ size_t fuse(std::vector<FusionView> &views, const std::vector<std::vector<int>> 
     PlyWriter ply;
     for (auto &v : views) {
         v.consumed.create(v.depth.rows, v.depth.cols, MAT_8UC1);
-        v.centre = camera_centre(v.cam);
+        set_geometry(v);
     }
     std::vector<Support> support;
     for (size_t i = 0; i < views.size(); ++i) {
@@ -162,20 +134,19 @@ size_t fuse(std::vector<FusionView> &views, const std::vector<std::vector<int>> 
                     continue;
                 }
                 const Vec3f ref_normal = ref.normal.at<Vec3f>(r, c);
-                const V3 P = lift(ref, c, r, ref_depth);
+                float P[3];
+                apd_fusion::lift(ref.geo, c, r, ref_depth, P);
                 int agreeing = 0;
                 float consistency = 0.0f;
                 for (size_t j = 0; j < ngb.size(); ++j) {
                     support[j] = Support();
-                    float score = 0.0f;
-                    if (vote(ref, views[ngb[j]], c, r, ref_depth, ref_normal, P, support[j], score)) {
-                        consistency += exp(-score);  // written as in APD.cpp:922 so the same `exp` overload is chosen
+                    float weight = 0.0f;
+                    if (vote(ref, views[ngb[j]], c, r, ref_depth, ref_normal, P, support[j], weight)) {
+                        consistency += weight;
                         agreeing++;
                     }
                 }
-                // WEAK pixels need stronger agreement (APD.cpp:937-938)
-                const float factor = (ref.weak.at<uint8_t>(r, c) == WEAK ? 0.45f : 0.3f);
-                if (!(agreeing >= 1 && (consistency > factor * agreeing))) {
+                if (!apd_fusion::accept_point(agreeing, consistency, (int)ref.weak.at<uint8_t>(r, c))) {
                     continue;
                 }
                 const float g = ref.grey.at<float>(r, c);
@@ -194,7 +165,7 @@ size_t fuse(std::vector<FusionView> &views, const std::vector<std::vector<int>> 
                 for (float &ch : colour) {
                     ch /= (agreeing + 1);
                 }
-                ply.add(P, colour);
+                ply.add(V3{P[0], P[1], P[2]}, colour);
             }
         }
     }
@@ -205,7 +176,45 @@ size_t fuse(std::vector<FusionView> &views, const std::vector<std::vector<int>> 
     return ply.count;
 }
 
+// GPU fusion through the C ABI (host pointers); APD_FUSION=cpu selects the sequential host loop above.
+size_t fuse_dispatch(std::vector<FusionView> &views, const std::vector<std::vector<int>> &sources, const path &ply_path)
+{
+    const char *mode = getenv("APD_FUSION");
+    if (mode && strcmp(mode, "cpu") == 0) {
+        return fuse(views, sources, ply_path);
+    }
+    const int V = (int)views.size();
+    std::vector<apd_camera> cams(V);
+    std::vector<const float *> imgs(V), deps(V), nors(V);
+    std::vector<const uint8_t *> weaks(V);
+    std::vector<int> rows(V), cols(V), offs(V + 1, 0), idx;
+    for (int i = 0; i < V; ++i) {
+        cams[i] = views[i].cam;
+        imgs[i] = views[i].grey.ptr<float>();
+        deps[i] = views[i].depth.ptr<float>();
+        nors[i] = views[i].normal.ptr<float>();
+        weaks[i] = views[i].weak.ptr<uint8_t>();
+        rows[i] = views[i].depth.rows;
+        cols[i] = views[i].depth.cols;
+        idx.insert(idx.end(), sources[i].begin(), sources[i].end());
+        offs[i + 1] = (int)idx.size();
+    }
+    if (idx.empty()) {
+        idx.push_back(0);
+    }
+    long long n = 0;
+    const int st = apd_fuse_views(g_fusion_device, V, cams.data(), imgs.data(), deps.data(), nors.data(), weaks.data(), rows.data(),
+                                  cols.data(), offs.data(), idx.data(), 0, ply_path.string().c_str(), &n);
+    if (st != APD_OK) {
+        std::cerr << apd_fusion_last_error() << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    return (size_t)n;
+}
+
 }  // namespace
+
+void SetFusionDevice(int device) { g_fusion_device = device; }
 
 // Reads every view's final maps from <dense>/APD/<id>/ and fuses them into APD/APD.ply (APD.cpp:826-977).
 void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
@@ -255,7 +264,7 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
         }
     }
     const path ply_path = dense_folder / path("APD") / path("APD.ply");
-    const size_t n = fuse(views, sources, ply_path);
+    const size_t n = fuse_dispatch(views, sources, ply_path);
     std::cout << "Fused " << n << " points into " << ply_path << std::endl;
 }
 
@@ -286,7 +295,7 @@ long long apdhost_fuse(int num_views, const apd_camera *cameras, const float *co
         memcpy(v.weak.data(), weaks[i], n);
         sources[i].assign(pair_indices + pair_offsets[i], pair_indices + pair_offsets[i + 1]);
     }
-    return (long long)fuse(views, sources, path(ply_path));
+    return (long long)fuse_dispatch(views, sources, path(ply_path));
 }
 
 }  // extern "C"

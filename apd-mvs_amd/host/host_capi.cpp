@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "APD.h"
+#include "../csrc/apd_fusion_math.h"
 
 bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height);
 
@@ -77,5 +78,16 @@ const char *apdhost_format_index(int index)
     s = ToFormatIndex(index);
     return s.c_str();
 }
+
+// acos / exp kernels of the fusion arithmetic (csrc/apd_fusion_math.h, contract C9): which = 0 acos_c9, 1 exp_c9
+void apdhost_fusion_math(const float *in, int n, int which, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        out[i] = which == 0 ? apd_fusion::acos_c9(in[i]) : apd_fusion::exp_c9(in[i]);
+    }
+}
+
+// HIP device of the fusion started by apdhost_fuse / RunFusion (default 0)
+void apdhost_set_fusion_device(int device) { SetFusionDevice(device); }
 
 }  // extern "C"

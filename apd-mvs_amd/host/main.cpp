@@ -145,6 +145,7 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
     APD::SetDevice(gpu_index);
+    SetFusionDevice(gpu_index);
     std::vector<Problem> problems;
     GenerateSampleList(dense_folder, problems);
     if (problems.empty()) {

@@ -350,12 +350,14 @@ def save_results(folder, scene, results):
                 raise IOError("cannot write " + os.path.join(d, name))
 
 
-def fuse(scene, results, ply_path):
-    """RunFusion (APD.cpp:826-977) on the gathered maps: consistency check and merge into a binary PLY, on the host CPU
-    like the reference (host/fusion.cpp).  Every view must be at one resolution per view; images are resampled to the
-    depth-map size if it differs (RescaleImageAndCamera, APD.cpp:729-750).  Returns the number of points."""
+def fuse(scene, results, ply_path, device=0):
+    """RunFusion (APD.cpp:826-977) on the gathered maps: consistency check and merge into a binary PLY on GPU `device`
+    (apd_fuse_views, csrc/apd_fusion.hip; APD_FUSION=cpu in the environment runs the reference's sequential host loop
+    of host/fusion.cpp instead -- same file, byte for byte).  Every view must be at one resolution per view; images are
+    resampled to the depth-map size if it differs (RescaleImageAndCamera, APD.cpp:729-750).  Returns the number of points."""
     import ctypes as C
     L = host_lib()
+    L.apdhost_set_fusion_device(int(device))
     V = scene.num_views
     cam_t = type(scene.cameras[0])
     cams = (cam_t * V)()

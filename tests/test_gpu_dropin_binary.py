@@ -219,3 +219,54 @@ def test_fusion_writes_a_consistent_point_cloud(gpu_pkg, synth, tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert (a / "APD" / "APD.ply").read_bytes() == (b / "APD" / "APD.ply").read_bytes()
+
+
+def _ring_depth(K, R, t, W, H):
+    """z-depth of the generator's two slanted planes (synth.make_scene) seen from camera (K, R, t), float64."""
+    K, R, t = np.asarray(K, np.float64), np.asarray(R, np.float64).reshape(3, 3), np.asarray(t, np.float64)
+    c = -R.T @ t
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    d = np.stack([(xs - K[2]) / K[0], (ys - K[5]) / K[4], np.ones_like(xs)], -1) @ R   # rows of R^T applied: world ray
+    best = np.full((H, W), 1e9)
+    for n, dd in ((np.array([-0.15, -0.10, 1.0]), -2.0), (np.array([0.25, 0.05, 1.0]), -2.6)):
+        sdist = -(n @ c + dd) / (d @ n)
+        best = np.minimum(best, np.where(sdist > 1e-6, sdist, 1e9))
+    return best, R
+
+
+def _fusion_inputs(synth, pipeline, pkg, W, H, nviews, nsrc, noise, seed):
+    """Depth/normal maps of a synthetic ring (exact surface + noise, holes, WEAK pixels): plenty of reference pixels
+    compete for the same source pixel, so the raster-order consumption matters."""
+    scene = pipeline.synthetic_ring(synth, W, H, nviews, nsrc, pkg.make_camera, seed=seed)
+    sc = synth.make_scene(W, H, nviews - 1, seed=seed)
+    rng = np.random.RandomState(seed)
+    results = {}
+    for v in range(nviews):
+        gt, Rw = _ring_depth(sc.K[v], sc.R[v], sc.t[v], W, H)
+        d = (gt * (1.0 + noise * rng.standard_normal(gt.shape))).astype(np.float32)
+        d[rng.rand(H, W) < 0.05] = 0.0
+        n = np.zeros((H, W, 3), np.float64)
+        n[..., 2] = -1.0
+        n[..., 0] = 0.01 * rng.standard_normal((H, W))
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        n = (n @ Rw).astype(np.float32)                         # camera -> world: R^T n
+        weak = (rng.rand(H, W) < 0.2).astype(np.uint8)          # 0 = WEAK for 80 %, 1 = STRONG for 20 %
+        results[v] = pipeline.ViewState(d, np.ascontiguousarray(n), weak, np.zeros((H, W), np.uint32))
+    return scene, results
+
+
+@pytest.mark.parametrize("W,H,nviews,nsrc,noise", [(160, 120, 5, 4, 0.0004), (333, 217, 7, 6, 0.0008)])
+def test_device_fusion_equals_the_sequential_host_loop(gpu_pkg, synth, tmp_path, monkeypatch, W, H, nviews, nsrc, noise):
+    """apd_fuse_views (GPU: per-view parallel votes + fixed-point resolution of the raster-order consumption) writes
+    the byte-identical APD.ply of the reference's sequential loop (host/fusion.cpp, APD_FUSION=cpu)."""
+    from apd_mvs_amd import pipeline
+    scene, results = _fusion_inputs(synth, pipeline, gpu_pkg, W, H, nviews, nsrc, noise, seed=5)
+    monkeypatch.setenv("APD_FUSION", "cpu")
+    n_cpu = pipeline.fuse(scene, results, tmp_path / "cpu.ply")
+    monkeypatch.delenv("APD_FUSION")
+    n_gpu = pipeline.fuse(scene, results, tmp_path / "gpu.ply")
+    assert n_cpu == n_gpu and n_cpu > 0.3 * W * H * nviews / (nsrc + 1)
+    assert (tmp_path / "cpu.ply").read_bytes() == (tmp_path / "gpu.ply").read_bytes()
+    # consumption did matter: fusing every view against fresh masks would give more points
+    xyz, _ = _read_ply(tmp_path / "gpu.ply")
+    assert len(xyz) < W * H * nviews

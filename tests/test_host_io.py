@@ -156,3 +156,24 @@ def test_rescale_nearest_keeps_swapped_scale_quirk(host):
             if 0 <= o_r < 5 and 0 <= o_c < 7:
                 ref[r, c] = src[o_r, o_c]
     assert np.array_equal(out, ref)
+
+
+def test_fusion_math_kernels(host):
+    """acos / exp of the fusion arithmetic (contract C9, csrc/apd_fusion_math.h): fixed binary32 kernels shared by the
+    host and the device fusion, within a few ulp of the correctly rounded function; NaN outside [-1, 1] as GetAngle expects."""
+    fp = C.POINTER(C.c_float)
+    host.apdhost_fusion_math.argtypes = [fp, C.c_int, C.c_int, fp]
+    x = np.concatenate([np.linspace(-1, 1, 20001), [1.0, -1.0, 0.0, 0.5, -0.5, 0.9999999, 1e-9, -1e-9]]).astype(np.float32)
+    out = np.zeros_like(x)
+    host.apdhost_fusion_math(x.ctypes.data_as(fp), len(x), 0, out.ctypes.data_as(fp))
+    ref = np.arccos(x.astype(np.float64))
+    assert np.abs(out - ref).max() < 4e-7
+    bad = np.array([1.0000001, -1.0000001, 2.0, np.nan], np.float32)
+    o2 = np.zeros_like(bad)
+    host.apdhost_fusion_math(bad.ctypes.data_as(fp), len(bad), 0, o2.ctypes.data_as(fp))
+    assert np.isnan(o2).all()
+    e = np.linspace(-30, 0, 10001).astype(np.float32)
+    oe = np.zeros_like(e)
+    host.apdhost_fusion_math(e.ctypes.data_as(fp), len(e), 1, oe.ctypes.data_as(fp))
+    refe = np.exp(e.astype(np.float64))
+    assert (np.abs(oe - refe) / refe).max() < 5e-7

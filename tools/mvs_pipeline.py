@@ -48,8 +48,9 @@ def main():
     if rank == 0:
         pipeline.save_results(args.dense_folder, scene, results)
         if not args.no_fusion:
-            n = pipeline.fuse(scene, results, os.path.join(args.dense_folder, "APD", "APD.ply"))
-            print("fused %d points into APD/APD.ply" % n, flush=True)
+            tf = time.time()
+            n = pipeline.fuse(scene, results, os.path.join(args.dense_folder, "APD", "APD.ply"), device=local_rank)
+            print("fused %d points into APD/APD.ply in %.2f s" % (n, time.time() - tf), flush=True)
         print("PatchMatch passes done in %.1f s; maps written under %s" % (time.time() - t0, os.path.join(args.dense_folder, "APD")), flush=True)
     if world > 1:
         dist.barrier()
