@@ -30,8 +30,11 @@ constexpr int kWinH = APD_WIN_H;
 
 // Places the window around the projections of the live pixels' centres under their current planes and stages it.
 // Every lane of the wave calls this (no divergence).
+// `trusted`: the pixel's plane already explains the images (low cost).  While the planes are still converging the
+// bounding box of all projections is useless (one wild plane moves its centre anywhere), so the box is taken over the
+// trusted pixels when there are any.
 __device__ __forceinline__ SrcWindow stage_window(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, bool alive, int px, int py,
-                                                  const float4 plane)
+                                                  const float4 plane, bool trusted)
 {
     float cx = 0.0f, cy = 0.0f;
     bool ok = false;
@@ -42,6 +45,11 @@ __device__ __forceinline__ SrcWindow stage_window(const FrameArgs &fa, const Vie
         correspond(H, (float)px, (float)py, cx, cy);
         ok = cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf;  // false for NaN
     }
+#ifndef APD_WIN_NO_TRUST
+    if (__builtin_amdgcn_ballot_w64(ok && trusted) != 0) {
+        ok = ok && trusted;
+    }
+#endif
     return stage_window_around<kWinH>(fa, vc, win, ok, cx, cy);
 }
 
@@ -97,6 +105,11 @@ __device__ __forceinline__ bool arm_pos(const FrameArgs &fa, int px, int py, int
     pos = best;
     return true;
 }
+
+#ifndef APD_WIN_TRUST
+#define APD_WIN_TRUST 0.5f
+#endif
+constexpr float kTrustedCost = APD_WIN_TRUST;
 
 #ifndef APD_K67W_WAVES
 #define APD_K67W_WAVES 4
@@ -159,9 +172,11 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
     float4 ref_normals[5];
     float tc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
+    bool trusted = false;  // window placement only: the plane from the previous update has a low cost
     if (alive) {
         rng = rng_load(fa.rng, center);
         plane_now = fa.planes[center];
+        trusted = fa.costs[center] < kTrustedCost;
 #pragma unroll 1
         for (int h = 0; h < 8; ++h) {
             int pos = 0;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
         const ViewConst &vc = fa.views[v];
-        const SrcWindow w = stage_window(fa, vc, win, alive, px, py, plane_now);
+        const SrcWindow w = stage_window(fa, vc, win, alive, px, py, plane_now, trusted);
         if (alive) {
 #pragma unroll 1
             for (int h = 0; h < 9; ++h) {
@@ -245,6 +260,7 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
             }
         }
         float ref_depths[5];
+        trusted = cost_now < kTrustedCost;
         make_refinement_set(fa, px, py, rng, plane_now, depth_now, ref_depths, ref_normals);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
             continue;  // nobody in the wave selected this view
         }
         const ViewConst &vc = fa.views[v];
-        const SrcWindow w = stage_window(fa, vc, win, alive, px, py, plane_now);
+        const SrcWindow w = stage_window(fa, vc, win, alive, px, py, plane_now, trusted);
         if (wv > 0) {
 #pragma unroll 1
             for (int k = 0; k < 5; ++k) {
