@@ -133,8 +133,7 @@ bool ReadGrayImage(const path &image_path_without_ext, Mat &image_float);
 // cv::resize(float, INTER_LINEAR) restated (APD.cpp:474)
 void ResizeLinear(const Mat &src, Mat &dst, int new_cols, int new_rows);
 
-// APD.h:34 -- consistency check + merge of the final depth maps into <dense>/APD/APD.ply (device fusion apd_fuse_views;
-// APD_FUSION=cpu in the environment selects the sequential host loop of host/fusion.cpp)
+// APD.h:34 -- consistency check + merge of the final depth maps into <dense>/APD/APD.ply (device fusion apd_fuse_views)
 void RunFusion(const path &dense_folder, const std::vector<Problem> &problems);
 void SetFusionDevice(int device);  // additive: HIP device of the fusion (default 0)
 

@@ -352,8 +352,7 @@ def save_results(folder, scene, results):
 
 def fuse(scene, results, ply_path, device=0):
     """RunFusion (APD.cpp:826-977) on the gathered maps: consistency check and merge into a binary PLY on GPU `device`
-    (apd_fuse_views, csrc/apd_fusion.hip; APD_FUSION=cpu in the environment runs the reference's sequential host loop
-    of host/fusion.cpp instead -- same file, byte for byte).  Every view must be at one resolution per view; images are
+    (apd_fuse_views, csrc/apd_fusion.hip).  Every view must be at one resolution per view; images are
     resampled to the depth-map size if it differs (RescaleImageAndCamera, APD.cpp:729-750).  Returns the number of points."""
     import ctypes as C
     L = host_lib()
@@ -394,4 +393,6 @@ def fuse(scene, results, ply_path, device=0):
         return (C.c_void_p * V)(*[a.ctypes.data for a in arrs])
 
     n = L.apdhost_fuse(V, C.byref(cams), ptrs(imgs), ptrs(deps), ptrs(nors), ptrs(weaks), rows, cols, offs, idx, str(ply_path).encode())
+    if n < 0:
+        raise RuntimeError("device fusion failed (apd_fuse_views): see stderr")
     return int(n)

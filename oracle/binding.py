@@ -66,10 +66,14 @@ def default_params(**kw):
     return p
 
 
+_FUSION_LIB_PATH = os.path.join(_HERE, "_build", "libapd_fusion_oracle.so")
+
+
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("apd_oracle.c", "apd_oracle.h")]
-    if (not force and os.path.exists(_LIB_PATH)
-            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+    src = [os.path.join(_HERE, f) for f in ("apd_oracle.c", "apd_oracle.h", "fusion_oracle.cpp", "Makefile")]
+    src.append(os.path.join(_HERE, "..", "apd-mvs_amd", "csrc", "apd_fusion_math.h"))
+    if (not force and os.path.exists(_LIB_PATH) and os.path.exists(_FUSION_LIB_PATH)
+            and all(min(os.path.getmtime(_LIB_PATH), os.path.getmtime(_FUSION_LIB_PATH)) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -262,3 +266,37 @@ class Oracle:
     def geom_cost(self, x, y, src, plane):
         p = (C.c_float * 4)(*[float(v) for v in plane])
         return lib().orc_geom_cost(self._h, x, y, src, p)
+
+
+def fuse(cameras, images, depths, normals, weaks, pairs, ply_path):
+    """The reference's sequential fusion loop (oracle/fusion_oracle.cpp, RunFusion APD.cpp:826-977) on host arrays:
+    cameras = ctypes array of Camera-compatible structs (one per view), images/depths float32 [H, W], normals float32
+    [H, W, 3], weaks uint8 [H, W], pairs[i] = source view indices of view i.  Writes `ply_path`, returns the point count."""
+    build()
+    L = C.CDLL(_FUSION_LIB_PATH)
+    L.orc_fuse.restype = C.c_longlong
+    V = len(images)
+    keep = []
+
+    def ptrs(arrs, dt):
+        out = (C.c_void_p * V)()
+        for i, a in enumerate(arrs):
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            out[i] = a.ctypes.data
+        return out
+
+    rows = (C.c_int * V)(*[d.shape[0] for d in depths])
+    cols = (C.c_int * V)(*[d.shape[1] for d in depths])
+    offs = (C.c_int * (V + 1))()
+    flat = []
+    for v in range(V):
+        offs[v] = len(flat)
+        flat += list(pairs[v])
+    offs[V] = len(flat)
+    idx = (C.c_int * max(len(flat), 1))(*flat)
+    n = L.orc_fuse(V, C.byref(cameras), ptrs(images, np.float32), ptrs(depths, np.float32), ptrs(normals, np.float32),
+                   ptrs(weaks, np.uint8), rows, cols, offs, idx, str(ply_path).encode())
+    if n < 0:
+        raise IOError("cannot write " + str(ply_path))
+    return int(n)

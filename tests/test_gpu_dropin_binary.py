@@ -256,17 +256,27 @@ def _fusion_inputs(synth, pipeline, pkg, W, H, nviews, nsrc, noise, seed):
 
 
 @pytest.mark.parametrize("W,H,nviews,nsrc,noise", [(160, 120, 5, 4, 0.0004), (333, 217, 7, 6, 0.0008)])
-def test_device_fusion_equals_the_sequential_host_loop(gpu_pkg, synth, tmp_path, monkeypatch, W, H, nviews, nsrc, noise):
+def test_device_fusion_equals_the_sequential_host_loop(gpu_pkg, ob, synth, tmp_path, W, H, nviews, nsrc, noise):
     """apd_fuse_views (GPU: per-view parallel votes + fixed-point resolution of the raster-order consumption) writes
-    the byte-identical APD.ply of the reference's sequential loop (host/fusion.cpp, APD_FUSION=cpu)."""
+    the byte-identical APD.ply of the reference's sequential loop (oracle/fusion_oracle.cpp)."""
+    import ctypes as C
     from apd_mvs_amd import pipeline
     scene, results = _fusion_inputs(synth, pipeline, gpu_pkg, W, H, nviews, nsrc, noise, seed=5)
-    monkeypatch.setenv("APD_FUSION", "cpu")
-    n_cpu = pipeline.fuse(scene, results, tmp_path / "cpu.ply")
-    monkeypatch.delenv("APD_FUSION")
+    cams = (type(scene.cameras[0]) * nviews)(*scene.cameras)
+    n_cpu = ob.fuse(cams, scene.images, [results[v].depth for v in range(nviews)], [results[v].normal for v in range(nviews)],
+                    [results[v].weak for v in range(nviews)], scene.pairs, tmp_path / "cpu.ply")
     n_gpu = pipeline.fuse(scene, results, tmp_path / "gpu.ply")
     assert n_cpu == n_gpu and n_cpu > 0.3 * W * H * nviews / (nsrc + 1)
     assert (tmp_path / "cpu.ply").read_bytes() == (tmp_path / "gpu.ply").read_bytes()
     # consumption did matter: fusing every view against fresh masks would give more points
     xyz, _ = _read_ply(tmp_path / "gpu.ply")
     assert len(xyz) < W * H * nviews
+    del C
+
+
+def test_device_fusion_refuses_a_view_that_is_its_own_source(gpu_pkg, synth, tmp_path):
+    from apd_mvs_amd import pipeline
+    scene, results = _fusion_inputs(synth, pipeline, gpu_pkg, 64, 48, 3, 2, 0.0004, seed=5)
+    scene.pairs[1] = [1, 0]
+    with pytest.raises(Exception):
+        pipeline.fuse(scene, results, tmp_path / "x.ply")
