@@ -114,3 +114,36 @@ def test_window_and_global_kernels_agree(gpu_pkg, synth, monkeypatch):
         runs[mode] = digests
         h.close()
     assert runs["1"] == runs["0"]
+
+
+def test_window_and_global_post_loop_kernels_agree(gpu_pkg, synth, monkeypatch):
+    """K14 DepthToWeak / K15 LocalRefine with LDS source windows (apd_kernels_k1415w.hip, default) against the
+    window-less kernels (APD_K1415_WINDOW=0): identical weak map and depths after a complete pass, photometric and with
+    the geometric term, at a size the oracle cannot reach."""
+    import torch
+    W, H, N = 1280, 960, 5
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("APD_K1415_WINDOW", mode)
+        sc = synth.make_scene(W, H, N, seed=4, device="cuda", textureless=0.15)
+        cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+        dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
+        digests = []
+        prior = None
+        for state, geom in ((gpu_pkg.FIRST_INIT, 0), (gpu_pkg.REFINE_ITER, 1)):
+            p = gpu_pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0, state=state, max_iterations=2,
+                                       weak_peak_radius=6, geom_consistency=geom, seed=77)
+            h = gpu_pkg.Handle(W, H, p, device=0)
+            deps = [sc.gt_depth] * (N + 1) if geom else None   # stand-in depth maps of the sources
+            h.upload_views(cams, sc.images, deps)
+            if prior is not None:
+                h.upload_prior(*prior)
+            h.run()
+            planes, weak, views = h.download()
+            digests.append(_digest([planes, weak, views]))
+            prior = common.postprocess(planes, weak, views, np.float32(dmin), np.float32(dmax))
+            h.close()
+        out[mode] = digests
+        del sc
+        torch.cuda.empty_cache()
+    assert out["1"] == out["0"]
