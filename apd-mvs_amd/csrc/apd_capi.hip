@@ -19,6 +19,7 @@ hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipS
 hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s);
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s);
 hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipStream_t s);
+hipError_t launch_pack_fquads(const float *img, int W, int H, fquad_t *fq, hipStream_t s);
 }  // namespace apd
 
 using apd::FrameArgs;
@@ -59,6 +60,7 @@ struct apd_context {
     std::vector<float *> images;
     std::vector<float *> depths;
     std::vector<apd::quad_t *> quads;
+    std::vector<apd::fquad_t *> fquads;
     int *flag_dev = nullptr;
     bool use_quads = false;
     ViewConst *views_dev = nullptr;
@@ -271,6 +273,9 @@ int apd_destroy(apd_handle c)
     for (apd::quad_t *p : c->quads) {
         hipFree(p);
     }
+    for (apd::fquad_t *p : c->fquads) {
+        hipFree(p);
+    }
     hipFree(c->flag_dev);
     hipFree(c->views_dev);
     hipFree(c->planes);
@@ -336,6 +341,10 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     for (apd::quad_t *p : c->quads) {
         hipFree(p);
     }
+    for (apd::fquad_t *p : c->fquads) {
+        hipFree(p);
+    }
+    c->fquads.assign(num_images, nullptr);
     c->images.assign(num_images, nullptr);
     c->depths.assign(num_images, nullptr);
     c->quads.assign(num_images, nullptr);
@@ -367,6 +376,16 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     HIP_TRY(hipMemcpyAsync(&all_u8, c->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->use_quads = all_u8 != 0 && getenv("APD_NO_QUADS") == nullptr;
+    if (!c->use_quads) {  // float grey values (e.g. a resampled pyramid level): float texel quads of the source views
+        const size_t fn = (size_t)(c->W + 1) * (c->H + 1);
+        for (int i = 1; i < num_images; ++i) {
+            HIP_TRY(hipMalloc(&c->fquads[i], fn * sizeof(apd::fquad_t)));
+            hipError_t e = apd::launch_pack_fquads(c->images[i], c->W, c->H, c->fquads[i], c->stream);
+            if (e != hipSuccess) {
+                return fail(APD_ERR_HIP, "k_pack_fquads failed: %s", hipGetErrorString(e));
+            }
+        }
+    }
     if (c->use_quads) {
         const size_t qn = (size_t)(c->W + 1) * (c->H + 1);
         for (int i = 1; i < num_images; ++i) {
@@ -407,6 +426,7 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         vc.img = c->images[v + 1];
         vc.depth = c->depths[v + 1];
         vc.quad = c->quads[v + 1];
+        vc.fquad = c->fquads[v + 1];
     }
     HIP_TRY(hipMemcpyAsync(c->views_dev, vcs.data(), vcs.size() * sizeof(ViewConst), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

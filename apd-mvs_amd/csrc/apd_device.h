@@ -32,6 +32,13 @@ constexpr int kQuadShift = 2;
 #endif
 constexpr unsigned kQuadBytes = 1u << kQuadShift;
 
+// One texel pair: the texel and the (rounded) difference to its right neighbour -- the two numbers the horizontal
+// lerp fmaf(a, t10 - t00, t00) needs, as binary32.  A float texel quad is the pair of a texel and the pair of the texel
+// below it: same taps, same three fused multiply-adds as a four-tap float sampler, one 16-byte gather instead of four
+// 4-byte ones and no subtractions in the sample loop.
+typedef float pair_t __attribute__((ext_vector_type(2)));
+typedef float fquad_t __attribute__((ext_vector_type(4)));
+
 // Per source view constants.  Rr/tr are the plane-independent part of ComputeHomography
 // (APD.cu:305-331) hoisted to the host once per (reference, source) pair; the kernels read them
 // through wave-uniform (scalar) loads.
@@ -50,6 +57,11 @@ struct ViewConst {
     // scale 1): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], holds the four clamped taps
     // {I(qx,qy), I(qx+1,qy), I(qx,qy+1), I(qx+1,qy+1)} of one bilinear fetch (quad_t below).
     const quad_t *quad;  // (H+1)*(W+1) entries or nullptr
+    // Float texel-quad image (every other input: float grey values, e.g. the resampled images of the coarse pyramid
+    // levels, APD.cpp:474): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], holds the two texel pairs
+    // {I(qx,qy), I(qx+1,qy) - I(qx,qy), I(qx,qy+1), I(qx+1,qy+1) - I(qx,qy+1)} with clamped coordinates (fquad_t below):
+    // one 16-byte gather per bilinear fetch.
+    const fquad_t *fquad;  // (H+1)*(W+1) entries or nullptr
 };
 
 struct FrameArgs {
@@ -425,6 +437,13 @@ __device__ __forceinline__ float sample_bilinear(Ptr img, int W, int H, float sx
 // struct would otherwise be "generic" and cost flat_load + 64-bit address arithmetic per gather).
 typedef const __attribute__((address_space(1))) quad_t *global_quad_ptr;
 typedef const __attribute__((address_space(1))) float *global_f32_ptr;
+typedef const __attribute__((address_space(1))) pair_t *global_pair_ptr;
+typedef const __attribute__((address_space(1))) fquad_t *global_fquad_ptr;
+
+__device__ __forceinline__ fquad_t fquad_fetch(global_fquad_ptr fq, unsigned off)
+{
+    return *(global_fquad_ptr)((const __attribute__((address_space(1))) char *)fq + off);
+}
 
 // Same fetch from the texel-quad image: one gather instead of four.  Bit-identical to
 // sample_bilinear on 8-bit data (the taps are the same floats, the lerp is the same three fmaf).
@@ -557,6 +576,15 @@ __device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float 
 // computed in lock step: every stage below is six independent instructions, and the scheduler is not
 // allowed to re-serialise the chains to save registers.
 #define APD_STAGE() __builtin_amdgcn_sched_barrier(0)
+
+// byte offset of a 16-byte float quad entry (qx, qy): qy*pitch + (pitch + 16) + 16*qx with pitch = (W+1)*16 bytes
+__device__ __forceinline__ unsigned fquad_byte_offset(int qx, int qy, int pitch, int origin)
+{
+    int row, off;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(pitch), "v"(origin));
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(off) : "v"(qx), "v"(row));
+    return (unsigned)off;
+}
 
 // Sample positions of one patch row (fixed x, six y) -> bilinear weights + texel-quad gathers in flight.
 template <bool kFastRecip>
@@ -691,6 +719,95 @@ __device__ __forceinline__ void quad_row_lerp(const quad_t (&t)[kPatchN], const 
     }
 }
 
+// The same two stages for float texel-quad images (float grey values).
+template <bool kFastRecip>
+__device__ __forceinline__ void fquad_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN],
+                                                global_fquad_ptr fq, unsigned pitch, int wm1, int hm1, float (&a)[kPatchN],
+                                                float (&b)[kPatchN], fquad_t (&t)[kPatchN])
+{
+    float z[kPatchN], X[kPatchN], Y[kPatchN], r[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        z[j] = fmaf(H.h[7], yf[j], bz);
+        X[j] = fmaf(H.h[1], yf[j], bx);
+        Y[j] = fmaf(H.h[4], yf[j], by);
+    }
+    APD_STAGE();
+    if (kFastRecip) {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = __builtin_amdgcn_rcpf(z[j]);
+        }
+        APD_STAGE();
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            z[j] = fmaf(-z[j], r[j], 1.0f);
+        }
+        APD_STAGE();
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = fmaf(z[j], r[j], r[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = 1.0f / z[j];
+        }
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        X[j] *= r[j];
+        Y[j] *= r[j];
+    }
+    APD_STAGE();
+    int qx[kPatchN], qy[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        a[j] = __builtin_amdgcn_fractf(X[j]);
+        b[j] = __builtin_amdgcn_fractf(Y[j]);
+        qx[j] = cvt_floor_i32(X[j]);
+        qy[j] = cvt_floor_i32(Y[j]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        qx[j] = med3_i32(qx[j], -1, wm1);
+        qy[j] = med3_i32(qy[j], -1, hm1);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        qx[j] = (int)fquad_byte_offset(qx[j], qy[j], (int)pitch, (int)(pitch + 16u));
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        t[j] = fquad_fetch(fq, (unsigned)qx[j]);
+    }
+}
+
+__device__ __forceinline__ void fquad_row_lerp(const fquad_t (&t)[kPatchN], const float (&a)[kPatchN], const float (&b)[kPatchN],
+                                               float (&v)[kPatchN])
+{
+    float top[kPatchN], bot[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        top[j] = fmaf(a[j], t[j].y, t[j].x);
+        bot[j] = fmaf(a[j], t[j].w, t[j].z);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        bot[j] -= top[j];
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        v[j] = fmaf(b[j], bot[j], top[j]);
+    }
+}
+
 // The 36 warped source samples of one fixed patch and their three moments (APD.cu:561-583), summed in the
 // reference's order (row partial sums, then total).  kFastRecip: every denominator is known to be in the
 // range where recip_fast is the correctly rounded reciprocal.
@@ -708,10 +825,11 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     const Homography &H = H_in;
     const int px = px_in, py = py_in;
 #endif
-    const global_f32_ptr src = (global_f32_ptr)vc.img;
     const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
     const int W = fa.W, Hh = fa.H;
     const unsigned qpitch = kQuadBytes * (unsigned)(W + 1);
+    const unsigned fpitch = 16u * (unsigned)(W + 1);
+    const global_fquad_ptr srcf = (global_fquad_ptr)vc.fquad;
     const int wm1 = W - 1, hm1 = Hh - 1;
     float yf[kPatchN];
 #pragma unroll
@@ -728,39 +846,36 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
 #endif
     constexpr int kDepth = APD_ROW_PREFETCH, kBuf = kDepth + 1;
     float a[kBuf][kPatchN], b[kBuf][kPatchN];
-    quad_t t[kBuf][kPatchN];
-    if (kQuad) {
+    quad_t t[kQuad ? kBuf : 1][kPatchN];
+    fquad_t tf[kQuad ? 1 : kBuf][kPatchN];
 #pragma unroll
-        for (int r = 0; r < kDepth; ++r) {
-            const float xf = (float)(px + kPatchStep * r - kPatchRadius);
-            quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq, qpitch,
-                                       wm1, hm1, a[r], b[r], t[r]);
+    for (int r = 0; r < kDepth; ++r) {
+        const float xf = (float)(px + kPatchStep * r - kPatchRadius);
+        const float bx = fmaf(H.h[0], xf, H.h[2]), by = fmaf(H.h[3], xf, H.h[5]), bz = fmaf(H.h[6], xf, H.h[8]);
+        if constexpr (kQuad) {
+            quad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[r], b[r], t[r]);
+        } else {
+            fquad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcf, fpitch, wm1, hm1, a[r], b[r], tf[r]);
         }
     }
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
         float v[kPatchN];
-        if (kQuad) {
-            if (i + kDepth < kPatchN) {
-                const float xf = (float)(px + kPatchStep * (i + kDepth) - kPatchRadius);
-                quad_row_issue<kFastRecip>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, srcq,
-                                           qpitch, wm1, hm1, a[(i + kDepth) % kBuf], b[(i + kDepth) % kBuf], t[(i + kDepth) % kBuf]);
+        if (i + kDepth < kPatchN) {
+            const int n = (i + kDepth) % kBuf;
+            const float xf = (float)(px + kPatchStep * (i + kDepth) - kPatchRadius);
+            const float bx = fmaf(H.h[0], xf, H.h[2]), by = fmaf(H.h[3], xf, H.h[5]), bz = fmaf(H.h[6], xf, H.h[8]);
+            if constexpr (kQuad) {
+                quad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[n], b[n], t[n]);
+            } else {
+                fquad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcf, fpitch, wm1, hm1, a[n], b[n], tf[n]);
             }
-            APD_STAGE();
+        }
+        APD_STAGE();
+        if constexpr (kQuad) {
             quad_row_lerp(t[i % kBuf], a[i % kBuf], b[i % kBuf], v);
         } else {
-            const float xf = (float)(px + kPatchStep * i - kPatchRadius);
-            const float bx = fmaf(H.h[0], xf, H.h[2]);
-            const float by = fmaf(H.h[3], xf, H.h[5]);
-            const float bz = fmaf(H.h[6], xf, H.h[8]);
-#pragma unroll
-            for (int j = 0; j < kPatchN; ++j) {
-                const float z = fmaf(H.h[7], yf[j], bz);
-                const float inv = kFastRecip ? recip_fast(z) : 1.0f / z;
-                const float sx = fmaf(H.h[1], yf[j], bx) * inv;
-                const float sy = fmaf(H.h[4], yf[j], by) * inv;
-                v[j] = sample_bilinear(src, W, Hh, sx, sy);
-            }
+            fquad_row_lerp(tf[i % kBuf], a[i % kBuf], b[i % kBuf], v);
         }
         float ref[kPatchN];
 #pragma unroll
@@ -939,6 +1054,112 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
             row_s += val;
             row_ss = fmaf(val, val, row_ss);
             row_rs = fmaf(ref, val, row_rs);
+        }
+        sum_s += row_s;
+        sum_ss += row_ss;
+        sum_rs += row_rs;
+    }
+    const float inv_w = 1.0f / 9.0f;
+    sum_s *= inv_w;
+    sum_ss *= inv_w;
+    sum_rs *= inv_w;
+    const float var_s = fmaf(-sum_s, sum_s, sum_ss);
+    const float kMinVar = 1e-5f;
+    if (var_r < kMinVar || var_s < kMinVar) {
+        return 2.0f;
+    }
+    const float covar = fmaf(-mean_r, sum_s, sum_rs);
+    const float denom = sqrtf(var_r * var_s);
+    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+}
+
+// The same sub-patch on a float texel-quad image (float grey values); ref[i * 3 + j] is read with stride `ref_stride` floats.
+__device__ __forceinline__ float subpatch_cost_fquad(const Homography &H, global_fquad_ptr fq, unsigned fpitch, int wm1, int hm1,
+                                                     int cx, int cy, const float *ref, int ref_stride, float mean_r, float var_r)
+{
+    constexpr int N = kSubN * kSubN;
+    float z[N], X[N], Y[N], r[N];
+#pragma unroll
+    for (int i = 0; i < kSubN; ++i) {
+        const float xf = (float)(cx + kSubStep * (i - 1));
+        const float bx = fmaf(H.h[0], xf, H.h[2]);
+        const float by = fmaf(H.h[3], xf, H.h[5]);
+        const float bz = fmaf(H.h[6], xf, H.h[8]);
+#pragma unroll
+        for (int j = 0; j < kSubN; ++j) {
+            const float yf = (float)(cy + kSubStep * (j - 1));
+            z[i * kSubN + j] = fmaf(H.h[7], yf, bz);
+            X[i * kSubN + j] = fmaf(H.h[1], yf, bx);
+            Y[i * kSubN + j] = fmaf(H.h[4], yf, by);
+        }
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        r[k] = __builtin_amdgcn_rcpf(z[k]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        z[k] = fmaf(-z[k], r[k], 1.0f);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        r[k] = fmaf(z[k], r[k], r[k]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        X[k] *= r[k];
+        Y[k] *= r[k];
+    }
+    APD_STAGE();
+    float a[N], b[N];
+    int qx[N], qy[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        a[k] = __builtin_amdgcn_fractf(X[k]);
+        b[k] = __builtin_amdgcn_fractf(Y[k]);
+        qx[k] = cvt_floor_i32(X[k]);
+        qy[k] = cvt_floor_i32(Y[k]);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        qx[k] = med3_i32(qx[k], -1, wm1);
+        qy[k] = med3_i32(qy[k], -1, hm1);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        qx[k] = (int)fquad_byte_offset(qx[k], qy[k], (int)fpitch, (int)(fpitch + 16u));
+    }
+    APD_STAGE();
+    fquad_t t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        t[k] = fquad_fetch(fq, (unsigned)qx[k]);
+    }
+    APD_STAGE();
+    float v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float top = fmaf(a[k], t[k].y, t[k].x);
+        const float bot = fmaf(a[k], t[k].w, t[k].z);
+        v[k] = fmaf(b[k], bot - top, top);
+    }
+    float sum_s = 0.0f, sum_ss = 0.0f, sum_rs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kSubN; ++i) {
+        float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kSubN; ++j) {
+            const float val = v[i * kSubN + j];
+            const float rf = ref[(i * kSubN + j) * ref_stride];
+            row_s += val;
+            row_ss = fmaf(val, val, row_ss);
+            row_rs = fmaf(rf, val, row_rs);
         }
         sum_s += row_s;
         sum_ss += row_ss;

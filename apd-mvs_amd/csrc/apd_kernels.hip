@@ -707,6 +707,25 @@ __global__ __launch_bounds__(256) void k_pack_quads(const float *__restrict__ im
 #endif
 }
 
+// float texel quads of a float image: entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1] (clamped coordinates)
+__global__ __launch_bounds__(256) void k_pack_fquads(const float *__restrict__ img, int W, int H, fquad_t *__restrict__ fq)
+{
+    const int qx = blockIdx.x * 32 + (threadIdx.x & 31);  // 0..W  <-> image x = qx - 1
+    const int qy = blockIdx.y * 8 + (threadIdx.x >> 5);   // 0..H  <-> image y = qy - 1
+    if (qx > W || qy > H) {
+        return;
+    }
+    const float t00 = fetch_texel(img, W, H, qx - 1, qy - 1), t10 = fetch_texel(img, W, H, qx, qy - 1);
+    const float t01 = fetch_texel(img, W, H, qx - 1, qy), t11 = fetch_texel(img, W, H, qx, qy);
+    fq[(size_t)qy * (W + 1) + qx] = fquad_t{t00, t10 - t00, t01, t11 - t01};
+}
+
+hipError_t launch_pack_fquads(const float *img, int W, int H, fquad_t *fq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pack_fquads, dim3((W + 1 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, fq);
+    return hipGetLastError();
+}
+
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s)
 {
     hipLaunchKernelGGL(k_check_u8, dim3((n + 255) / 256), dim3(256), 0, s, img, n, flag);
@@ -782,7 +801,7 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
     case APD_K6_BLACK_UPDATE_STRONG:
     case APD_K7_RED_UPDATE_STRONG: {
         const int colour = (kernel_id == APD_K6_BLACK_UPDATE_STRONG) ? 0 : 1;
-        if (fa.use_quads && k67_window_enabled()) {
+        if (k67_window_enabled()) {
             return launch_k67_windowed(fa, colour, iter, s);
         }
         if (fa.num_src <= 8) {
@@ -803,7 +822,7 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
                            (kernel_id == APD_K12_BLACK_FILTER) ? 0 : 1);
         break;
     case APD_K14_DEPTH_TO_WEAK:
-        if (fa.use_quads && k1415_window_enabled()) {
+        if (k1415_window_enabled()) {
             return launch_k14_windowed(fa, s);
         }
         if (fa.use_quads) {
@@ -813,7 +832,7 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
         }
         break;
     case APD_K15_LOCAL_REFINE:
-        if (fa.use_quads && k1415_window_enabled()) {
+        if (k1415_window_enabled()) {
             return launch_k15_windowed(fa, s);
         }
         if (fa.use_quads) {

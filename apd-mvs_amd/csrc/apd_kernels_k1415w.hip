@@ -22,7 +22,10 @@ constexpr int kFwPitch = kFwLds + 1;                       // 27
 #ifndef APD_K14_WIN_H
 #define APD_K14_WIN_H 32  // rows of fetch positions: 8 + 2 * (patch radius 5 + 7 texels of slack)
 #endif
-constexpr int kK14WinH = APD_K14_WIN_H;
+#ifndef APD_K14_WIN_H_F32
+#define APD_K14_WIN_H_F32 32
+#endif
+template <bool kQuad> constexpr int k14_win_h() { return kQuad ? APD_K14_WIN_H : APD_K14_WIN_H_F32; }
 #ifndef APD_K14_CHUNK
 #define APD_K14_CHUNK 8  // depth samples per staged window (K14 ms at 4096x3072, 8 views: 4: 144.7, 6: 138.8, 8: 135.6, 16: 140.6, 31: 161.1)
 #endif
@@ -83,6 +86,7 @@ __device__ __forceinline__ int fw_baseline_and_weight(const FrameArgs &fa, uint3
 }
 
 // Window of view vc around where the pixels of the wave land when their planes are (origin normal, distance w).
+template <bool kQuad>
 __device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, bool use, int px, int py,
                                               const float4 origin, float w)
 {
@@ -97,7 +101,7 @@ __device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewCon
         correspond(H, (float)px, (float)py, cx, cy);
         ok = cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf;  // false for NaN
     }
-    return stage_window_around<kK14WinH>(fa, vc, win, ok, cx, cy);
+    return stage_window_around<kQuad, k14_win_h<kQuad>()>(fa, vc, win, ok, cx, cy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -110,10 +114,14 @@ __device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewCon
 #ifndef APD_K15W_WAVES
 #define APD_K15W_WAVES 3  // 4 waves/SIMD (100 VGPRs spilled) 30.5, 3 waves 27.1
 #endif
-__global__ __launch_bounds__(256, APD_K14W_WAVES) void k14w_depth_to_weak(FrameArgs fa)
+#ifndef APD_K1415W_WAVES_F32
+#define APD_K1415W_WAVES_F32 2  // float windows: 16.9 KB per wave, two workgroups per CU
+#endif
+template <bool kQuad>
+__global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32) void k14w_depth_to_weak(FrameArgs fa)
 {
     __shared__ float tile[kFwLds * kFwPitch];
-    __shared__ uint32_t windows[4][window_entries(kK14WinH)];
+    __shared__ uint32_t windows[4][window_dwords(kQuad, k14_win_h<kQuad>())];
     int px, py;
     fw_pixel(px, py);
     const RefPatchLds<kFwPitch> rp = fw_stage_ref(fa, tile, px, py);
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, APD_K14W_WAVES) void k14w_depth_to_weak(FrameA
                 continue;  // nobody has a sample to score in this chunk
             }
             const int mid = (c0 + c1) >> 1;
-            const SrcWindow w = fw_stage(fa, vc, win, use && ((in_range >> mid) & 1ull) != 0, px, py, origin, pw[mid]);
+            const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use && ((in_range >> mid) & 1ull) != 0, px, py, origin, pw[mid]);
 #pragma unroll 1
             for (int i = c0; i < c1; ++i) {
                 if (use && ((in_range >> i) & 1ull)) {
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256, APD_K14W_WAVES) void k14w_depth_to_weak(FrameA
                     float qx, qy, qz;
                     plane_q(pl, qx, qy, qz);
                     float tc = 0.0f;
-                    tc += ncc_fixed_windowed(fa, vc, w, rp, px, py, qx, qy, qz);
+                    tc += ncc_fixed_windowed<kQuad>(fa, vc, w, rp, px, py, qx, qy, qz);
                     if (fa.geom_consistency) {
                         tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
                     }
@@ -259,10 +267,11 @@ __global__ __launch_bounds__(256, APD_K14W_WAVES) void k14w_depth_to_weak(FrameA
 // K15
 // ------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256, APD_K15W_WAVES) void k15w_local_refine(FrameArgs fa)
+template <bool kQuad>
+__global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32) void k15w_local_refine(FrameArgs fa)
 {
     __shared__ float tile[kFwLds * kFwPitch];
-    __shared__ uint32_t windows[4][window_entries(kK14WinH)];
+    __shared__ uint32_t windows[4][window_dwords(kQuad, k14_win_h<kQuad>())];
     int px, py;
     fw_pixel(px, py);
     const RefPatchLds<kFwPitch> rp = fw_stage_ref(fa, tile, px, py);
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256, APD_K15W_WAVES) void k15w_local_refine(FrameAr
         }
         const ViewConst &vc = fa.views[v];
         const float wv = (float)vw.get(v);
-        const SrcWindow w = fw_stage(fa, vc, win, use, px, py, origin, w_now);
+        const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use, px, py, origin, w_now);
         // sample -1: the current depth with K14's cost form (:2173-2183); samples 0..10: LocalRefine's (:2217-2220)
 #pragma unroll 1
         for (int i = -1; i < NP; ++i) {
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(256, APD_K15W_WAVES) void k15w_local_refine(FrameAr
                 pl.w = (i < 0) ? w_now : pw[i];
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                const float c = ncc_fixed_windowed(fa, vc, w, rp, px, py, qx, qy, qz);
+                const float c = ncc_fixed_windowed<kQuad>(fa, vc, w, rp, px, py, qx, qy, qz);
                 if (i < 0) {
                     float tc = 0.0f;
                     tc += c;
@@ -371,13 +380,23 @@ __global__ __launch_bounds__(256, APD_K15W_WAVES) void k15w_local_refine(FrameAr
 
 hipError_t launch_k14_windowed(const FrameArgs &fa, hipStream_t s)
 {
-    hipLaunchKernelGGL(k14w_depth_to_weak, dim3((fa.W + kFwTile - 1) / kFwTile, (fa.H + kFwTile - 1) / kFwTile), dim3(256), 0, s, fa);
+    const dim3 grid((fa.W + kFwTile - 1) / kFwTile, (fa.H + kFwTile - 1) / kFwTile);
+    if (fa.use_quads) {
+        hipLaunchKernelGGL(k14w_depth_to_weak<true>, grid, dim3(256), 0, s, fa);
+    } else {
+        hipLaunchKernelGGL(k14w_depth_to_weak<false>, grid, dim3(256), 0, s, fa);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_k15_windowed(const FrameArgs &fa, hipStream_t s)
 {
-    hipLaunchKernelGGL(k15w_local_refine, dim3((fa.W + kFwTile - 1) / kFwTile, (fa.H + kFwTile - 1) / kFwTile), dim3(256), 0, s, fa);
+    const dim3 grid((fa.W + kFwTile - 1) / kFwTile, (fa.H + kFwTile - 1) / kFwTile);
+    if (fa.use_quads) {
+        hipLaunchKernelGGL(k15w_local_refine<true>, grid, dim3(256), 0, s, fa);
+    } else {
+        hipLaunchKernelGGL(k15w_local_refine<false>, grid, dim3(256), 0, s, fa);
+    }
     return hipGetLastError();
 }
 

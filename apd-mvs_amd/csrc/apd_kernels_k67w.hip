@@ -33,6 +33,7 @@ constexpr int kWinH = APD_WIN_H;
 // `trusted`: the pixel's plane already explains the images (low cost).  While the planes are still converging the
 // bounding box of all projections is useless (one wild plane moves its centre anywhere), so the box is taken over the
 // trusted pixels when there are any.
+template <bool kQuad>
 __device__ __forceinline__ SrcWindow stage_window(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, bool alive, int px, int py,
                                                   const float4 plane, bool trusted)
 {
@@ -50,7 +51,7 @@ __device__ __forceinline__ SrcWindow stage_window(const FrameArgs &fa, const Vie
         ok = ok && trusted;
     }
 #endif
-    return stage_window_around<kWinH>(fa, vc, win, ok, cx, cy);
+    return stage_window_around<kQuad, kWinH>(fa, vc, win, ok, cx, cy);
 }
 
 // Cheapest candidate of propagation arm `arm` (order of APD.cu:1020: near/far x up,down,left,right).
@@ -114,11 +115,14 @@ constexpr float kTrustedCost = APD_WIN_TRUST;
 #ifndef APD_K67W_WAVES
 #define APD_K67W_WAVES 4
 #endif
-template <int NMAX>
-__global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameArgs fa, int colour, int iter)
+#ifndef APD_K67W_WAVES_F32
+#define APD_K67W_WAVES_F32 3  // float windows are twice the size: three workgroups per CU
+#endif
+template <int NMAX, bool kQuad>
+__global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) void k67w_update_strong(FrameArgs fa, int colour, int iter)
 {
     __shared__ float tile[kLdsH * kLdsPitch];
-    __shared__ uint32_t windows[4][window_entries(kWinH)];
+    __shared__ uint32_t windows[4][window_dwords(kQuad, kWinH)];
     const TilePixel t = checkerboard_pixel(fa, colour);
     // stage the reference tile + 5 px halo (clamp-to-edge, as the texture unit would)
     for (int idx = threadIdx.x; idx < kLdsW * kLdsH; idx += 256) {
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
         const ViewConst &vc = fa.views[v];
-        const SrcWindow w = stage_window(fa, vc, win, alive, px, py, plane_now, trusted);
+        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted);
         if (alive) {
 #pragma unroll 1
             for (int h = 0; h < 9; ++h) {
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
                 const float4 pl = (h < 8) ? fa.planes[positions[h]] : plane_now;
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                cost_array[h][v] = ncc_fixed_windowed(fa, vc, w, rp, px, py, qx, qy, qz);
+                cost_array[h][v] = ncc_fixed_windowed<kQuad>(fa, vc, w, rp, px, py, qx, qy, qz);
             }
         }
     }
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
             continue;  // nobody in the wave selected this view
         }
         const ViewConst &vc = fa.views[v];
-        const SrcWindow w = stage_window(fa, vc, win, alive, px, py, plane_now, trusted);
+        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted);
         if (wv > 0) {
 #pragma unroll 1
             for (int k = 0; k < 5; ++k) {
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
                 pl.w = ref_w[k];
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                tc[k] += (float)wv * ncc_fixed_windowed(fa, vc, w, rp, px, py, qx, qy, qz);
+                tc[k] += (float)wv * ncc_fixed_windowed<kQuad>(fa, vc, w, rp, px, py, qx, qy, qz);
             }
         }
     }
@@ -319,15 +323,25 @@ __global__ __launch_bounds__(256, APD_K67W_WAVES) void k67w_update_strong(FrameA
 }
 
 
+template <bool kQuad>
+static void launch_k67w(const FrameArgs &fa, int tiles, int colour, int iter, hipStream_t s)
+{
+    if (fa.num_src <= 8) {
+        hipLaunchKernelGGL((k67w_update_strong<8, kQuad>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    } else if (fa.num_src <= 16) {
+        hipLaunchKernelGGL((k67w_update_strong<16, kQuad>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    } else {
+        hipLaunchKernelGGL((k67w_update_strong<32, kQuad>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    }
+}
+
 hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
     const int tiles = ((fa.W + kTileW - 1) / kTileW) * ((fa.H + kTileH - 1) / kTileH);
-    if (fa.num_src <= 8) {
-        hipLaunchKernelGGL((k67w_update_strong<8>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
-    } else if (fa.num_src <= 16) {
-        hipLaunchKernelGGL((k67w_update_strong<16>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    if (fa.use_quads) {
+        launch_k67w<true>(fa, tiles, colour, iter, s);
     } else {
-        hipLaunchKernelGGL((k67w_update_strong<32>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+        launch_k67w<false>(fa, tiles, colour, iter, s);
     }
     return hipGetLastError();
 }

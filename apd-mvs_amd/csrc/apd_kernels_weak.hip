@@ -439,13 +439,16 @@ __global__ __launch_bounds__(256) void k8_ransac_fit_plane(FrameArgs fa)
 // Per-pixel, hypothesis-independent data of the eight neighbours lives in LDS ([slot][lane], so a wave
 // reads consecutive banks): position, the nine reference texels of the 3x3 sub-patch (texel-quad mode:
 // bytes, three per dword) and their mean / variance in the reference's summation order.
-struct WeakLds {
+template <bool kQuad>
+struct WeakLdsT {
     int nb[8][64];            // x | y << 16, -1 = empty slot
-    uint32_t ref[8][kSubN][64];
+    // reference texels of the 3x3 sub-patches: texel-quad mode three per dword (bytes), else nine floats
+    typename std::conditional<kQuad, uint32_t[8][kSubN][64], float[8][kSubN * kSubN][64]>::type ref;
     float mean[8][64];
     float var[8][64];
-    uint32_t centre[kPatchN * kPatchN / 4][64];  // texel-quad mode: the pixel's own 36 reference texels as bytes
+    uint32_t centre[kQuad ? kPatchN * kPatchN / 4 : 1][64];  // texel-quad mode: the pixel's own 36 reference texels as bytes
 };
+typedef WeakLdsT<true> WeakLds;
 
 // The pixel's own 6x6 reference patch kept as bytes in LDS (texel-quad mode: every texel is an integer 0..255):
 // frees 36 VGPRs per lane in the register-hungry weak kernel.  Same interface as RefPatch / RefPatchLds.
@@ -474,7 +477,7 @@ __device__ __forceinline__ RefPatchBytes ref_patch_to_lds(const RefPatch &rp, We
 }
 
 template <bool kQuad>
-__device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, const short2 *nb, WeakLds &lds, int lane)
+__device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, const short2 *nb, WeakLdsT<kQuad> &lds, int lane)
 {
     const int W = fa.W, H = fa.H;
 #pragma unroll 1
@@ -482,7 +485,7 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
         const short2 q = nb[k + 1];
         const bool valid = !(q.x == -1 || q.y == -1);
         lds.nb[k][lane] = valid ? ((int)(unsigned short)q.x | ((int)q.y << 16)) : -1;
-        if (!valid || !kQuad) {
+        if (!valid) {
             continue;
         }
         float sum_r = 0.0f, sum_rr = 0.0f;
@@ -495,11 +498,17 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
                 const float r = fetch_texel(fa.ref_img, W, H, q.x + kSubStep * (i - 1), q.y + kSubStep * (j - 1));
                 row_r += r;
                 row_rr = fmaf(r, r, row_rr);
-                packed |= (uint32_t)r << (8 * j);
+                if constexpr (kQuad) {
+                    packed |= (uint32_t)r << (8 * j);
+                } else {
+                    lds.ref[k][i * kSubN + j][lane] = r;
+                }
             }
             sum_r += row_r;
             sum_rr += row_rr;
-            lds.ref[k][i][lane] = packed;
+            if constexpr (kQuad) {
+                lds.ref[k][i][lane] = packed;
+            }
         }
         const float inv_w = 1.0f / 9.0f;
         sum_r *= inv_w;
@@ -510,7 +519,7 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
 }
 
 template <bool kQuad, typename Ref>
-__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLds &lds,
+__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLdsT<kQuad> &lds,
                                               int lane, int px, int py, const float4 pl)
 {
     float qx, qy, qz;
@@ -529,6 +538,8 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
 #endif
     const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
     const unsigned qpitch = kQuadBytes * (unsigned)(fa.W + 1);
+    const unsigned fpitch = 16u * (unsigned)(fa.W + 1);
+    const global_fquad_ptr srcf = (global_fquad_ptr)vc.fquad;
     const int wm1 = fa.W - 1, hm1 = fa.H - 1;
     float strong_cost = 0.0f;
     int strong_count = 0;
@@ -553,9 +564,14 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
             continue;
         }
         float c;
-        if (kQuad && denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep))) {
-            const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-            c = subpatch_cost_quad(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+        if (denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep))) {
+            if constexpr (kQuad) {
+                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
+                c = subpatch_cost_quad(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+            } else {
+                c = subpatch_cost_fquad(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
+                                        lds.var[k][lane]);
+            }
         } else {
             c = patch_cost_generic(fa, vc, H, nbx, nby, 5, 5);
         }
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(64) void k_compact_weak(FrameArgs fa, int colour, i
 template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, const int *__restrict__ count)
 {
-    __shared__ WeakLds lds;
+    __shared__ WeakLdsT<kQuad> lds;
 #ifdef APD_EXPERIMENT_K910_LDS_PAD  // timing experiment only: KiB of unused LDS per wave to cap the waves per CU
     __shared__ char lds_pad[APD_EXPERIMENT_K910_LDS_PAD * 1024];
     if (blockIdx.x == 0x7fffffff) {

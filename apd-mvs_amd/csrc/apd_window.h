@@ -1,4 +1,4 @@
-// apd_window.h -- per-wave LDS windows of a source view's texel-quad image and the fixed-patch NCC that reads them
+// apd_window.h -- per-wave LDS windows of a source view's texel-quad / texel-pair image and the fixed-patch NCC that reads them
 // (used by the K6/K7 and K14/K15 window kernels; see apd_kernels_k67w.hip for the why).
 #pragma once
 
@@ -8,14 +8,27 @@
 
 namespace apd {
 
-// Window geometry.  One entry per texel (qx, qy): the binary16 pair {I(qx,qy), I(qx+1,qy) - I(qx,qy)} (integers up to 255 and
-// their differences are exact in binary16).  A bilinear fetch at (qx, qy) reads the entries (qx, qy) and (qx, qy + 1) with one
-// two-address LDS read and lerps each pair with one v_fma_mix_f32: 4 VALU instructions instead of the 10 of the byte quads,
-// same taps, same three fused multiply-adds.  The pitch is the wave size, so lane l stages column l of every row.
+// Window geometry.  One entry per texel (qx, qy): the pair {I(qx,qy), I(qx+1,qy) - I(qx,qy)}.
+//   kQuad (8-bit input, staged from the byte quads): two binary16 values in 4 bytes -- integers up to 255 and their
+//     differences are exact in binary16 -- lerped with one v_fma_mix_f32 each;
+//   otherwise (float grey values, staged from the float texel-quad image): two binary32 values in 8 bytes, one v_fma_f32 each.
+// A bilinear fetch at (qx, qy) reads the entries (qx, qy) and (qx, qy + 1) with one two-address LDS read: 4 VALU
+// instructions for the whole lerp, same taps, same three fused multiply-adds as the global paths.  The pitch is the wave
+// size, so lane l stages column l of every row.
 constexpr int kWinW = 64;
 // LDS dwords of a window with WINH rows of fetch positions (+ the row below the last one)
-constexpr int window_entries(int winh) { return kWinW * (winh + 1); }
+constexpr int window_dwords(bool quad, int winh) { return kWinW * (winh + 1) * (quad ? 1 : 2); }
 static_assert(kQuadShift == 2, "the window is staged from 4-byte quad entries");
+
+template <bool kQuad> struct WinEntry;
+template <> struct WinEntry<true> {
+    typedef uint32_t type;   // {binary16 t, binary16 dx}
+    static constexpr int kShift = 2;
+};
+template <> struct WinEntry<false> {
+    typedef pair_t type;     // {binary32 t, binary32 dx}
+    static constexpr int kShift = 3;
+};
 
 typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
 
@@ -30,14 +43,24 @@ __device__ __forceinline__ int lds_address(uint32_t *p)
 }
 
 // entries (qx, qy) and (qx, qy + 1)
-__device__ __forceinline__ uint2 lds_read_pair(int addr)
+template <typename E>
+struct WinTaps {
+    E top, bot;
+};
+
+template <typename E>
+__device__ __forceinline__ WinTaps<E> lds_read_pair(int addr)
 {
+    WinTaps<E> t;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(uint32_t)addr;
-    return make_uint2(p[0], p[kWinW]);
+    typedef __attribute__((address_space(3))) E *lds_ptr;
+    const lds_ptr p = (lds_ptr)(uintptr_t)(uint32_t)addr;
+    t.top = p[0];
+    t.bot = p[kWinW];
 #else
-    return make_uint2(0, 0);
+    t.top = t.bot = E();
 #endif
+    return t;
 }
 
 #ifdef APD_EXPERIMENT_WIN_STATS  // diagnostic build only: [0] NCCs through the window, [1] global fast, [2] global slow,
@@ -87,11 +110,12 @@ __device__ __forceinline__ float wave_max(float v)
 
 // Every lane of the wave calls this (no divergence): centres a window with WINH rows of fetch positions on the bounding
 // box of the points (cx, cy) of the lanes with `ok` and copies it from the quad image.  `win` is this wave's LDS region
-// (window_entries(WINH) dwords).
-template <int WINH>
+// (window_dwords(kQuad, WINH) dwords).
+template <bool kQuad, int WINH>
 __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, bool ok, float cx, float cy)
 {
     constexpr int kWinRows = WINH + 1;
+    constexpr int kShift = WinEntry<kQuad>::kShift;
     SrcWindow w;
     const float big = 3.0e38f;
     const float x_lo = wave_min(ok ? cx : big), x_hi = wave_max(ok ? cx : -big);
@@ -106,22 +130,40 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
     // centre the window on the bounding box of the projected centres (all values are wave-uniform)
     const int wx0 = __builtin_amdgcn_readfirstlane((int)floorf(0.5f * (x_lo + x_hi)) - kWinW / 2);
     const int wy0 = __builtin_amdgcn_readfirstlane((int)floorf(0.5f * (y_lo + y_hi)) - WINH / 2);
-    const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
     const int lane = threadIdx.x & 63;
     const int qp = fa.W + 1;
     // entries outside the image replicate the edge entry, exactly like the clamp of the global path
     const int col = med3_i32(wx0 + lane, -1, fa.W - 1) + 1;
-    uint32_t tmp[kWinRows];
+    if constexpr (kQuad) {
+        const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
+        uint32_t tmp[kWinRows];
 #pragma unroll
-    for (int k = 0; k < kWinRows; ++k) {
-        const int gy = min(max(wy0 + k, -1), fa.H - 1);  // wave-uniform
-        tmp[k] = srcq[(unsigned)((gy + 1) * qp + col)];
-    }
+        for (int k = 0; k < kWinRows; ++k) {
+            const int gy = min(max(wy0 + k, -1), fa.H - 1);  // wave-uniform
+            tmp[k] = srcq[(unsigned)((gy + 1) * qp + col)];
+        }
 #pragma unroll
-    for (int k = 0; k < kWinRows; ++k) {
-        const float t0 = (float)(tmp[k] & 0xFFu);
-        const float dx = (float)((tmp[k] >> 8) & 0xFFu) - t0;
-        win[k * kWinW + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, dx));
+        for (int k = 0; k < kWinRows; ++k) {
+            const float t0 = (float)(tmp[k] & 0xFFu);
+            const float dx = (float)((tmp[k] >> 8) & 0xFFu) - t0;
+            win[k * kWinW + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, dx));
+        }
+    } else {
+        // the pair of texel row gy is the first half of float quad (., gy); the row below the image (gy == H, a copy
+        // of row H - 1 by the clamp) is the second half of quad (., H - 1)
+        const global_pair_ptr srcp = (global_pair_ptr)vc.fquad;  // two pairs per quad entry
+        pair_t *winp = reinterpret_cast<pair_t *>(win);
+        pair_t tmp[kWinRows];
+#pragma unroll
+        for (int k = 0; k < kWinRows; ++k) {
+            const int gy = min(max(wy0 + k, -1), fa.H);  // wave-uniform
+            const int qrow = min(gy, fa.H - 1) + 1;
+            tmp[k] = srcp[2u * (unsigned)(qrow * qp + col) + (gy == fa.H ? 1u : 0u)];
+        }
+#pragma unroll
+        for (int k = 0; k < kWinRows; ++k) {
+            winp[k * kWinW + lane] = tmp[k];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -136,13 +178,25 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
     w.hi_x = (float)(wx0 + kWinW - 1);
     w.lo_y = (float)(wy0 + 1);
     w.hi_y = (float)(wy0 + WINH - 1);
-    w.addr0 = __builtin_amdgcn_readfirstlane(lds_address(win) - 4 * (wy0 * kWinW + wx0));
+    w.addr0 = __builtin_amdgcn_readfirstlane(lds_address(win) - (wy0 * kWinW + wx0) * (1 << kShift));
     return w;
 }
 
-// quad_row_issue for samples known to lie inside the window: no clamps, LDS addresses.
+// byte address of window entry (qx, qy): qy * pitch + (qx << shift) + addr0
+template <int kShift>
+__device__ __forceinline__ int win_byte_address(int qx, int qy, int addr0)
+{
+    int row, off;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(kWinW << kShift), "v"(addr0));
+    asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(off) : "v"(qx), "v"(row), "n"(kShift));
+    return off;
+}
+
+// quad_row_issue / fquad_row_issue for samples known to lie inside the window: no clamps, LDS addresses.
+template <bool kQuad>
 __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN], int addr0,
-                                              float (&a)[kPatchN], float (&b)[kPatchN], uint2 (&t)[kPatchN])
+                                              float (&a)[kPatchN], float (&b)[kPatchN],
+                                              WinTaps<typename WinEntry<kQuad>::type> (&t)[kPatchN])
 {
     float z[kPatchN], X[kPatchN], Y[kPatchN], r[kPatchN];
 #pragma unroll
@@ -184,24 +238,30 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = (int)quad_byte_offset(qx[j], qy[j], 4 * kWinW, addr0);
+        qx[j] = win_byte_address<WinEntry<kQuad>::kShift>(qx[j], qy[j], addr0);
     }
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        t[j] = lds_read_pair(qx[j]);
+        t[j] = lds_read_pair<typename WinEntry<kQuad>::type>(qx[j]);
     }
 }
 
 // Pairs + weights of one row -> six bilinear values: fmaf(a, t10 - t00, t00), fmaf(a, t11 - t01, t01), fmaf(b, bot - top, top).
-__device__ __forceinline__ void win_row_lerp(const uint2 (&t)[kPatchN], const float (&a)[kPatchN], const float (&b)[kPatchN],
-                                             float (&v)[kPatchN])
+template <bool kQuad>
+__device__ __forceinline__ void win_row_lerp(const WinTaps<typename WinEntry<kQuad>::type> (&t)[kPatchN], const float (&a)[kPatchN],
+                                             const float (&b)[kPatchN], float (&v)[kPatchN])
 {
     float top[kPatchN], bot[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        top[j] = lerp_f16_pair(a[j], t[j].x);
-        bot[j] = lerp_f16_pair(a[j], t[j].y);
+        if constexpr (kQuad) {
+            top[j] = lerp_f16_pair(a[j], t[j].top);
+            bot[j] = lerp_f16_pair(a[j], t[j].bot);
+        } else {
+            top[j] = fmaf(a[j], t[j].top.y, t[j].top.x);
+            bot[j] = fmaf(a[j], t[j].bot.y, t[j].bot.x);
+        }
     }
     APD_STAGE();
 #pragma unroll
@@ -215,8 +275,8 @@ __device__ __forceinline__ void win_row_lerp(const uint2 (&t)[kPatchN], const fl
     }
 }
 
-// ncc_fixed_moments (quad mode, fast reciprocal) reading the window.
-template <typename Ref>
+// ncc_fixed_moments (fast reciprocal) reading the window.
+template <bool kQuad, typename Ref>
 __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homography &H, int px, int py, int addr0, float &sum_s,
                                                    float &sum_ss, float &sum_rs)
 {
@@ -229,10 +289,10 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
     sum_ss = 0.0f;
     sum_rs = 0.0f;
     float a[2][kPatchN], b[2][kPatchN];
-    uint2 t[2][kPatchN];
+    WinTaps<typename WinEntry<kQuad>::type> t[2][kPatchN];
     {
         const float xf = (float)(px - kPatchRadius);
-        win_row_issue(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[0], b[0], t[0]);
+        win_row_issue<kQuad>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[0], b[0], t[0]);
     }
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
@@ -247,11 +307,11 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
         APD_STAGE();
         if (i + 1 < kPatchN) {
             const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
-            win_row_issue(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[(i + 1) & 1],
-                          b[(i + 1) & 1], t[(i + 1) & 1]);
+            win_row_issue<kQuad>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0,
+                                 a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
         }
         APD_STAGE();
-        win_row_lerp(t[i & 1], a[i & 1], b[i & 1], v);
+        win_row_lerp<kQuad>(t[i & 1], a[i & 1], b[i & 1], v);
         float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
 #pragma unroll
         for (int j = 0; j < kPatchN; ++j) {
@@ -275,7 +335,7 @@ __device__ __forceinline__ void corner_position(const Homography &H, float xf, f
 }
 
 // ComputeBilateralNCCOld (APD.cu:530-614) for plane q = n/d against source view vc, window first.
-template <typename Ref>
+template <bool kQuad, typename Ref>
 __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const ViewConst &vc, const SrcWindow &w, const Ref &rp, int px,
                                                     int py, float qx, float qy, float qz)
 {
@@ -321,11 +381,11 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
 #endif
     float sum_s, sum_ss, sum_rs;
     if (in_window) {
-        ncc_window_moments(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
+        ncc_window_moments<kQuad>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
     } else if (__builtin_expect(fast_recip, 1)) {
-        ncc_fixed_moments<true, true, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, true, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else {
-        ncc_fixed_moments<true, false, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, false, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     }
     const float inv_w = 1.0f / 36.0f;
     sum_s *= inv_w;
