@@ -83,6 +83,7 @@ def lib():
     L.apd_default_params.restype = None
     L.apd_create.argtypes = [C.POINTER(H), C.c_int, C.c_int, C.c_int, C.POINTER(Params)]
     L.apd_destroy.argtypes = [H]
+    L.apd_reset.argtypes = [H, C.POINTER(Params)]
     L.apd_upload_views.argtypes = [H, C.c_int, C.POINTER(Camera), fpp, fpp]
     L.apd_upload_prior.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
     L.apd_run.argtypes = [H]
@@ -173,6 +174,12 @@ class Handle:
         if self._h:
             lib().apd_destroy(self._h)
             self._h = C.c_void_p()
+
+    def reset(self, params):
+        """Re-arms the handle for another (view, pass) of the same size (apd_reset): same initial state as a new one."""
+        self.params = params
+        self._keep = []
+        _check(lib().apd_reset(self._h, C.byref(params)))
 
     def __del__(self):
         try:

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -202,6 +203,25 @@ int apd_device_count(void)
     return n;
 }
 
+// State a freshly constructed APD object starts from (CudaSpaceInitialization, APD.cpp:636-666); also what apd_reset
+// restores, so a recycled handle behaves exactly like a new one.
+static int initial_state(apd_context *c)
+{
+    const size_t n = (size_t)c->W * c->H;
+    HIP_TRY(hipMemsetAsync(c->costs, 0, n * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->rng, 0, n * 6 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->selected_views, 0, n * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->view_weight, 0, n * APD_MAX_IMAGES, c->stream));  // uninitialised in the reference
+    HIP_TRY(hipMemsetAsync(c->planes, 0, n * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->fit_planes, 0, n * sizeof(float4), c->stream));    // APD.cpp:651
+    HIP_TRY(hipMemsetAsync(c->weak_info, APD_STRONG, n, c->stream));             // APD.cpp:541-547
+    HIP_TRY(hipMemsetAsync(c->weak_reliable, 0, n, c->stream));
+    HIP_TRY(hipMemsetAsync(c->nearest_strong, 0, n * sizeof(short2), c->stream));
+    HIP_TRY(hipMemsetAsync(c->neighbours_map, 0, n * sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->neighbours, 0, c->neighbours_cap * APD_NEIGHBOUR_NUM * sizeof(short2), c->stream));
+    return APD_OK;
+}
+
 int apd_create(apd_handle *out, int device, int width, int height, const apd_params *params)
 {
     if (!out || !params || width <= 0 || height <= 0) {
@@ -238,22 +258,36 @@ int apd_create(apd_handle *out, int device, int width, int height, const apd_par
     HIP_TRY(hipMalloc(&c->column_nearest, n));
     HIP_TRY(hipMalloc(&c->neighbours_map, n * sizeof(int)));
     HIP_TRY(hipMalloc(&c->views_dev, APD_MAX_IMAGES * sizeof(ViewConst)));
-    HIP_TRY(hipMemsetAsync(c->costs, 0, n * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->rng, 0, n * 6 * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->selected_views, 0, n * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->view_weight, 0, n * APD_MAX_IMAGES, c->stream));  // uninitialised in the reference
-    HIP_TRY(hipMemsetAsync(c->planes, 0, n * sizeof(float4), c->stream));
-    HIP_TRY(hipMemsetAsync(c->fit_planes, 0, n * sizeof(float4), c->stream));    // APD.cpp:651
-    HIP_TRY(hipMemsetAsync(c->weak_info, APD_STRONG, n, c->stream));             // APD.cpp:541-547
-    HIP_TRY(hipMemsetAsync(c->weak_reliable, 0, n, c->stream));
-    HIP_TRY(hipMemsetAsync(c->nearest_strong, 0, n * sizeof(short2), c->stream));
-    HIP_TRY(hipMemsetAsync(c->neighbours_map, 0, n * sizeof(int), c->stream));
     HIP_TRY(hipMalloc(&c->neighbours, APD_NEIGHBOUR_NUM * sizeof(short2)));
     c->neighbours_cap = 1;
-    HIP_TRY(hipMemsetAsync(c->neighbours, 0, APD_NEIGHBOUR_NUM * sizeof(short2), c->stream));
+    const int st = initial_state(c);
+    if (st != APD_OK) {
+        return st;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     refresh_frame_args(c);
     *out = c;
+    return APD_OK;
+}
+
+int apd_reset(apd_handle c, const apd_params *params)
+{
+    if (!c || !params) {
+        return fail(APD_ERR_INVALID, "apd_reset: bad argument");
+    }
+    if (params->strong_radius != 5 || params->strong_increment != 2 || params->weak_radius != 5 || params->weak_increment != 5) {
+        return fail(APD_ERR_UNSUPPORTED, "apd_reset: only strong 5/2 and weak 5/5 patch geometry is built");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    c->params = *params;
+    c->views_uploaded = false;
+    c->prior_uploaded = false;
+    c->weak_count = 0;
+    const int st = initial_state(c);
+    if (st != APD_OK) {
+        return st;
+    }
+    refresh_frame_args(c);
     return APD_OK;
 }
 
@@ -332,31 +366,35 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     }
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)c->W * c->H;
-    for (float *p : c->images) {
-        hipFree(p);
-    }
-    for (float *p : c->depths) {
-        hipFree(p);
-    }
-    for (apd::quad_t *p : c->quads) {
-        hipFree(p);
-    }
-    for (apd::fquad_t *p : c->fquads) {
-        hipFree(p);
-    }
-    c->fquads.assign(num_images, nullptr);
-    c->images.assign(num_images, nullptr);
-    c->depths.assign(num_images, nullptr);
+    // a recycled handle (apd_reset) keeps its buffers: per-image float planes are reused, the derived texel-quad /
+    // float-quad images are rebuilt below and change kind with the input, so they are released here
+    auto release = [](auto &vec, size_t keep) {
+        for (size_t i = keep; i < vec.size(); ++i) {
+            hipFree(vec[i]);
+        }
+        vec.resize(keep);
+    };
+    release(c->images, std::min(c->images.size(), (size_t)num_images));
+    release(c->depths, depths ? std::min(c->depths.size(), (size_t)num_images) : 0);
+    release(c->quads, 0);
+    release(c->fquads, 0);
+    c->images.resize(num_images, nullptr);
+    c->depths.resize(num_images, nullptr);
     c->quads.assign(num_images, nullptr);
+    c->fquads.assign(num_images, nullptr);
     for (int i = 0; i < num_images; ++i) {
         if (cameras[i].width != c->W || cameras[i].height != c->H) {
             return fail(APD_ERR_INVALID, "apd_upload_views: camera %d is %dx%d, handle is %dx%d", i, cameras[i].width, cameras[i].height,
                         c->W, c->H);
         }
-        HIP_TRY(hipMalloc(&c->images[i], n * sizeof(float)));
+        if (!c->images[i]) {
+            HIP_TRY(hipMalloc(&c->images[i], n * sizeof(float)));
+        }
         HIP_TRY(hipMemcpyAsync(c->images[i], images[i], n * sizeof(float), hipMemcpyDefault, c->stream));
         if (depths) {
-            HIP_TRY(hipMalloc(&c->depths[i], n * sizeof(float)));
+            if (!c->depths[i]) {
+                HIP_TRY(hipMalloc(&c->depths[i], n * sizeof(float)));
+            }
             HIP_TRY(hipMemcpyAsync(c->depths[i], depths[i], n * sizeof(float), hipMemcpyDefault, c->stream));
         }
     }

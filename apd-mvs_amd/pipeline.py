@@ -156,6 +156,12 @@ class HipBackend:
     def __init__(self, pkg, device=0):
         self.pkg = pkg
         self.device = device
+        self._pool = {}  # (width, height) -> recycled handle: no hipMalloc / hipFree per (view, pass)
+
+    def close(self):
+        for h in self._pool.values():
+            h.close()
+        self._pool.clear()
 
     @property
     def camera_type(self):
@@ -163,15 +169,19 @@ class HipBackend:
 
     def run_pass(self, width, height, params, cameras, images, depths, prior):
         pkg = self.pkg
-        h = pkg.Handle(width, height, pkg.default_params(**params), device=self.device)
-        try:
-            h.upload_views(cameras, images, depths)
-            if prior is not None:
-                h.upload_prior(*prior)
-            h.run()
-            return h.download()
-        finally:
-            h.close()
+        h = self._pool.get((width, height))
+        if h is None:
+            if len(self._pool) >= 2:  # one level at a time (+ views of another size): drop what is no longer used
+                self.close()
+            h = pkg.Handle(width, height, pkg.default_params(**params), device=self.device)
+            self._pool[(width, height)] = h
+        else:
+            h.reset(pkg.default_params(**params))
+        h.upload_views(cameras, images, depths)
+        if prior is not None:
+            h.upload_prior(*prior)
+        h.run()
+        return h.download()
 
 
 def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=None, max_rounds=None, max_passes=None, log=None):

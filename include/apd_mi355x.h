@@ -124,6 +124,12 @@ int apd_create(apd_handle *out, int device, int width, int height, const apd_par
 /* ~APD (APD.cpp:361-397). */
 int apd_destroy(apd_handle h);
 
+/* Re-arms a handle for another (view, pass) of the same width x height with new parameters: the state arrays return to
+ * what apd_create leaves (so a recycled handle gives the same bits as a new one), uploads are forgotten, device buffers
+ * are kept.  Saves the ~25 hipMalloc/hipFree pairs per (view, pass) of the construct-run-destroy cycle of
+ * ProcessProblem (main.cpp:91-138). */
+int apd_reset(apd_handle h, const apd_params *params);
+
 /* Image / depth / camera upload of CudaSpaceInitialization (APD.cpp:588-634).  images[0] is the
  * reference view; `depths` may be NULL unless params.geom_consistency.  All images are W*H floats,
  * row-major, no padding.  Sets params.num_images. */
