@@ -156,3 +156,17 @@ def test_export_matches_process_problem_postprocessing(gpu_pkg, synth):
     assert np.array_equal(normal.cpu().numpy().view(np.uint32), np.ascontiguousarray(ref[..., :3]).view(np.uint32))
     assert (ref[..., 3] == 0).any()
     h.close()
+
+
+@pytest.mark.parametrize("case", [3, 6, 16, 18, 29, 39])
+def test_randomised_three_pass_cases(gpu_pkg, ob, synth, case):
+    """Cases of tools/parity_fuzz.py (random size, N = 1..9, textureless share, iterations, 8-bit or float images) through
+    FIRST_INIT, REFINE_INIT + APD and REFINE_ITER + APD + geometric term: every state array bit-identical after each pass.
+    The full sweep (`python tools/parity_fuzz.py 40`) is part of the round's profile set."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("parity_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                               "tools", "parity_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run_case(case)

@@ -1,0 +1,63 @@
+"""Randomised bit-exact parity sweep: HIP path vs CPU oracle over random sizes, view counts, scenes and seeds through the
+three pass kinds (FIRST_INIT, REFINE_INIT + APD, REFINE_ITER + APD + geometric term), 8-bit and float images, compared
+after every pass (all state arrays).  Usage: python tools/parity_fuzz.py [cases] [first_seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from apd_mvs_amd import synth
+from oracle import binding as ob
+import common
+
+
+def run_case(case):
+    """One random configuration through the three pass kinds; raises AssertionError on the first differing state array."""
+    rng = np.random.RandomState(1000 + case)
+    W, H = int(rng.randint(36, 260)), int(rng.randint(30, 180))
+    N = int(rng.randint(1, 10))
+    tl = float(rng.choice([0.0, 0.15, 0.3]))
+    iters = int(rng.randint(1, 4))
+    float_images = bool(rng.rand() < 0.35)
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=case, textureless=tl, rotate=bool(rng.rand() < 0.8))
+    if float_images:  # what a resampled pyramid level holds: non-integer grey values
+        imgs = [(im * np.float32(0.731) + np.float32(3.3) * np.sin(np.arange(im.size, dtype=np.float32).reshape(im.shape) * 0.01)).astype(np.float32)
+                for im in imgs]
+    deps = common.fake_depth_maps(W, H, N + 1)
+    passes = [dict(state=0, use_APD=0, weak_peak_radius=6),
+              dict(state=1, use_APD=1, weak_peak_radius=6, rotate_time=2, ransac_threshold=0.01 - 0.00125),
+              dict(state=2, use_APD=1, weak_peak_radius=4, rotate_time=4, ransac_threshold=0.01 - 0.0025, geom_consistency=1)]
+    prior = None
+    label = "case %d: %dx%d N=%d textureless=%.2f iters=%d %s" % (case, W, H, N, tl, iters, "float" if float_images else "8-bit")
+    for pi, extra in enumerate(passes):
+        p = common.base_params(sc, N, seed=100 + case, max_iterations=iters, **extra)
+        geom = bool(p.get("geom_consistency"))
+        h = common.make_handle(pkg, sc, imgs, N, p, depths=deps if geom else None, prior=prior)
+        o = common.make_oracle(ob, sc, imgs, N, p, depths=deps if geom else None, prior=prior)
+        try:
+            assert h.weak_count == o.weak_count, label
+            h.run()
+            o.run()
+            common.assert_state_equal(pkg, h, o, "%s pass %d" % (label, pi))
+            planes, weak, views = h.download()
+            prior = common.postprocess(planes, weak, views, p["depth_min"], p["depth_max"])
+        finally:
+            h.close()
+            o.close()
+    return label
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    t0 = time.time()
+    for case in range(first, first + cases):
+        try:
+            print("ok   " + run_case(case), flush=True)
+        except AssertionError as e:
+            bad += 1
+            print("FAIL case %d: %s" % (case, e), flush=True)
+    print("%d case(s), %d failure(s), %.0f s" % (cases, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
