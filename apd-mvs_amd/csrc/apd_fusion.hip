@@ -36,7 +36,7 @@ constexpr int kMaxSrc = APD_MAX_IMAGES;  // sources of one reference view (main.
 
 struct DevView {
     View geo;
-    const float *grey;    // rows*cols, 0..255
+    const float *image;   // rows*cols*channels, 0..255; channels 1 (grey) or 3 (blue, green, red)
     const float *depth;   // <= 0: no estimate
     const float *normal;  // 3 per pixel, world frame
     const uint8_t *weak;  // PixelState
@@ -52,6 +52,7 @@ struct RefTask {
     float *vote_w;           // exp(-score) of that vote
     uint8_t *state;          // 0 inactive, 1 undecided, 2 accepted, 3 rejected
     int *flags;              // [0] undecided pixels left after this round
+    int channels;            // of the images
 };
 
 enum : uint8_t { kInactive = 0, kUndecided = 1, kAccepted = 2, kRejected = 3 };
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void k_fusion_decide(const DevView *__restrict
 
 // Accepted pixels consume their supports and produce their point (APD.cpp:939-960); per-block counts for the scan.
 __global__ __launch_bounds__(256) void k_fusion_emit(const DevView *__restrict__ views, RefTask task, float *__restrict__ xyz_sparse,
-                                                      uint8_t *__restrict__ grey_sparse, int *__restrict__ block_counts)
+                                                      uint8_t *__restrict__ bgr_sparse, int *__restrict__ block_counts)
 {
     const DevView &rv = views[task.ref];
     const int n = rv.geo.rows * rv.geo.cols;
@@ -174,22 +175,29 @@ __global__ __launch_bounds__(256) void k_fusion_emit(const DevView *__restrict__
         const int r = p / rv.geo.cols, c = p - r * rv.geo.cols;
         float P[3];
         apd_fusion::lift(rv.geo, c, r, rv.depth[p], P);
-        float colour = rv.grey[p];
+        const int nc = task.channels;
+        float colour[3];
+        for (int k = 0; k < 3; ++k) {
+            colour[k] = rv.image[(size_t)p * nc + (nc == 3 ? k : 0)];
+        }
         int agreeing = 0;
         for (int j = 0; j < task.num_src; ++j) {
             const int s = task.vote_idx[(size_t)p * task.num_src + j];
             if (s >= 0) {
                 const DevView &sv = views[task.src[j]];
                 sv.consumed[s] = 1;
-                colour += sv.grey[s];
+                for (int k = 0; k < 3; ++k) {
+                    colour[k] += sv.image[(size_t)s * nc + (nc == 3 ? k : 0)];
+                }
                 agreeing++;
             }
         }
-        colour /= (agreeing + 1);
         xyz_sparse[3 * (size_t)p + 0] = P[0];
         xyz_sparse[3 * (size_t)p + 1] = P[1];
         xyz_sparse[3 * (size_t)p + 2] = P[2];
-        grey_sparse[p] = static_cast<uint8_t>(colour);
+        for (int k = 0; k < 3; ++k) {
+            bgr_sparse[3 * (size_t)p + k] = static_cast<uint8_t>(colour[k] / (agreeing + 1));
+        }
     }
     const unsigned long long m = __ballot(acc);
     __shared__ int wave_counts[4];
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(1024) void k_fusion_scan(int *__restrict__ counts, 
 }
 
 __global__ __launch_bounds__(256) void k_fusion_compact(RefTask task, int n, const float *__restrict__ xyz_sparse,
-                                                         const uint8_t *__restrict__ grey_sparse, const int *__restrict__ block_offsets,
-                                                         float *__restrict__ xyz_out, uint8_t *__restrict__ grey_out)
+                                                         const uint8_t *__restrict__ bgr_sparse, const int *__restrict__ block_offsets,
+                                                         float *__restrict__ xyz_out, uint8_t *__restrict__ bgr_out)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const bool acc = p < n && task.state[p] == kAccepted;
@@ -253,7 +261,9 @@ __global__ __launch_bounds__(256) void k_fusion_compact(RefTask task, int n, con
         xyz_out[3 * (size_t)pos + 0] = xyz_sparse[3 * (size_t)p + 0];
         xyz_out[3 * (size_t)pos + 1] = xyz_sparse[3 * (size_t)p + 1];
         xyz_out[3 * (size_t)pos + 2] = xyz_sparse[3 * (size_t)p + 2];
-        grey_out[pos] = grey_sparse[p];
+        bgr_out[3 * (size_t)pos + 0] = bgr_sparse[3 * (size_t)p + 0];
+        bgr_out[3 * (size_t)pos + 1] = bgr_sparse[3 * (size_t)p + 1];
+        bgr_out[3 * (size_t)pos + 2] = bgr_sparse[3 * (size_t)p + 2];
     }
 }
 
@@ -280,15 +290,19 @@ int fusion_fail(int code, const char *what, hipError_t e)
 
 extern "C" const char *apd_fusion_last_error(void) { return g_fusion_error.c_str(); }
 
-extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *cameras, const float *const *images, const float *const *depths,
-                              const float *const *normals, const uint8_t *const *weaks, const int *rows, const int *cols,
-                              const int *pair_offsets, const int *pair_indices, int maps_on_device, const char *ply_path,
-                              long long *num_points)
+extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *cameras, const float *const *images, int image_channels,
+                              const float *const *depths, const float *const *normals, const uint8_t *const *weaks, const int *rows,
+                              const int *cols, const int *pair_offsets, const int *pair_indices, int maps_on_device,
+                              const char *ply_path, long long *num_points)
 {
     g_fusion_error.clear();
     if (num_views <= 0 || !cameras || !images || !depths || !normals || !weaks || !rows || !cols || !pair_offsets || !pair_indices ||
         !ply_path || !num_points) {
         g_fusion_error = "apd_fuse_views: null argument";
+        return APD_ERR_INVALID;
+    }
+    if (image_channels != 1 && image_channels != 3) {
+        g_fusion_error = "apd_fuse_views: images have 1 (grey) or 3 (blue, green, red) channels";
         return APD_ERR_INVALID;
     }
     for (int i = 0; i < num_views; ++i) {
@@ -341,21 +355,21 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
         v.geo.rows = rows[i];
         v.geo.cols = cols[i];
         if (maps_on_device) {
-            v.grey = images[i];
+            v.image = images[i];
             v.depth = depths[i];
             v.normal = normals[i];
             v.weak = weaks[i];
         } else {
             void *g, *d, *nm, *w;
-            FUS_TRY(dev_alloc(n * 4, &g));
+            FUS_TRY(dev_alloc(n * 4 * image_channels, &g));
             FUS_TRY(dev_alloc(n * 4, &d));
             FUS_TRY(dev_alloc(n * 12, &nm));
             FUS_TRY(dev_alloc(n, &w));
-            FUS_TRY(hipMemcpy(g, images[i], n * 4, hipMemcpyHostToDevice));
+            FUS_TRY(hipMemcpy(g, images[i], n * 4 * image_channels, hipMemcpyHostToDevice));
             FUS_TRY(hipMemcpy(d, depths[i], n * 4, hipMemcpyHostToDevice));
             FUS_TRY(hipMemcpy(nm, normals[i], n * 12, hipMemcpyHostToDevice));
             FUS_TRY(hipMemcpy(w, weaks[i], n, hipMemcpyHostToDevice));
-            v.grey = (const float *)g;
+            v.image = (const float *)g;
             v.depth = (const float *)d;
             v.normal = (const float *)nm;
             v.weak = (const uint8_t *)w;
@@ -385,11 +399,11 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
     FUS_TRY(dev_alloc(max_px, &state));
     FUS_TRY(dev_alloc(sizeof(int), &flags));
     FUS_TRY(dev_alloc(max_px * 12, &xyz_sparse));
-    FUS_TRY(dev_alloc(max_px, &grey_sparse));
+    FUS_TRY(dev_alloc(max_px * 3, &grey_sparse));
     FUS_TRY(dev_alloc((size_t)max_blocks * 4, &block_counts));
     FUS_TRY(dev_alloc(sizeof(int), &total));
     FUS_TRY(dev_alloc(max_px * 12, &xyz_out));
-    FUS_TRY(dev_alloc(max_px, &grey_out));
+    FUS_TRY(dev_alloc(max_px * 3, &grey_out));
 
     const bool verbose = getenv("APD_FUSION_VERBOSE") != nullptr;
     std::vector<uint8_t> body;  // PLY records: x y z float + diffuse_blue/green/red uchar (APD.cpp:214-254)
@@ -410,6 +424,7 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
         task.vote_w = (float *)vote_w;
         task.state = (uint8_t *)state;
         task.flags = (int *)flags;
+        task.channels = image_channels;
         if (n == 0) {
             continue;
         }
@@ -442,15 +457,15 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
         }
         if (npts > 0) {
             hxyz.resize((size_t)npts * 3);
-            hgrey.resize((size_t)npts);
+            hgrey.resize((size_t)npts * 3);
             FUS_TRY(hipMemcpy(hxyz.data(), xyz_out, (size_t)npts * 12, hipMemcpyDeviceToHost));
-            FUS_TRY(hipMemcpy(hgrey.data(), grey_out, (size_t)npts, hipMemcpyDeviceToHost));
+            FUS_TRY(hipMemcpy(hgrey.data(), grey_out, (size_t)npts * 3, hipMemcpyDeviceToHost));
             const size_t base = body.size();
             body.resize(base + (size_t)npts * 15);
             for (int k = 0; k < npts; ++k) {
                 uint8_t *rec = body.data() + base + (size_t)k * 15;
                 memcpy(rec, &hxyz[3 * (size_t)k], 12);
-                rec[12] = rec[13] = rec[14] = hgrey[k];  // grey input: blue = green = red
+                memcpy(rec + 12, &hgrey[3 * (size_t)k], 3);  // diffuse_blue, diffuse_green, diffuse_red
             }
             count += npts;
         }

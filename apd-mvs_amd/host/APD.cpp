@@ -10,6 +10,7 @@
 #include <sstream>
 
 bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height);
+bool DecodeJpegBGR(const uint8_t *data, size_t size, std::vector<uint8_t> &bgr, int &width, int &height);
 
 // ---------------------------------------------------------------------------------------------
 // file formats (APD.cpp:3-92, 350-354)
@@ -198,6 +199,77 @@ bool ReadGrayImage(const path &stem, Mat &image_float)
         return read_pgm(bytes, image_float);
     }
     std::cerr << "Can't read image: " << stem << ".{jpg,pgm}" << std::endl;
+    return false;
+}
+
+// cv::imread(IMREAD_COLOR) of `images/%08d.jpg` as the fusion reads it (APD.cpp:859): 3 x float per pixel, blue first.
+// `.pgm` (grey: B = G = R) and binary `.ppm` (P6) are accepted too.
+bool ReadColorImage(const path &stem, Mat &image_bgr)
+{
+    std::vector<uint8_t> bytes;
+    path p = stem;
+    p += ".jpg";
+    if (read_file(p, bytes)) {
+        std::vector<uint8_t> bgr;
+        int w = 0, h = 0;
+        if (!DecodeJpegBGR(bytes.data(), bytes.size(), bgr, w, h)) {
+            std::cerr << "Unsupported JPEG (only baseline sequential Huffman is built): " << p << std::endl;
+            return false;
+        }
+        image_bgr.create(h, w, MAT_32FC3);
+        for (size_t i = 0; i < bgr.size(); ++i) {
+            image_bgr.ptr<float>()[i] = (float)bgr[i];
+        }
+        return true;
+    }
+    p = stem;
+    p += ".ppm";
+    if (read_file(p, bytes)) {  // "P6 <w> <h> 255\n" + RGB triples
+        size_t pos = 0;
+        auto token = [&]() {
+            std::string t;
+            while (pos < bytes.size() && (isspace(bytes[pos]) || bytes[pos] == '#')) {
+                if (bytes[pos] == '#') {
+                    while (pos < bytes.size() && bytes[pos] != '\n') {
+                        ++pos;
+                    }
+                } else {
+                    ++pos;
+                }
+            }
+            while (pos < bytes.size() && !isspace(bytes[pos])) {
+                t.push_back((char)bytes[pos++]);
+            }
+            return t;
+        };
+        if (token() != "P6") {
+            return false;
+        }
+        const int w = atoi(token().c_str()), h = atoi(token().c_str()), maxval = atoi(token().c_str());
+        ++pos;
+        if (w <= 0 || h <= 0 || maxval != 255 || pos + (size_t)w * h * 3 > bytes.size()) {
+            return false;
+        }
+        image_bgr.create(h, w, MAT_32FC3);
+        float *o = image_bgr.ptr<float>();
+        for (size_t i = 0; i < (size_t)w * h; ++i) {
+            o[3 * i + 0] = (float)bytes[pos + 3 * i + 2];
+            o[3 * i + 1] = (float)bytes[pos + 3 * i + 1];
+            o[3 * i + 2] = (float)bytes[pos + 3 * i + 0];
+        }
+        return true;
+    }
+    Mat grey;
+    p = stem;
+    p += ".pgm";
+    if (read_file(p, bytes) && read_pgm(bytes, grey)) {
+        image_bgr.create(grey.rows, grey.cols, MAT_32FC3);
+        for (size_t i = 0; i < (size_t)grey.rows * grey.cols; ++i) {
+            image_bgr.ptr<float>()[3 * i] = image_bgr.ptr<float>()[3 * i + 1] = image_bgr.ptr<float>()[3 * i + 2] = grey.ptr<float>()[i];
+        }
+        return true;
+    }
+    std::cerr << "Can't read image: " << stem << ".{jpg,ppm,pgm}" << std::endl;
     return false;
 }
 

@@ -130,6 +130,8 @@ template <typename TYPE> void RescaleMatToTargetSize(const Mat &src, Mat &dst, i
 
 // image input: `images/%08d.jpg` decoded to 8-bit grey (APD.cpp:410-413); `.pgm` / `.pfm` accepted too
 bool ReadGrayImage(const path &image_path_without_ext, Mat &image_float);
+// the same file as cv::imread(IMREAD_COLOR) returns it (fusion colours, APD.cpp:859): MAT_32FC3, blue first
+bool ReadColorImage(const path &image_path_without_ext, Mat &image_bgr);
 // cv::resize(float, INTER_LINEAR) restated (APD.cpp:474)
 void ResizeLinear(const Mat &src, Mat &dst, int new_cols, int new_rows);
 

@@ -6,9 +6,8 @@
 // device fusion ends the program like any other device error.  (The reference's sequential loop lives in
 // oracle/fusion_oracle.cpp as the checker of the device fusion.)
 //
-// Outside the PatchMatch path proper.  One deviation: colours.  The reference re-reads the images in
-// colour (cv::imread(IMREAD_COLOR), APD.cpp:859); the only decoder in this build returns the luma plane, so blue, green
-// and red of a point all carry the grey value (identical to the reference for grey input images).
+// Outside the PatchMatch path proper.  Like the reference, the images are re-read in colour for the
+// point colours (cv::imread(IMREAD_COLOR), APD.cpp:859; host/jpeg_gray.cpp decodes to the same BGR bytes as libjpeg).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +24,7 @@ int g_fusion_device = 0;
 
 struct FusionView {
     Camera cam;
-    Mat grey;      // float, 0..255
+    Mat image;     // float 0..255: 3 channels (blue, green, red, cv::imread(IMREAD_COLOR), APD.cpp:859) or 1 (grey)
     Mat depth;     // float, <= 0: no estimate
     Mat normal;    // 3 x float, world frame
     Mat weak;      // uint8 PixelState
@@ -41,7 +40,7 @@ long long fuse_dispatch(std::vector<FusionView> &views, const std::vector<std::v
     std::vector<int> rows(V), cols(V), offs(V + 1, 0), idx;
     for (int i = 0; i < V; ++i) {
         cams[i] = views[i].cam;
-        imgs[i] = views[i].grey.ptr<float>();
+        imgs[i] = views[i].image.ptr<float>();
         deps[i] = views[i].depth.ptr<float>();
         nors[i] = views[i].normal.ptr<float>();
         weaks[i] = views[i].weak.ptr<uint8_t>();
@@ -54,8 +53,9 @@ long long fuse_dispatch(std::vector<FusionView> &views, const std::vector<std::v
         idx.push_back(0);
     }
     long long n = 0;
-    const int st = apd_fuse_views(g_fusion_device, V, cams.data(), imgs.data(), deps.data(), nors.data(), weaks.data(), rows.data(),
-                                  cols.data(), offs.data(), idx.data(), 0, ply_path.string().c_str(), &n);
+    const int channels = (V > 0 && views[0].image.type == MAT_32FC3) ? 3 : 1;
+    const int st = apd_fuse_views(g_fusion_device, V, cams.data(), imgs.data(), channels, deps.data(), nors.data(), weaks.data(),
+                                  rows.data(), cols.data(), offs.data(), idx.data(), 0, ply_path.string().c_str(), &n);
     if (st != APD_OK) {
         std::cerr << apd_fusion_last_error() << std::endl;
         return -1;
@@ -77,7 +77,7 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
         FusionView &v = views[i];
         std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
         index_of_id.emplace(problem.ref_image_id, (int)i);
-        if (!ReadGrayImage(dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id)), v.grey)) {
+        if (!ReadColorImage(dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id)), v.image)) {
             exit(EXIT_FAILURE);
         }
         memset(&v.cam, 0, sizeof(v.cam));
@@ -89,15 +89,22 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
             std::cerr << "Missing maps of view " << problem.ref_image_id << " in " << problem.result_folder << std::endl;
             exit(EXIT_FAILURE);
         }
-        if (v.depth.cols != v.grey.cols || v.depth.rows != v.grey.rows) {  // RescaleImageAndCamera, APD.cpp:729-750
-            const float scale_x = v.depth.cols / static_cast<float>(v.grey.cols);
-            const float scale_y = v.depth.rows / static_cast<float>(v.grey.rows);
-            Mat scaled;
-            ResizeLinear(v.grey, scaled, v.depth.cols, v.depth.rows);
-            for (size_t k = 0; k < (size_t)scaled.rows * scaled.cols; ++k) {
-                scaled.ptr<float>()[k] = std::nearbyint(scaled.ptr<float>()[k]);  // the reference resizes an 8-bit image
+        if (v.depth.cols != v.image.cols || v.depth.rows != v.image.rows) {  // RescaleImageAndCamera, APD.cpp:729-750
+            const float scale_x = v.depth.cols / static_cast<float>(v.image.cols);
+            const float scale_y = v.depth.rows / static_cast<float>(v.image.rows);
+            // the reference resizes the 8-bit colour image: each channel resampled, then rounded back to 8 bit
+            const size_t n_in = (size_t)v.image.rows * v.image.cols, n_out = (size_t)v.depth.rows * v.depth.cols;
+            Mat out(v.depth.rows, v.depth.cols, MAT_32FC3), plane(v.image.rows, v.image.cols, MAT_32FC1), scaled;
+            for (int ch = 0; ch < 3; ++ch) {
+                for (size_t k = 0; k < n_in; ++k) {
+                    plane.ptr<float>()[k] = v.image.ptr<float>()[3 * k + ch];
+                }
+                ResizeLinear(plane, scaled, v.depth.cols, v.depth.rows);
+                for (size_t k = 0; k < n_out; ++k) {
+                    out.ptr<float>()[3 * k + ch] = std::nearbyint(scaled.ptr<float>()[k]);
+                }
             }
-            v.grey = scaled;
+            v.image = out;
             v.cam.K[0] *= scale_x;
             v.cam.K[2] *= scale_x;
             v.cam.K[4] *= scale_y;
@@ -127,9 +134,9 @@ extern "C" {
 // Flat entry for the Python pipeline (maps already in memory after the all-gather): per-view pointers, all maps of view
 // i are rows[i] x cols[i]; sources of view i are pair_indices[pair_offsets[i] .. pair_offsets[i+1]).  Returns the
 // number of points written to `ply_path`.
-long long apdhost_fuse(int num_views, const apd_camera *cameras, const float *const *images, const float *const *depths,
-                       const float *const *normals, const uint8_t *const *weaks, const int *rows, const int *cols,
-                       const int *pair_offsets, const int *pair_indices, const char *ply_path)
+long long apdhost_fuse(int num_views, const apd_camera *cameras, const float *const *images, int image_channels,
+                       const float *const *depths, const float *const *normals, const uint8_t *const *weaks, const int *rows,
+                       const int *cols, const int *pair_offsets, const int *pair_indices, const char *ply_path)
 {
     std::vector<FusionView> views(num_views);
     std::vector<std::vector<int>> sources(num_views);
@@ -139,11 +146,11 @@ long long apdhost_fuse(int num_views, const apd_camera *cameras, const float *co
         v.cam = cameras[i];
         v.cam.width = cols[i];
         v.cam.height = rows[i];
-        v.grey.create(rows[i], cols[i], MAT_32FC1);
+        v.image.create(rows[i], cols[i], image_channels == 3 ? MAT_32FC3 : MAT_32FC1);
         v.depth.create(rows[i], cols[i], MAT_32FC1);
         v.normal.create(rows[i], cols[i], MAT_32FC3);
         v.weak.create(rows[i], cols[i], MAT_8UC1);
-        memcpy(v.grey.data(), images[i], n * 4);
+        memcpy(v.image.data(), images[i], n * 4 * (image_channels == 3 ? 3 : 1));
         memcpy(v.depth.data(), depths[i], n * 4);
         memcpy(v.normal.data(), normals[i], n * 12);
         memcpy(v.weak.data(), weaks[i], n);

@@ -53,6 +53,21 @@ int apdhost_read_gray_image(const char *stem, int *rows, int *cols, float *out, 
     return 0;
 }
 
+// colour read (blue, green, red floats per pixel); `out` holds rows*cols*3 floats
+int apdhost_read_color_image(const char *stem, int *rows, int *cols, float *out, size_t cap_floats)
+{
+    Mat m;
+    if (!ReadColorImage(path(stem), m)) {
+        return -1;
+    }
+    *rows = m.rows;
+    *cols = m.cols;
+    if (out && (size_t)m.rows * m.cols * 3 <= cap_floats) {
+        memcpy(out, m.data(), (size_t)m.rows * m.cols * 3 * sizeof(float));
+    }
+    return 0;
+}
+
 int apdhost_resize_linear(const float *src, int rows, int cols, float *dst, int new_rows, int new_cols)
 {
     Mat s(rows, cols, MAT_32FC1), d;

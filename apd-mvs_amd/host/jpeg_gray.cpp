@@ -236,8 +236,76 @@ inline int be16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
 
 }  // namespace
 
-// Decodes `data` (a whole .jpg file) to grey; returns false on unsupported / corrupt input.
-bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height)
+namespace {
+
+// libjpeg's "fancy" (triangle filter) chroma upsampling, jdsample.c: h2v1_fancy_upsample / h2v2_fancy_upsample, and
+// plain replication for every other integral factor (int_upsample).  `in` is the decoded component plane (pitch in_w,
+// real size cw x ch: the columns / rows beyond belong to the encoder's block padding and are not used; rows above the
+// first and below the last real row are copies of them, jdmainct.c), `out` the full-resolution plane.
+void upsample_component(const std::vector<uint8_t> &in, int in_w, int cw, int ch, int hexp, int vexp, int width, int height,
+                        std::vector<uint8_t> &out)
+{
+    out.assign((size_t)width * height, 0);
+    auto row = [&](int r) { return &in[(size_t)(r < 0 ? 0 : (r >= ch ? ch - 1 : r)) * in_w]; };
+    if (hexp == 1 && vexp == 1) {
+        for (int y = 0; y < height; ++y) {
+            memcpy(&out[(size_t)y * width], row(y), (size_t)width);
+        }
+        return;
+    }
+    const bool fancy_h2v1 = hexp == 2 && vexp == 1 && cw > 2;
+    const bool fancy_h2v2 = hexp == 2 && vexp == 2 && cw > 2;
+    if (!fancy_h2v1 && !fancy_h2v2) {  // replication
+        for (int y = 0; y < height; ++y) {
+            const uint8_t *r = row(y / vexp);
+            for (int x = 0; x < width; ++x) {
+                out[(size_t)y * width + x] = r[x / hexp];
+            }
+        }
+        return;
+    }
+    std::vector<uint8_t> line((size_t)2 * cw);
+    if (fancy_h2v1) {
+        for (int y = 0; y < height; ++y) {
+            const uint8_t *r = row(y);
+            line[0] = r[0];
+            line[1] = (uint8_t)((r[0] * 3 + r[1] + 2) >> 2);
+            for (int i = 1; i < cw - 1; ++i) {
+                const int v = r[i] * 3;
+                line[2 * i] = (uint8_t)((v + r[i - 1] + 1) >> 2);
+                line[2 * i + 1] = (uint8_t)((v + r[i + 1] + 2) >> 2);
+            }
+            line[2 * cw - 2] = (uint8_t)((r[cw - 1] * 3 + r[cw - 2] + 1) >> 2);
+            line[2 * cw - 1] = r[cw - 1];
+            memcpy(&out[(size_t)y * width], line.data(), (size_t)width);
+        }
+        return;
+    }
+    for (int y = 0; y < height; ++y) {  // h2v2: nearer input row 3/4, farther 1/4, then the same filter along the row
+        const int r0 = y >> 1;
+        const uint8_t *near = row(r0), *far = row((y & 1) ? r0 + 1 : r0 - 1);
+        int thiscol = near[0] * 3 + far[0], nextcol = near[1] * 3 + far[1], lastcol;
+        line[0] = (uint8_t)((thiscol * 4 + 8) >> 4);
+        line[1] = (uint8_t)((thiscol * 3 + nextcol + 7) >> 4);
+        lastcol = thiscol;
+        thiscol = nextcol;
+        for (int i = 1; i < cw - 1; ++i) {
+            nextcol = near[i + 1] * 3 + far[i + 1];
+            line[2 * i] = (uint8_t)((thiscol * 3 + lastcol + 8) >> 4);
+            line[2 * i + 1] = (uint8_t)((thiscol * 3 + nextcol + 7) >> 4);
+            lastcol = thiscol;
+            thiscol = nextcol;
+        }
+        line[2 * cw - 2] = (uint8_t)((thiscol * 3 + lastcol + 8) >> 4);
+        line[2 * cw - 1] = (uint8_t)((thiscol * 4 + 7) >> 4);
+        memcpy(&out[(size_t)y * width], line.data(), (size_t)width);
+    }
+}
+
+inline uint8_t clamp_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// Whole-file decoder behind DecodeJpegGray / DecodeJpegBGR.
+bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector<uint8_t> &pixels, int &width, int &height)
 {
     if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) {
         return false;
@@ -249,6 +317,9 @@ bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray
     int ncomp = 0, restart_interval = 0;
     int hmax = 1, vmax = 1;
     bool have_sof = false;
+    bool scanned[4] = {false, false, false, false};
+    int plane_w[4] = {0, 0, 0, 0}, plane_h[4] = {0, 0, 0, 0};
+    static thread_local std::vector<uint8_t> planes[4];
     size_t pos = 2;
     while (pos + 4 <= size) {
         if (data[pos] != 0xFF) {
@@ -358,14 +429,16 @@ bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray
                 scan_comp[s] = ci;
             }
             pos += len;
-            // luma plane padded to whole MCUs
+            // component planes padded to whole MCUs (grey output decodes the luma plane only)
             const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
             const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
             const int yc = 0;  // component 0 is Y by JFIF convention
-            const int plane_w = mcus_x * comp[yc].h * 8, plane_h = mcus_y * comp[yc].v * 8;
-            static thread_local std::vector<uint8_t> plane;
-            if (plane.size() != (size_t)plane_w * plane_h) {
-                plane.assign((size_t)plane_w * plane_h, 0);
+            for (int c = 0; c < ncomp; ++c) {
+                plane_w[c] = mcus_x * comp[c].h * 8;
+                plane_h[c] = mcus_y * comp[c].v * 8;
+                if ((c == yc || want_colour) && planes[c].size() != (size_t)plane_w[c] * plane_h[c]) {
+                    planes[c].assign((size_t)plane_w[c] * plane_h[c], 0);
+                }
             }
             BitReader br{data + pos, data + size};
             for (int c = 0; c < ncomp; ++c) {
@@ -433,7 +506,8 @@ bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray
                                 coef[kZigZag[k]] = extend(br.get_bits(sz), sz) * qt[cc.tq][kZigZag[k]];
                                 ++k;
                             }
-                            if (scan_comp[s] == yc) {
+                            const int pc = scan_comp[s];
+                            if (pc == yc || want_colour) {
                                 int px, py;
                                 if (interleaved) {
                                     px = ((u % mcus_x) * cc.h + bx) * 8;
@@ -442,8 +516,8 @@ bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray
                                     px = (u % blocks_x) * 8;
                                     py = (u / blocks_x) * 8;
                                 }
-                                if (px + 8 <= plane_w && py + 8 <= plane_h) {
-                                    idct_islow(coef, &plane[(size_t)py * plane_w + px], plane_w);
+                                if (px + 8 <= plane_w[pc] && py + 8 <= plane_h[pc]) {
+                                    idct_islow(coef, &planes[pc][(size_t)py * plane_w[pc] + px], plane_w[pc]);
                                 }
                             }
                         }
@@ -457,20 +531,75 @@ bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray
                 ++q;
             }
             pos = (size_t)(q - data);
-            bool luma_done = false;
             for (int s = 0; s < ns; ++s) {
-                luma_done |= scan_comp[s] == yc;
+                scanned[scan_comp[s]] = true;
             }
-            if (luma_done) {
-                gray.resize((size_t)width * height);
+            bool done = scanned[yc];
+            if (want_colour) {
+                for (int c = 0; c < ncomp; ++c) {
+                    done = done && scanned[c];
+                }
+            }
+            if (!done) {
+                continue;
+            }
+            if (!want_colour || ncomp == 1) {
+                const int ch = want_colour ? 3 : 1;
+                pixels.resize((size_t)width * height * ch);
                 for (int y = 0; y < height; ++y) {
-                    memcpy(&gray[(size_t)y * width], &plane[(size_t)y * plane_w], (size_t)width);
+                    const uint8_t *src = &planes[yc][(size_t)y * plane_w[yc]];
+                    if (ch == 1) {
+                        memcpy(&pixels[(size_t)y * width], src, (size_t)width);
+                    } else {
+                        for (int x = 0; x < width; ++x) {  // grey file read as colour: B = G = R = Y
+                            pixels[((size_t)y * width + x) * 3 + 0] = pixels[((size_t)y * width + x) * 3 + 1] =
+                                pixels[((size_t)y * width + x) * 3 + 2] = src[x];
+                        }
+                    }
                 }
                 return true;
             }
-            continue;
+            // YCbCr -> BGR: upsample the chroma planes (jdsample.c), then libjpeg's 16-bit fixed-point conversion
+            // (jdcolor.c: build_ycc_rgb_table / ycc_rgb_convert), stored blue first like cv::imread(IMREAD_COLOR)
+            std::vector<uint8_t> full[3];
+            for (int c = 0; c < 3; ++c) {
+                if (hmax % comp[c].h != 0 || vmax % comp[c].v != 0) {
+                    return false;  // fractional sampling ratios: not built
+                }
+                const int cw = (width * comp[c].h + hmax - 1) / hmax, chh = (height * comp[c].v + vmax - 1) / vmax;
+                upsample_component(planes[c], plane_w[c], cw, chh, hmax / comp[c].h, vmax / comp[c].v, width, height, full[c]);
+            }
+            pixels.resize((size_t)width * height * 3);
+            const int kScale = 16, kHalf = 1 << 15;
+            const int f_1_40200 = (int)(1.40200 * 65536 + 0.5), f_1_77200 = (int)(1.77200 * 65536 + 0.5);
+            const int f_0_71414 = (int)(0.71414 * 65536 + 0.5), f_0_34414 = (int)(0.34414 * 65536 + 0.5);
+            for (size_t i = 0; i < (size_t)width * height; ++i) {
+                const int y = full[0][i], cb = full[1][i] - 128, cr = full[2][i] - 128;
+                const int r = y + ((f_1_40200 * cr + kHalf) >> kScale);
+                const int g = y + (((-f_0_34414) * cb + kHalf + (-f_0_71414) * cr) >> kScale);
+                const int b = y + ((f_1_77200 * cb + kHalf) >> kScale);
+                pixels[3 * i + 0] = clamp_u8(b);
+                pixels[3 * i + 1] = clamp_u8(g);
+                pixels[3 * i + 2] = clamp_u8(r);
+            }
+            return true;
         }
         pos += len;
     }
     return false;
+}
+
+}  // namespace
+
+// Decodes `data` (a whole .jpg file) to grey; returns false on unsupported / corrupt input.
+bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height)
+{
+    return decode_jpeg(data, size, false, gray, width, height);
+}
+
+// Decodes to interleaved 8-bit BGR, what cv::imread(IMREAD_COLOR) returns for the file (the reference's fusion colours,
+// APD.cpp:859): libjpeg's islow IDCT, fancy chroma upsampling and fixed-point YCbCr -> RGB.
+bool DecodeJpegBGR(const uint8_t *data, size_t size, std::vector<uint8_t> &bgr, int &width, int &height)
+{
+    return decode_jpeg(data, size, true, bgr, width, height);
 }

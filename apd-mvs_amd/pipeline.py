@@ -360,10 +360,31 @@ def save_results(folder, scene, results):
                 raise IOError("cannot write " + os.path.join(d, name))
 
 
-def fuse(scene, results, ply_path, device=0):
+def load_colour_images(folder, ids):
+    """images/%08d.{jpg,ppm,pgm} as cv::imread(IMREAD_COLOR) returns them: float32 [H, W, 3], blue first (APD.cpp:859)."""
+    import ctypes as C
+    import os
+    L = host_lib()
+    ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
+    L.apdhost_read_color_image.argtypes = [C.c_char_p, ip, ip, fp, C.c_size_t]
+    out = []
+    for v in ids:
+        stem = os.path.join(folder, "images", "%08d" % v).encode()
+        r, c = C.c_int(), C.c_int()
+        if L.apdhost_read_color_image(stem, C.byref(r), C.byref(c), None, 0) != 0:
+            raise IOError("cannot read image %d of %s" % (v, folder))
+        a = np.zeros((r.value, c.value, 3), np.float32)
+        L.apdhost_read_color_image(stem, C.byref(r), C.byref(c), a.ctypes.data_as(fp), a.size)
+        out.append(a)
+    return out
+
+
+def fuse(scene, results, ply_path, device=0, colour_images=None):
     """RunFusion (APD.cpp:826-977) on the gathered maps: consistency check and merge into a binary PLY on GPU `device`
     (apd_fuse_views, csrc/apd_fusion.hip).  Every view must be at one resolution per view; images are
-    resampled to the depth-map size if it differs (RescaleImageAndCamera, APD.cpp:729-750).  Returns the number of points."""
+    resampled to the depth-map size if it differs (RescaleImageAndCamera, APD.cpp:729-750).  colour_images: optional
+    float32 [H, W, 3] arrays (blue, green, red, as load_colour_images returns them) for the point colours; the grey
+    images of the scene otherwise (blue = green = red).  Returns the number of points."""
     import ctypes as C
     L = host_lib()
     L.apdhost_set_fusion_device(int(device))
@@ -376,11 +397,14 @@ def fuse(scene, results, ply_path, device=0):
         st = results[v]
         h, w = st.depth.shape
         cam = cam_t.from_buffer_copy(scene.cameras[v])
-        img = scene.images[v]
-        if img.shape != (h, w):
+        img = scene.images[v] if colour_images is None else colour_images[v]
+        if img.shape[:2] != (h, w):
             sx = np.float32(w) / np.float32(img.shape[1])
             sy = np.float32(h) / np.float32(img.shape[0])
-            img = np.rint(resize_linear(img, w, h)).astype(np.float32)
+            if img.ndim == 3:
+                img = np.stack([np.rint(resize_linear(img[..., k], w, h)) for k in range(3)], -1).astype(np.float32)
+            else:
+                img = np.rint(resize_linear(img, w, h)).astype(np.float32)
             cam.K[0] = float(np.float32(cam.K[0]) * sx)
             cam.K[2] = float(np.float32(cam.K[2]) * sx)
             cam.K[4] = float(np.float32(cam.K[4]) * sy)
@@ -402,7 +426,9 @@ def fuse(scene, results, ply_path, device=0):
     def ptrs(arrs):
         return (C.c_void_p * V)(*[a.ctypes.data for a in arrs])
 
-    n = L.apdhost_fuse(V, C.byref(cams), ptrs(imgs), ptrs(deps), ptrs(nors), ptrs(weaks), rows, cols, offs, idx, str(ply_path).encode())
+    channels = 3 if imgs[0].ndim == 3 else 1
+    n = L.apdhost_fuse(V, C.byref(cams), ptrs(imgs), channels, ptrs(deps), ptrs(nors), ptrs(weaks), rows, cols, offs, idx,
+                       str(ply_path).encode())
     if n < 0:
         raise RuntimeError("device fusion failed (apd_fuse_views): see stderr")
     return int(n)

@@ -270,7 +270,8 @@ class Oracle:
 
 def fuse(cameras, images, depths, normals, weaks, pairs, ply_path):
     """The reference's sequential fusion loop (oracle/fusion_oracle.cpp, RunFusion APD.cpp:826-977) on host arrays:
-    cameras = ctypes array of Camera-compatible structs (one per view), images/depths float32 [H, W], normals float32
+    cameras = ctypes array of Camera-compatible structs (one per view), images float32 [H, W] (grey) or [H, W, 3] (blue,
+    green, red), depths float32 [H, W], normals float32
     [H, W, 3], weaks uint8 [H, W], pairs[i] = source view indices of view i.  Writes `ply_path`, returns the point count."""
     build()
     L = C.CDLL(_FUSION_LIB_PATH)
@@ -295,7 +296,8 @@ def fuse(cameras, images, depths, normals, weaks, pairs, ply_path):
         flat += list(pairs[v])
     offs[V] = len(flat)
     idx = (C.c_int * max(len(flat), 1))(*flat)
-    n = L.orc_fuse(V, C.byref(cameras), ptrs(images, np.float32), ptrs(depths, np.float32), ptrs(normals, np.float32),
+    channels = 3 if np.asarray(images[0]).ndim == 3 else 1
+    n = L.orc_fuse(V, C.byref(cameras), ptrs(images, np.float32), channels, ptrs(depths, np.float32), ptrs(normals, np.float32),
                    ptrs(weaks, np.uint8), rows, cols, offs, idx, str(ply_path).encode())
     if n < 0:
         raise IOError("cannot write " + str(ply_path))

@@ -8,7 +8,8 @@
 // APD.cpp:776-824, :896-925) is the header the device build compiles too (csrc/apd_fusion_math.h, contract C9); what
 // this file pins is the order-dependent part: raster-order consumption of source pixels.
 //
-// Colours: the reference re-reads the images in colour (APD.cpp:859); the inputs here are grey, so blue = green = red.
+// Colours: images with 3 channels are blue, green, red as cv::imread(IMREAD_COLOR) gives them (APD.cpp:859); grey images
+// (1 channel) give blue = green = red.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -27,7 +28,8 @@ struct Cam {  // == apd_camera (include/apd_mi355x.h), main.h:47-56
 }  // namespace
 
 // Same flat arguments as apd_fuse_views with host pointers.  Returns the number of points written, -1 on I/O failure.
-extern "C" long long orc_fuse(int num_views, const void *cameras_v, const float *const *images, const float *const *depths,
+extern "C" long long orc_fuse(int num_views, const void *cameras_v, const float *const *images, int image_channels,
+                              const float *const *depths,
                               const float *const *normals, const uint8_t *const *weaks, const int *rows, const int *cols,
                               const int *pair_offsets, const int *pair_indices, const char *ply_path)
 {
@@ -95,18 +97,25 @@ extern "C" long long orc_fuse(int num_views, const void *cameras_v, const float 
                 if (!apd_fusion::accept_point(num_consistent, dynamic_consistency, (int)weaks[i][p])) {  // :933-934
                     continue;
                 }
-                float colour = images[i][p];
+                const int nc = image_channels;
+                float colour[3];
+                for (int k = 0; k < 3; ++k) {
+                    colour[k] = images[i][p * nc + (nc == 3 ? k : 0)];
+                }
                 for (int j = 0; j < num_ngb; ++j) {  // :939-950
                     if (used[j] < 0) {
                         continue;
                     }
                     masks[ngb[j]][used[j]] = 1;
-                    colour += images[ngb[j]][used[j]];
+                    for (int k = 0; k < 3; ++k) {
+                        colour[k] += images[ngb[j]][(size_t)used[j] * nc + (nc == 3 ? k : 0)];
+                    }
                 }
-                colour /= (num_consistent + 1);
                 uint8_t rec[15];
                 memcpy(rec, P, 12);
-                rec[12] = rec[13] = rec[14] = static_cast<uint8_t>(colour);
+                for (int k = 0; k < 3; ++k) {
+                    rec[12 + k] = static_cast<uint8_t>(colour[k] / (num_consistent + 1));
+                }
                 body.insert(body.end(), rec, rec + 15);
                 ++count;
             }

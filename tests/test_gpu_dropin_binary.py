@@ -271,6 +271,17 @@ def test_device_fusion_equals_the_sequential_host_loop(gpu_pkg, ob, synth, tmp_p
     # consumption did matter: fusing every view against fresh masks would give more points
     xyz, _ = _read_ply(tmp_path / "gpu.ply")
     assert len(xyz) < W * H * nviews
+    # colour images (blue, green, red per pixel, APD.cpp:859): the same points, per-channel averages of the supports
+    rng = np.random.RandomState(9)
+    colour = [np.ascontiguousarray(np.stack([im, np.roll(im, 3, 1), 255.0 - im], -1) + rng.randint(0, 3, im.shape + (3,)), np.float32)
+              .clip(0, 255) for im in scene.images]
+    n_cpu_c = ob.fuse(cams, colour, [results[v].depth for v in range(nviews)], [results[v].normal for v in range(nviews)],
+                      [results[v].weak for v in range(nviews)], scene.pairs, tmp_path / "cpu_c.ply")
+    n_gpu_c = pipeline.fuse(scene, results, tmp_path / "gpu_c.ply", colour_images=colour)
+    assert n_cpu_c == n_gpu_c == n_cpu
+    assert (tmp_path / "cpu_c.ply").read_bytes() == (tmp_path / "gpu_c.ply").read_bytes()
+    xyz_c, bgr_c = _read_ply(tmp_path / "gpu_c.ply")
+    assert np.array_equal(xyz_c, xyz) and (bgr_c[:, 0] != bgr_c[:, 2]).mean() > 0.9
     del C
 
 

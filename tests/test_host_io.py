@@ -177,3 +177,36 @@ def test_fusion_math_kernels(host):
     host.apdhost_fusion_math(e.ctypes.data_as(fp), len(e), 1, oe.ctypes.data_as(fp))
     refe = np.exp(e.astype(np.float64))
     assert (np.abs(oe - refe) / refe).max() < 5e-7
+
+
+@pytest.mark.parametrize("size", [(64, 48), (65, 47), (33, 17), (17, 9), (3, 5), (129, 130)])
+def test_colour_jpeg_decode_matches_libjpeg(host, tmp_path, size):
+    """ReadColorImage == cv::imread(IMREAD_COLOR) as far as libjpeg defines it (the fusion's point colours, APD.cpp:859):
+    islow IDCT, fancy chroma upsampling (4:2:2, 4:2:0), fixed-point YCbCr -> RGB.  PIL decodes with libjpeg too, so its
+    bytes are the golden vector."""
+    Image = pytest.importorskip("PIL.Image")
+    w, h = size
+    rng = np.random.RandomState(w * 1000 + h)
+    ys, xs = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 100 * np.sin(xs * 0.2 + ys * 0.05), 127 + 100 * np.cos(ys * 0.3), (xs * 7 + ys * 3) % 256], -1)
+    img = np.clip(img + rng.randn(h, w, 3) * 20, 0, 255).astype(np.uint8)
+    ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
+    host.apdhost_read_color_image.argtypes = [C.c_char_p, ip, ip, fp, C.c_size_t]
+    for sub in (0, 1, 2):          # 4:4:4, 4:2:2, 4:2:0
+        for q in (95, 60):
+            stem = str(tmp_path / ("c_%d_%d" % (sub, q)))
+            Image.fromarray(img, "RGB").save(stem + ".jpg", quality=q, subsampling=sub)
+            ref = np.asarray(Image.open(stem + ".jpg").convert("RGB"))[..., ::-1].astype(np.float32)
+            r, c = C.c_int(), C.c_int()
+            out = np.zeros((h, w, 3), np.float32)
+            assert host.apdhost_read_color_image(stem.encode(), C.byref(r), C.byref(c), out.ctypes.data_as(fp), out.size) == 0
+            assert (r.value, c.value) == (h, w)
+            assert np.array_equal(out, ref), (sub, q, int((out != ref).sum()))
+    # a grey JPEG read as colour: three equal channels
+    stem = str(tmp_path / "g")
+    Image.fromarray(img[..., 0], "L").save(stem + ".jpg", quality=90)
+    out = np.zeros((h, w, 3), np.float32)
+    r, c = C.c_int(), C.c_int()
+    assert host.apdhost_read_color_image(stem.encode(), C.byref(r), C.byref(c), out.ctypes.data_as(fp), out.size) == 0
+    ref = np.asarray(Image.open(stem + ".jpg")).astype(np.float32)
+    assert np.array_equal(out[..., 0], ref) and np.array_equal(out[..., 1], ref) and np.array_equal(out[..., 2], ref)
