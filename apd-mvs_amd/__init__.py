@@ -167,6 +167,7 @@ class Handle:
         self._h = C.c_void_p()
         self.W, self.H = int(width), int(height)
         self.params = params
+        self.device = int(device)
         self._keep = []
         _check(lib().apd_create(C.byref(self._h), device, self.W, self.H, C.byref(params)))
 
@@ -210,9 +211,17 @@ class Handle:
         return a
 
     def upload_prior(self, planes=None, selected_views=None, weak_info=None):
-        p = None if planes is None else np.ascontiguousarray(planes, np.float32)
-        v = None if selected_views is None else np.ascontiguousarray(selected_views, np.uint32)
-        w = None if weak_info is None else np.ascontiguousarray(weak_info, np.uint8)
+        """numpy arrays or torch tensors (host or device): planes float32 [H, W, 4], selected views 32-bit, weak uint8."""
+        def prep(a, np_dtype, itemsize):
+            if a is None:
+                return None
+            if hasattr(a, "data_ptr"):
+                a = a.contiguous()
+                assert a.element_size() == itemsize
+                return a
+            return np.ascontiguousarray(a, np_dtype)
+        p, v, w = prep(planes, np.float32, 4), prep(selected_views, np.uint32, 4), prep(weak_info, np.uint8, 1)
+        self._keep_prior = (p, v, w)
         _check(lib().apd_upload_prior(self._h, _ptr(p), _ptr(v), _ptr(w)))
 
     def run(self):
@@ -238,6 +247,17 @@ class Handle:
         weak = np.empty((self.H, self.W), np.uint8)
         views = np.empty((self.H, self.W), np.uint32)
         _check(lib().apd_download(self._h, planes.ctypes.data, weak.ctypes.data, views.ctypes.data))
+        return planes, weak, views
+
+    def download_device(self):
+        """The same three maps as torch tensors on the handle's device (device-to-device copies): planes float32
+        [H, W, 4], weak uint8 [H, W], selected views as int32 bit patterns [H, W]."""
+        import torch
+        dev = torch.device("cuda", self.device if self.device >= 0 else torch.cuda.current_device())
+        planes = torch.empty((self.H, self.W, 4), dtype=torch.float32, device=dev)
+        weak = torch.empty((self.H, self.W), dtype=torch.uint8, device=dev)
+        views = torch.empty((self.H, self.W), dtype=torch.int32, device=dev)
+        _check(lib().apd_download(self._h, planes.data_ptr(), weak.data_ptr(), views.data_ptr()))
         return planes, weak, views
 
     def state(self, which):

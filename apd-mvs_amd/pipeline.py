@@ -116,6 +116,20 @@ def rescale_nearest(src, target_width, target_height):
     rows, cols = src.shape[:2]
     if cols == target_width and rows == target_height:
         return src
+    if hasattr(src, "data_ptr"):  # torch tensor (host or device): the same index arithmetic in float32
+        import torch
+        sx = np.float32(target_width) / np.float32(cols)
+        sy = np.float32(target_height) / np.float32(rows)
+        o_r = (torch.arange(target_height, dtype=torch.float32) / float(sx)).to(torch.int64)
+        o_c = (torch.arange(target_width, dtype=torch.float32) / float(sy)).to(torch.int64)
+        ok_r, ok_c = o_r < rows, o_c < cols
+        out = torch.zeros((target_height, target_width) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+        rr = o_r.clamp(max=rows - 1).to(src.device)
+        cc = o_c.clamp(max=cols - 1).to(src.device)
+        picked = src[rr][:, cc]
+        mask = (ok_r[:, None] & ok_c[None, :]).to(src.device)
+        out[mask] = picked[mask]
+        return out
     scale_x = np.float32(target_width) / np.float32(cols)
     scale_y = np.float32(target_height) / np.float32(rows)
     o_r = (np.arange(target_height, dtype=np.float32) / scale_x).astype(np.int64)
@@ -153,6 +167,8 @@ def level_inputs(scene, scale_size, camera_type):
 class HipBackend:
     """One (view, pass) on the MI355X through the C ABI (== ProcessProblem, main.cpp:91-115)."""
 
+    accepts_tensors = True  # run_pass takes and returns torch tensors on `device`: no host copies between the passes
+
     def __init__(self, pkg, device=0):
         self.pkg = pkg
         self.device = device
@@ -168,6 +184,9 @@ class HipBackend:
         return self.pkg.Camera
 
     def run_pass(self, width, height, params, cameras, images, depths, prior):
+        import torch
+        # the inputs were produced on torch's stream, the handle copies and computes on its own: hand over on the host
+        torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()
         pkg = self.pkg
         h = self._pool.get((width, height))
         if h is None:
@@ -181,7 +200,7 @@ class HipBackend:
         if prior is not None:
             h.upload_prior(*prior)
         h.run()
-        return h.download()
+        return h.download_device()
 
 
 def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=None, max_rounds=None, max_passes=None, log=None):
@@ -201,15 +220,37 @@ def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=
     schedule = pass_schedule(round_num, iters, single_level)
     if max_passes is not None:
         schedule = schedule[:max_passes]
-    state = {}        # own views: ViewState at the level they were last written
+    # Everything between the passes lives in torch tensors on the backend's device (the GPU of this rank for the HIP
+    # backend): level images, depth maps of all views, prior state, post-processing, nearest-neighbour upsampling
+    # (APD.cpp:752-774) and the all-gathers.  Only the final result is copied to the host.
+    on_gpu = getattr(backend, "device", None) is not None and torch.cuda.is_available()
+    device = torch.device("cuda", backend.device) if on_gpu else torch.device("cpu")
+    tensors_in = bool(getattr(backend, "accepts_tensors", False))
+
+    def to_dev(a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(device)
+
+    def call_backend(W, H, p, cams_, imgs_, depths_, prior_):
+        if tensors_in:
+            return backend.run_pass(W, H, p, cams_, imgs_, depths_, prior_)
+        # numpy backend (the CPU oracle in the tests): zero-copy views of the CPU tensors
+        npy = lambda t: None if t is None else t.contiguous().numpy()
+        pr = None if prior_ is None else (npy(prior_[0]), None if prior_[1] is None else npy(prior_[1]).view(np.uint32), npy(prior_[2]))
+        planes, weak, views = backend.run_pass(W, H, p, cams_, [npy(t) for t in imgs_],
+                                               None if depths_ is None else [npy(t) for t in depths_], pr)
+        return to_dev(planes), to_dev(weak), to_dev(views.view(np.int32))
+
+    state = {}        # own views: (planes4 = world normal xyz + depth w, weak, views as int32 bits) at the level last written
     depth_store = {}  # every view's depth map as this rank knows it
-    device = torch.device("cuda", backend.device) if getattr(backend, "device", None) is not None and torch.cuda.is_available() \
-        else torch.device("cpu")
     level_cache = {}
     for spec in schedule:
         if spec.scale_size not in level_cache:
             level_cache.clear()
-            level_cache[spec.scale_size] = level_inputs(scene, spec.scale_size, backend.camera_type)
+            cams, imgs = level_inputs(scene, spec.scale_size, backend.camera_type)
+            level_cache[spec.scale_size] = (cams, [to_dev(im) for im in imgs])
         cams, imgs = level_cache[spec.scale_size]
         for idx in mine:
             order = [idx] + list(scene.pairs[idx])
@@ -221,47 +262,47 @@ def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=
             p["seed"] = seed + spec.iteration_index * 7919 + idx
             depths = None
             if p["geom_consistency"]:
-                depths = [np.ascontiguousarray(rescale_nearest(depth_store[j], W, H)) for j in order]
+                depths = [rescale_nearest(depth_store[j], W, H).contiguous() for j in order]
             prior = None
             if p["state"] != 0:
-                st = state[idx]
-                depth = rescale_nearest(st.depth, W, H)
-                normal = rescale_nearest(st.normal, W, H)
-                views = rescale_nearest(st.views, W, H)
-                weak = rescale_nearest(st.weak, W, H) if p["use_APD"] else None
-                prior = (np.ascontiguousarray(np.concatenate([normal, depth[..., None]], -1)), np.ascontiguousarray(views),
-                         None if weak is None else np.ascontiguousarray(weak))
-            planes, weak, views = backend.run_pass(W, H, p, [cams[j] for j in order], [imgs[j] for j in order], depths, prior)
-            d = planes[..., 3].copy()
-            bad = (d < np.float32(p["depth_min"])) | (d > np.float32(p["depth_max"]))   # main.cpp:109-112
+                planes0, weak0, views0 = state[idx]
+                prior = (rescale_nearest(planes0, W, H).contiguous(), rescale_nearest(views0, W, H).contiguous(),
+                         rescale_nearest(weak0, W, H).contiguous() if p["use_APD"] else None)
+            planes, weak, views = call_backend(W, H, p, [cams[j] for j in order], [imgs[j] for j in order], depths, prior)
+            d = planes[..., 3]
+            bad = (d < p["depth_min"]) | (d > p["depth_max"])   # main.cpp:109-112 (float32 comparisons)
             d[bad] = 0
-            weak = weak.copy()
             weak[bad] = 2
-            state[idx] = ViewState(d, np.ascontiguousarray(planes[..., :3]), weak, views.copy())
-            depth_store[idx] = d
+            state[idx] = (planes, weak, views)
+            depth_store[idx] = d.contiguous()
             if log:
                 log("pass %d (round %d, scale %d) view %d done on rank %d" % (spec.iteration_index, spec.round_index, spec.scale_size, idx, rank))
         if world > 1:
-            local = {v: torch.from_numpy(state[v].depth[..., None]).to(device) for v in mine}
-            gathered = sharding.allgather_maps(local, V, group=group)
-            g = gathered.cpu().numpy()
+            gathered = sharding.allgather_maps({v: depth_store[v][..., None] for v in mine}, V, group=group)
             for v in range(V):
                 if v not in state:
-                    depth_store[v] = g[v, ..., 0]
+                    depth_store[v] = gathered[v, ..., 0].contiguous()
+
+    def to_view_state(planes, weak, views):
+        pl = planes.cpu().numpy()
+        return ViewState(np.ascontiguousarray(pl[..., 3]), np.ascontiguousarray(pl[..., :3]), weak.cpu().numpy().astype(np.uint8),
+                         np.ascontiguousarray(views.cpu().numpy()).view(np.uint32))
+
     # before fusion: everybody gets every view's depth + normal + weak (+ selected views)
     if world > 1:
         packed = {}
         for v in mine:
-            st = state[v]
-            packed[v] = torch.from_numpy(np.concatenate([st.depth[..., None], st.normal, st.weak[..., None].astype(np.float32),
-                                                         st.views[..., None].view(np.float32)], -1)).to(device)
-        g = sharding.allgather_maps(packed, V, group=group).cpu().numpy()
+            planes, weak, views = state[v]
+            packed[v] = torch.cat([planes[..., 3:4], planes[..., :3], weak[..., None].to(torch.float32),
+                                   views.contiguous()[..., None].view(torch.float32)], -1)
+        g = sharding.allgather_maps(packed, V, group=group)
         out = {}
         for v in range(V):
-            out[v] = ViewState(np.ascontiguousarray(g[v, ..., 0]), np.ascontiguousarray(g[v, ..., 1:4]),
-                               g[v, ..., 4].astype(np.uint8), np.ascontiguousarray(g[v, ..., 5]).view(np.uint32))
+            gv = g[v]
+            out[v] = to_view_state(torch.cat([gv[..., 1:4], gv[..., 0:1]], -1), gv[..., 4].to(torch.uint8),
+                                   gv[..., 5].contiguous().view(torch.int32))
         return out
-    return state
+    return {v: to_view_state(*state[v]) for v in state}
 
 
 def synthetic_ring(synth, width, height, num_views, num_src, camera_factory, seed=0, textureless=0.0):

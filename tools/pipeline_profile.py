@@ -20,6 +20,8 @@ H.run = timed("run", H.run)
 H.download = timed("download", H.download)
 H.close = timed("close", H.close)
 pipeline.rescale_nearest = timed("rescale_nearest", pipeline.rescale_nearest)
+H.download_device = timed("download_device", H.download_device)
+H.reset = timed("reset", H.reset)
 pipeline.level_inputs = timed("level_inputs", pipeline.level_inputs)
 scene = pipeline.synthetic_ring(synth, 1920, 1080, 6, 5, pkg.make_camera, seed=0, textureless=0.2)
 t0 = time.perf_counter()
