@@ -443,6 +443,11 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
             if (undecided == 0) {
                 break;
             }
+            if (rounds > n) {  // cannot happen: the first undecided pixel decides in every round
+                cleanup();
+                g_fusion_error = "apd_fuse_views: consumption rounds did not converge";
+                return APD_ERR_STATE;
+            }
         }
         hipLaunchKernelGGL(k_fusion_emit, dim3(blocks), dim3(256), 0, 0, dviews, task, (float *)xyz_sparse, (uint8_t *)grey_sparse,
                            (int *)block_counts);
