@@ -8,6 +8,7 @@
 #include <iomanip>
 #include <iostream>
 #include <sstream>
+#include <unordered_map>
 
 bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height);
 bool DecodeJpegBGR(const uint8_t *data, size_t size, std::vector<uint8_t> &bgr, int &width, int &height);
@@ -175,7 +176,39 @@ static bool read_pgm(const std::vector<uint8_t> &b, Mat &out)
     return true;
 }
 
+// Decoded grey images of this process, by path.  The reference decodes every image again for every (view, pass)
+// (APD.cpp:410-427): 4 * round_num * (1 + sources) decodes per view.  With the PatchMatch pass itself down to a fraction
+// of a second that would be most of the run time, so each file is decoded once and handed out as a copy.  The cache
+// holds at most APD_IMAGE_CACHE_MB megabytes (default 16384; 0 disables it); images are not expected to change on
+// disk while the program runs.
+static bool read_gray_image_uncached(const path &stem, Mat &image_float);
+
 bool ReadGrayImage(const path &stem, Mat &image_float)
+{
+    static std::unordered_map<std::string, Mat> cache;
+    static size_t cached_bytes = 0;
+    static const size_t cap_bytes = [] {
+        const char *e = getenv("APD_IMAGE_CACHE_MB");
+        return (size_t)(e ? atoll(e) : 16384) << 20;
+    }();
+    const std::string key = stem.string();
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        image_float = it->second.clone();
+        return true;
+    }
+    if (!read_gray_image_uncached(stem, image_float)) {
+        return false;
+    }
+    const size_t bytes = (size_t)image_float.rows * image_float.step();
+    if (cached_bytes + bytes <= cap_bytes) {
+        cache.emplace(key, image_float.clone());
+        cached_bytes += bytes;
+    }
+    return true;
+}
+
+static bool read_gray_image_uncached(const path &stem, Mat &image_float)
 {
     std::vector<uint8_t> bytes;
     path p = stem;

@@ -19,6 +19,7 @@ struct HuffTable {
     // canonical Huffman decoding tables (T.81 Annex F.2.2.3)
     int mincode[17], maxcode[18], valptr[17];
     uint8_t vals[256];
+    uint16_t look[512];  // 9-bit lookahead: (code length << 8) | symbol, 0 = longer code
     bool present = false;
 };
 
@@ -105,22 +106,42 @@ bool build_huff(HuffTable &t, const uint8_t counts[16], const uint8_t *vals, int
         return false;
     }
     memcpy(t.vals, vals, (size_t)nvals);
+    memset(t.look, 0, sizeof(t.look));
+    for (int l = 1; l <= 9; ++l) {
+        for (int i = 0; i < counts[l - 1]; ++i) {
+            const int c = t.mincode[l] + i;  // the l-bit code of symbol vals[valptr[l] + i]
+            const int first = c << (9 - l);
+            for (int f = 0; f < (1 << (9 - l)); ++f) {
+                t.look[first + f] = (uint16_t)((l << 8) | t.vals[t.valptr[l] + i]);
+            }
+        }
+    }
     t.present = true;
     return true;
 }
 
 int decode_symbol(BitReader &br, const HuffTable &t)
 {
-    int code = br.get_bit();
-    int l = 1;
-    while (l <= 16 && (t.maxcode[l] < 0 || code > t.maxcode[l])) {
-        code = (code << 1) | br.get_bit();
-        ++l;
+    if (br.bits < 16) {
+        br.fill();
     }
-    if (l > 16) {
-        return -1;
+    const uint16_t e = t.look[br.acc >> 23];
+    if (e) {
+        const int l = e >> 8;
+        br.acc <<= l;
+        br.bits -= l;
+        return e & 0xFF;
     }
-    return t.vals[t.valptr[l] + code - t.mincode[l]];
+    const int peek = (int)(br.acc >> 16);
+    for (int l = 10; l <= 16; ++l) {
+        const int code = peek >> (16 - l);
+        if (t.maxcode[l] >= 0 && code <= t.maxcode[l]) {
+            br.acc <<= l;
+            br.bits -= l;
+            return t.vals[t.valptr[l] + code - t.mincode[l]];
+        }
+    }
+    return -1;
 }
 
 inline int extend(int v, int n) { return (n && v < (1 << (n - 1))) ? v - (1 << n) + 1 : v; }
