@@ -40,6 +40,7 @@ struct DevView {
     const float *depth;   // <= 0: no estimate
     const float *normal;  // 3 per pixel, world frame
     const uint8_t *weak;  // PixelState
+    const uint8_t *block; // optional `blocks/mask_<id>.jpg` (APD.cpp:849-853): pixels < 128 are not fused as reference pixels
     uint8_t *consumed;    // the reference's `masks`
     unsigned long long *claim;  // epoch-stamped first claimant of this pixel in the view being fused
 };
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void k_fusion_votes(const DevView *__restrict_
     }
     uint8_t st = kInactive;
     const float ref_depth = rv.depth[p];
-    if (rv.consumed[p] != 1 && !(ref_depth <= 0.0f)) {
+    if (!(rv.block && rv.block[p] < 128) && rv.consumed[p] != 1 && !(ref_depth <= 0.0f)) {
         const int r = p / rv.geo.cols, c = p - r * rv.geo.cols;
         const float ref_n[3] = {rv.normal[3 * (size_t)p], rv.normal[3 * (size_t)p + 1], rv.normal[3 * (size_t)p + 2]};
         float P[3];
@@ -291,8 +292,8 @@ int fusion_fail(int code, const char *what, hipError_t e)
 extern "C" const char *apd_fusion_last_error(void) { return g_fusion_error.c_str(); }
 
 extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *cameras, const float *const *images, int image_channels,
-                              const float *const *depths, const float *const *normals, const uint8_t *const *weaks, const int *rows,
-                              const int *cols, const int *pair_offsets, const int *pair_indices, int maps_on_device,
+                              const float *const *depths, const float *const *normals, const uint8_t *const *weaks,
+                              const uint8_t *const *blocks, const int *rows, const int *cols, const int *pair_offsets, const int *pair_indices, int maps_on_device,
                               const char *ply_path, long long *num_points)
 {
     g_fusion_error.clear();
@@ -359,6 +360,7 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
             v.depth = depths[i];
             v.normal = normals[i];
             v.weak = weaks[i];
+            v.block = blocks ? blocks[i] : nullptr;
         } else {
             void *g, *d, *nm, *w;
             FUS_TRY(dev_alloc(n * 4 * image_channels, &g));
@@ -373,6 +375,13 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
             v.depth = (const float *)d;
             v.normal = (const float *)nm;
             v.weak = (const uint8_t *)w;
+            v.block = nullptr;
+            if (blocks && blocks[i]) {
+                void *b;
+                FUS_TRY(dev_alloc(n, &b));
+                FUS_TRY(hipMemcpy(b, blocks[i], n, hipMemcpyHostToDevice));
+                v.block = (const uint8_t *)b;
+            }
         }
         void *cons, *claim;
         FUS_TRY(dev_alloc(n, &cons));

@@ -28,6 +28,7 @@ struct FusionView {
     Mat depth;     // float, <= 0: no estimate
     Mat normal;    // 3 x float, world frame
     Mat weak;      // uint8 PixelState
+    Mat block;     // optional uint8 mask of <dense>/blocks (APD.cpp:849-853); empty = none
 };
 
 // Device fusion through the C ABI (host pointers).
@@ -36,7 +37,8 @@ long long fuse_dispatch(std::vector<FusionView> &views, const std::vector<std::v
     const int V = (int)views.size();
     std::vector<apd_camera> cams(V);
     std::vector<const float *> imgs(V), deps(V), nors(V);
-    std::vector<const uint8_t *> weaks(V);
+    std::vector<const uint8_t *> weaks(V), blocks(V, nullptr);
+    bool any_block = false;
     std::vector<int> rows(V), cols(V), offs(V + 1, 0), idx;
     for (int i = 0; i < V; ++i) {
         cams[i] = views[i].cam;
@@ -44,6 +46,10 @@ long long fuse_dispatch(std::vector<FusionView> &views, const std::vector<std::v
         deps[i] = views[i].depth.ptr<float>();
         nors[i] = views[i].normal.ptr<float>();
         weaks[i] = views[i].weak.ptr<uint8_t>();
+        if (!views[i].block.empty()) {
+            blocks[i] = views[i].block.ptr<uint8_t>();
+            any_block = true;
+        }
         rows[i] = views[i].depth.rows;
         cols[i] = views[i].depth.cols;
         idx.insert(idx.end(), sources[i].begin(), sources[i].end());
@@ -55,7 +61,7 @@ long long fuse_dispatch(std::vector<FusionView> &views, const std::vector<std::v
     long long n = 0;
     const int channels = (V > 0 && views[0].image.type == MAT_32FC3) ? 3 : 1;
     const int st = apd_fuse_views(g_fusion_device, V, cams.data(), imgs.data(), channels, deps.data(), nors.data(), weaks.data(),
-                                  rows.data(), cols.data(), offs.data(), idx.data(), 0, ply_path.string().c_str(), &n);
+                                  any_block ? blocks.data() : nullptr, rows.data(), cols.data(), offs.data(), idx.data(), 0, ply_path.string().c_str(), &n);
     if (st != APD_OK) {
         std::cerr << apd_fusion_last_error() << std::endl;
         return -1;
@@ -72,6 +78,8 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
 {
     std::vector<FusionView> views(problems.size());
     std::unordered_map<int, int> index_of_id;
+    const path block_folder = dense_folder / path("blocks");
+    const bool use_block = std::filesystem::exists(block_folder);  // APD.cpp:849-853
     for (size_t i = 0; i < problems.size(); ++i) {
         const Problem &problem = problems[i];
         FusionView &v = views[i];
@@ -113,6 +121,16 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
         v.cam.width = v.depth.cols;
         v.cam.height = v.depth.rows;
         RescaleMatToTargetSize<uint8_t>(v.weak, v.weak, v.depth.cols, v.depth.rows);
+        if (use_block) {  // blocks/mask_<id>.jpg, read as grey (APD.cpp:871-875); must have the size of the depth map
+            Mat grey;
+            if (ReadGrayImage(block_folder / path("mask_" + std::to_string(problem.ref_image_id)), grey) && grey.rows == v.depth.rows &&
+                grey.cols == v.depth.cols) {
+                v.block.create(grey.rows, grey.cols, MAT_8UC1);
+                for (size_t k = 0; k < (size_t)grey.rows * grey.cols; ++k) {
+                    v.block.ptr<uint8_t>()[k] = (uint8_t)grey.ptr<float>()[k];
+                }
+            }
+        }
     }
     std::vector<std::vector<int>> sources(problems.size());
     for (size_t i = 0; i < problems.size(); ++i) {
@@ -135,8 +153,9 @@ extern "C" {
 // i are rows[i] x cols[i]; sources of view i are pair_indices[pair_offsets[i] .. pair_offsets[i+1]).  Returns the
 // number of points written to `ply_path`.
 long long apdhost_fuse(int num_views, const apd_camera *cameras, const float *const *images, int image_channels,
-                       const float *const *depths, const float *const *normals, const uint8_t *const *weaks, const int *rows,
-                       const int *cols, const int *pair_offsets, const int *pair_indices, const char *ply_path)
+                       const float *const *depths, const float *const *normals, const uint8_t *const *weaks,
+                       const uint8_t *const *blocks, const int *rows, const int *cols, const int *pair_offsets,
+                       const int *pair_indices, const char *ply_path)
 {
     std::vector<FusionView> views(num_views);
     std::vector<std::vector<int>> sources(num_views);
@@ -154,6 +173,10 @@ long long apdhost_fuse(int num_views, const apd_camera *cameras, const float *co
         memcpy(v.depth.data(), depths[i], n * 4);
         memcpy(v.normal.data(), normals[i], n * 12);
         memcpy(v.weak.data(), weaks[i], n);
+        if (blocks && blocks[i]) {
+            v.block.create(rows[i], cols[i], MAT_8UC1);
+            memcpy(v.block.data(), blocks[i], n);
+        }
         sources[i].assign(pair_indices + pair_offsets[i], pair_indices + pair_offsets[i + 1]);
     }
     return fuse_dispatch(views, sources, path(ply_path));  // -1: the device fusion failed (message on stderr)

@@ -420,12 +420,13 @@ def load_colour_images(folder, ids):
     return out
 
 
-def fuse(scene, results, ply_path, device=0, colour_images=None):
+def fuse(scene, results, ply_path, device=0, colour_images=None, block_masks=None):
     """RunFusion (APD.cpp:826-977) on the gathered maps: consistency check and merge into a binary PLY on GPU `device`
     (apd_fuse_views, csrc/apd_fusion.hip).  Every view must be at one resolution per view; images are
     resampled to the depth-map size if it differs (RescaleImageAndCamera, APD.cpp:729-750).  colour_images: optional
     float32 [H, W, 3] arrays (blue, green, red, as load_colour_images returns them) for the point colours; the grey
-    images of the scene otherwise (blue = green = red).  Returns the number of points."""
+    images of the scene otherwise (blue = green = red).  block_masks: optional uint8 [H, W] arrays (or None per view), the
+    `blocks/mask_<id>.jpg` of APD.cpp:849-853: reference pixels below 128 are not fused.  Returns the number of points."""
     import ctypes as C
     L = host_lib()
     L.apdhost_set_fusion_device(int(device))
@@ -468,7 +469,11 @@ def fuse(scene, results, ply_path, device=0, colour_images=None):
         return (C.c_void_p * V)(*[a.ctypes.data for a in arrs])
 
     channels = 3 if imgs[0].ndim == 3 else 1
-    n = L.apdhost_fuse(V, C.byref(cams), ptrs(imgs), channels, ptrs(deps), ptrs(nors), ptrs(weaks), rows, cols, offs, idx,
+    blocks = None
+    if block_masks is not None:
+        keep = [None if b is None else np.ascontiguousarray(b, np.uint8) for b in block_masks]
+        blocks = (C.c_void_p * V)(*[None if b is None else b.ctypes.data for b in keep])
+    n = L.apdhost_fuse(V, C.byref(cams), ptrs(imgs), channels, ptrs(deps), ptrs(nors), ptrs(weaks), blocks, rows, cols, offs, idx,
                        str(ply_path).encode())
     if n < 0:
         raise RuntimeError("device fusion failed (apd_fuse_views): see stderr")

@@ -186,15 +186,17 @@ int apd_set_stream(apd_handle h, void *hip_stream);
  * produce, i.e. <dense>/APD/APD.ply, from the final maps of every view (after the all-gather in a multi-GPU run).
  * View i has cameras[i] (K already scaled to the map size, APD.cpp:729-750), image images[i] (floats 0..255,
  * image_channels = 1: grey, 3: blue, green, red interleaved as cv::imread(IMREAD_COLOR) gives them, APD.cpp:859),
- * depths[i] (<= 0: no estimate), normals[i] (3 floats per pixel, world frame), weaks[i] (PixelState), all
+ * depths[i] (<= 0: no estimate), normals[i] (3 floats per pixel, world frame), weaks[i] (PixelState), optionally
+ * blocks[i] (the `blocks/mask_<id>.jpg` of APD.cpp:849-853: reference pixels below 128 are skipped; `blocks` or any
+ * blocks[i] may be NULL), all
  * rows[i] x cols[i]; its sources are pair_indices[pair_offsets[i] .. pair_offsets[i+1]) (indices of views, in
  * pair.txt order).  maps_on_device != 0: the four map arrays hold DEVICE pointers (e.g. the gathered torch tensors).
  * Views are fused in order, and inside a view the raster-order consumption of source pixels (`masks`) is resolved
  * exactly, so the point list is the one the sequential host loop writes.  A view that lists itself as a source is
  * refused (APD_ERR_INVALID). */
 int apd_fuse_views(int device, int num_views, const apd_camera *cameras, const float *const *images, int image_channels,
-                   const float *const *depths, const float *const *normals, const uint8_t *const *weaks, const int *rows,
-                   const int *cols, const int *pair_offsets, const int *pair_indices, int maps_on_device, const char *ply_path,
+                   const float *const *depths, const float *const *normals, const uint8_t *const *weaks,
+                   const uint8_t *const *blocks, const int *rows, const int *cols, const int *pair_offsets, const int *pair_indices, int maps_on_device, const char *ply_path,
                    long long *num_points);
 const char *apd_fusion_last_error(void);
 

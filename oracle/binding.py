@@ -268,7 +268,7 @@ class Oracle:
         return lib().orc_geom_cost(self._h, x, y, src, p)
 
 
-def fuse(cameras, images, depths, normals, weaks, pairs, ply_path):
+def fuse(cameras, images, depths, normals, weaks, pairs, ply_path, blocks=None):
     """The reference's sequential fusion loop (oracle/fusion_oracle.cpp, RunFusion APD.cpp:826-977) on host arrays:
     cameras = ctypes array of Camera-compatible structs (one per view), images float32 [H, W] (grey) or [H, W, 3] (blue,
     green, red), depths float32 [H, W], normals float32
@@ -298,7 +298,8 @@ def fuse(cameras, images, depths, normals, weaks, pairs, ply_path):
     idx = (C.c_int * max(len(flat), 1))(*flat)
     channels = 3 if np.asarray(images[0]).ndim == 3 else 1
     n = L.orc_fuse(V, C.byref(cameras), ptrs(images, np.float32), channels, ptrs(depths, np.float32), ptrs(normals, np.float32),
-                   ptrs(weaks, np.uint8), rows, cols, offs, idx, str(ply_path).encode())
+                   ptrs(weaks, np.uint8), None if blocks is None else ptrs(blocks, np.uint8), rows, cols, offs, idx,
+                   str(ply_path).encode())
     if n < 0:
         raise IOError("cannot write " + str(ply_path))
     return int(n)

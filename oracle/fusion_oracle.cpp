@@ -30,7 +30,8 @@ struct Cam {  // == apd_camera (include/apd_mi355x.h), main.h:47-56
 // Same flat arguments as apd_fuse_views with host pointers.  Returns the number of points written, -1 on I/O failure.
 extern "C" long long orc_fuse(int num_views, const void *cameras_v, const float *const *images, int image_channels,
                               const float *const *depths,
-                              const float *const *normals, const uint8_t *const *weaks, const int *rows, const int *cols,
+                              const float *const *normals, const uint8_t *const *weaks, const uint8_t *const *blocks,
+                              const int *rows, const int *cols,
                               const int *pair_offsets, const int *pair_indices, const char *ply_path)
 {
     const Cam *cameras = static_cast<const Cam *>(cameras_v);
@@ -59,6 +60,9 @@ extern "C" long long orc_fuse(int num_views, const void *cameras_v, const float 
         for (int r = 0; r < rows[i]; ++r) {
             for (int c = 0; c < cols[i]; ++c) {
                 const size_t p = (size_t)r * cols[i] + c;
+                if (blocks && blocks[i] && blocks[i][p] < 128) {  // use_block, :898-900
+                    continue;
+                }
                 if (masks[i][p] == 1) {  // :905
                     continue;
                 }

@@ -282,6 +282,16 @@ def test_device_fusion_equals_the_sequential_host_loop(gpu_pkg, ob, synth, tmp_p
     assert (tmp_path / "cpu_c.ply").read_bytes() == (tmp_path / "gpu_c.ply").read_bytes()
     xyz_c, bgr_c = _read_ply(tmp_path / "gpu_c.ply")
     assert np.array_equal(xyz_c, xyz) and (bgr_c[:, 0] != bgr_c[:, 2]).mean() > 0.9
+    # blocks/ masks (APD.cpp:849-853, :898): reference pixels below 128 are skipped, their supports stay available
+    masks = [np.full((H, W), 255, np.uint8) for _ in range(nviews)]
+    masks[0][:, : W // 2] = 0
+    masks[2] = None
+    n_cpu_b = ob.fuse(cams, scene.images, [results[v].depth for v in range(nviews)], [results[v].normal for v in range(nviews)],
+                      [results[v].weak for v in range(nviews)], scene.pairs, tmp_path / "cpu_b.ply",
+                      blocks=[m if m is not None else np.full((H, W), 255, np.uint8) for m in masks])
+    n_gpu_b = pipeline.fuse(scene, results, tmp_path / "gpu_b.ply", block_masks=masks)
+    assert n_cpu_b == n_gpu_b and n_gpu_b != n_cpu
+    assert (tmp_path / "cpu_b.ply").read_bytes() == (tmp_path / "gpu_b.ply").read_bytes()
     del C
 
 
