@@ -147,3 +147,38 @@ def test_window_and_global_post_loop_kernels_agree(gpu_pkg, synth, monkeypatch):
         del sc
         torch.cuda.empty_cache()
     assert out["1"] == out["0"]
+
+
+def test_recycled_handle_equals_a_new_one(gpu_pkg, synth):
+    """apd_reset: a handle that already ran another (view, pass) -- other images, other parameters, geometric term, WEAK
+    pixels -- gives the same bits as a freshly created one."""
+    W, H, N = 160, 120, 4
+    sc_a, imgs_a = common.scene_inputs(synth, W, H, N, seed=5, textureless=0.25)
+    sc_b, imgs_b = common.scene_inputs(synth, W, H, N - 1, seed=9)
+    deps = common.fake_depth_maps(W, H, N + 1)
+    pa = common.base_params(sc_a, N, seed=21, state=0, use_APD=0, weak_peak_radius=6, max_iterations=2)
+    h = common.make_handle(gpu_pkg, sc_a, imgs_a, N, pa)
+    h.run()
+    planes, weak, views = h.download()
+    prior = common.postprocess(planes, weak, views, pa["depth_min"], pa["depth_max"])
+    pa2 = common.base_params(sc_a, N, seed=22, state=2, use_APD=1, weak_peak_radius=4, rotate_time=2, ransac_threshold=0.00875,
+                             geom_consistency=1, max_iterations=2)
+    h.reset(gpu_pkg.default_params(**pa2))
+    cams_a = [gpu_pkg.make_camera(sc_a.K[i], sc_a.R[i], sc_a.t[i], W, H, sc_a.depth_min, sc_a.depth_max) for i in range(N + 1)]
+    h.upload_views(cams_a, imgs_a, deps)
+    h.upload_prior(*prior)
+    h.run()
+    assert h.weak_count > 0
+    # now a completely different job on the recycled handle and on a new one
+    pb = common.base_params(sc_b, N - 1, seed=33, state=0, use_APD=0, weak_peak_radius=6, max_iterations=2)
+    h.reset(gpu_pkg.default_params(**pb))
+    cams_b = [gpu_pkg.make_camera(sc_b.K[i], sc_b.R[i], sc_b.t[i], W, H, sc_b.depth_min, sc_b.depth_max) for i in range(N)]
+    h.upload_views(cams_b, imgs_b)
+    h.run()
+    fresh = common.make_handle(gpu_pkg, sc_b, imgs_b, N - 1, pb)
+    fresh.run()
+    for which in (gpu_pkg.STATE_PLANES, gpu_pkg.STATE_COSTS, gpu_pkg.STATE_SELECTED_VIEWS, gpu_pkg.STATE_VIEW_WEIGHT,
+                  gpu_pkg.STATE_WEAK_INFO, gpu_pkg.STATE_RNG, gpu_pkg.STATE_FIT_PLANES):
+        assert np.array_equal(common.bits(h.state(which)), common.bits(fresh.state(which))), which
+    h.close()
+    fresh.close()
