@@ -546,8 +546,13 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
 #ifdef APD_EXPERIMENT_WEAK_NO_SUB  // timing experiment only: centre patch alone
     return center_cost;
 #endif
+#ifdef APD_EXPERIMENT_WEAK_NB  // timing experiment only: sub-patches of the first APD_EXPERIMENT_WEAK_NB neighbours
+    constexpr int kNbEnd = APD_EXPERIMENT_WEAK_NB;
+#else
+    constexpr int kNbEnd = 8;
+#endif
 #pragma unroll 1
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < kNbEnd; ++k) {
         const int packed = lds.nb[k][lane];
         if (packed == -1) {
             continue;
@@ -621,12 +626,20 @@ template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, const int *__restrict__ count)
 {
     __shared__ WeakLdsT<kQuad> lds;
-#ifdef APD_EXPERIMENT_K910_LDS_PAD  // timing experiment only: KiB of unused LDS per wave to cap the waves per CU
-    __shared__ char lds_pad[APD_EXPERIMENT_K910_LDS_PAD * 1024];
-    if (blockIdx.x == 0x7fffffff) {
-        lds_pad[threadIdx.x] = 1;
-    }
+    // The kernel is bound by the L1/L2 traffic of its scattered sub-patch gathers, not by latency: with six waves per
+    // CU instead of the eight the registers allow, the waves evict each other's lines less (ms per launch at 4096x3072,
+    // 18 % WEAK: 8 waves 38.9, 7: 37.4, 6: 36.8, 5: 38.0, 4: 39.9, 3: 48.8).  Unused LDS is what caps the count: 14.6 + 10
+    // KiB per wave in texel-quad mode; the float mode's 24.8 KiB already give six.
+#ifndef APD_K910_LDS_PAD_KB
+#define APD_K910_LDS_PAD_KB 10
 #endif
+    constexpr int kPadBytes = kQuad ? APD_K910_LDS_PAD_KB * 1024 : 0;
+    if constexpr (kPadBytes > 0) {
+        __shared__ char lds_pad[kPadBytes > 0 ? kPadBytes : 1];
+        if (blockIdx.x == 0x7fffffff) {
+            lds_pad[threadIdx.x] = 1;
+        }
+    }
     const int lane = threadIdx.x;
     const int gid = blockIdx.x * 64 + lane;
     if (gid >= *count) {
