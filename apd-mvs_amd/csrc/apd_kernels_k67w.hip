@@ -35,8 +35,16 @@ constexpr int kWinH = APD_WIN_H;
 // trusted pixels when there are any.
 template <bool kQuad>
 __device__ __forceinline__ SrcWindow stage_window(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, bool alive, int px, int py,
-                                                  const float4 plane, bool trusted)
+                                                  const float4 plane, bool trusted, bool enabled)
 {
+    if (!enabled) {  // wave-uniform: the planes are still random (first iteration of a FIRST_INIT pass), nothing to stage
+        SrcWindow none;
+        none.valid = 0;
+        none.wx0 = none.wy0 = none.addr0 = 0;
+        none.lo_x = none.lo_y = 3.0e38f;
+        none.hi_x = none.hi_y = -3.0e38f;
+        return none;
+    }
     float cx = 0.0f, cy = 0.0f;
     bool ok = false;
     if (alive) {
@@ -176,6 +184,12 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
     float4 ref_normals[5];
     float tc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
+    // After K5's random initialisation nearly every hypothesis of the first iteration lands somewhere else in the
+    // source image (10 % of the NCCs could read a window, 60 % of the waves are mixed): no windows in that iteration.
+#ifndef APD_WIN_FROM_ITER
+#define APD_WIN_FROM_ITER 1  // configs[1] Mpix*iter/s: 0: 207, 1: 216
+#endif
+    const bool use_windows = !(fa.state == APD_FIRST_INIT && iter < APD_WIN_FROM_ITER);
     bool trusted = false;  // window placement only: the plane from the previous update has a low cost
     if (alive) {
         rng = rng_load(fa.rng, center);
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
         const ViewConst &vc = fa.views[v];
-        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted);
+        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
         if (alive) {
 #pragma unroll 1
             for (int h = 0; h < 9; ++h) {
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
             continue;  // nobody in the wave selected this view
         }
         const ViewConst &vc = fa.views[v];
-        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted);
+        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
         if (wv > 0) {
 #pragma unroll 1
             for (int k = 0; k < 5; ++k) {
