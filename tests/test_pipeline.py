@@ -123,3 +123,17 @@ def test_two_ranks_jacobi_vs_one_rank_gauss_seidel(pkg, synth, ob, tmp_path):
         ok = (d1 > 0) & (d2 > 0)
         assert ok.mean() > 0.5
         assert (np.abs(d1[ok] - d2[ok]) <= 0.05 * d2[ok]).mean() > 0.8
+
+
+def test_rescale_nearest_tensor_path_matches_numpy(pkg):
+    """The device-resident pipeline resamples prior state with torch (RescaleMatToTargetSize, APD.cpp:752-774, swapped
+    factors included); it must pick exactly the pixels the numpy / C++ host version picks, for every dtype it carries."""
+    import torch
+    from apd_mvs_amd import pipeline
+    rng = np.random.RandomState(3)
+    for (h, w), (th, tw) in (((30, 41), (60, 82)), ((31, 40), (61, 80)), ((33, 47), (67, 93)), ((20, 20), (20, 20)), ((50, 37), (25, 19))):
+        for arr in (rng.rand(h, w).astype(np.float32), rng.rand(h, w, 4).astype(np.float32),
+                    rng.randint(0, 3, (h, w)).astype(np.uint8), rng.randint(-2**31, 2**31 - 1, (h, w)).astype(np.int32)):
+            ref = pipeline.rescale_nearest(arr, tw, th)
+            out = pipeline.rescale_nearest(torch.from_numpy(arr), tw, th).numpy()
+            assert out.shape == ref.shape and np.array_equal(out, ref), ((h, w), (th, tw), arr.dtype)
