@@ -19,7 +19,8 @@ def _declared_functions():
 def test_header_declares_the_expected_entry_points():
     names = _declared_functions()
     for must in ("apd_create", "apd_destroy", "apd_upload_views", "apd_upload_prior", "apd_run", "apd_run_kernel",
-                 "apd_run_sweeps", "apd_download", "apd_export_depth_normal_device", "apd_profile_get"):
+                 "apd_run_sweeps", "apd_download", "apd_export_depth_normal_device", "apd_profile_get", "apd_reset",
+                 "apd_fuse_views", "apd_fusion_last_error"):
         assert must in names
 
 
@@ -49,3 +50,25 @@ def test_no_gpu_means_loud_failure_not_fallback(pkg):
         pytest.skip("a GPU is visible")
     with pytest.raises(pkg.ApdError):
         pkg.Handle(32, 32, pkg.default_params(), device=0)
+
+
+def test_no_gpu_means_the_fusion_fails_loudly_too(pkg, tmp_path):
+    """apd_fuse_views has no host fallback either: without a device it returns an error and writes nothing."""
+    import numpy as np
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    L = pkg.lib()
+    L.apd_fusion_last_error.restype = C.c_char_p
+    cams = (pkg.Camera * 2)()
+    img = np.zeros((4, 4), np.float32)
+    nrm = np.zeros((4, 4, 3), np.float32)
+    weak = np.zeros((4, 4), np.uint8)
+    fptr = (C.c_void_p * 2)(img.ctypes.data, img.ctypes.data)
+    nptr = (C.c_void_p * 2)(nrm.ctypes.data, nrm.ctypes.data)
+    wptr = (C.c_void_p * 2)(weak.ctypes.data, weak.ctypes.data)
+    rows, cols = (C.c_int * 2)(4, 4), (C.c_int * 2)(4, 4)
+    offs, idx = (C.c_int * 3)(0, 1, 2), (C.c_int * 2)(1, 0)
+    n = C.c_longlong(0)
+    out = tmp_path / "x.ply"
+    st = L.apd_fuse_views(0, 2, cams, fptr, 1, fptr, nptr, wptr, None, rows, cols, offs, idx, 0, str(out).encode(), C.byref(n))
+    assert st != 0 and not out.exists() and L.apd_fusion_last_error()
