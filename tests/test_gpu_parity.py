@@ -170,3 +170,29 @@ def test_randomised_three_pass_cases(gpu_pkg, ob, synth, case):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.run_case(case)
+
+
+@pytest.mark.parametrize("W,H,N,float_images", [(80, 60, 20, False), (72, 56, 12, True), (64, 48, 31, False)])
+def test_many_source_views(gpu_pkg, ob, synth, W, H, N, float_images):
+    """The 16- and 32-view instantiations of the sweep kernels (the reference allows MAX_IMAGES = 32 including the
+    reference view, main.h:8) through the three pass kinds, bit-identical after every pass."""
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=2, textureless=0.2)
+    if float_images:
+        imgs = [(im * np.float32(0.9) + np.float32(1.7)).astype(np.float32) for im in imgs]
+    deps = common.fake_depth_maps(W, H, N + 1)
+    passes = [dict(state=0, use_APD=0, weak_peak_radius=6),
+              dict(state=1, use_APD=1, weak_peak_radius=6, rotate_time=2, ransac_threshold=0.00875),
+              dict(state=2, use_APD=1, weak_peak_radius=4, rotate_time=4, ransac_threshold=0.0075, geom_consistency=1)]
+    prior = None
+    for pi, extra in enumerate(passes):
+        p = common.base_params(sc, N, seed=50, max_iterations=2, **extra)
+        geom = bool(p.get("geom_consistency"))
+        h = common.make_handle(gpu_pkg, sc, imgs, N, p, depths=deps if geom else None, prior=prior)
+        o = common.make_oracle(ob, sc, imgs, N, p, depths=deps if geom else None, prior=prior)
+        h.run()
+        o.run()
+        common.assert_state_equal(gpu_pkg, h, o, "N=%d pass %d" % (N, pi))
+        planes, weak, views = h.download()
+        prior = common.postprocess(planes, weak, views, p["depth_min"], p["depth_max"])
+        h.close()
+        o.close()
