@@ -436,8 +436,21 @@ void APD::InuputInitialization()
             const int new_rows = (int)std::round(images[i].rows * factor);
             const float scale_x = new_cols / static_cast<float>(images[i].cols);
             const float scale_y = new_rows / static_cast<float>(images[i].rows);
+            // the resampled level image of a file is the same for every (view, pass) of the run: computed once per
+            // process (see ReadGrayImage for the rationale), handed out as a copy
+            static std::unordered_map<std::string, Mat> level_cache;
+            const std::string key = (image_folder / path(ToFormatIndex(ids[i]))).string() + "@" + std::to_string(new_cols) + "x" +
+                                    std::to_string(new_rows);
             Mat scaled;
-            ResizeLinear(images[i], scaled, new_cols, new_rows);
+            auto hit = level_cache.find(key);
+            if (hit != level_cache.end()) {
+                scaled = hit->second.clone();
+            } else {
+                ResizeLinear(images[i], scaled, new_cols, new_rows);
+                if (getenv("APD_IMAGE_CACHE_MB") == nullptr || atoll(getenv("APD_IMAGE_CACHE_MB")) > 0) {
+                    level_cache.emplace(key, scaled.clone());
+                }
+            }
             images[i] = scaled;
             width = scaled.cols;
             height = scaled.rows;
