@@ -18,7 +18,15 @@ namespace apd {
 
 constexpr int kFwTile = 16;                                // workgroup tile: 16x16 pixels, wave64 = 8x8
 constexpr int kFwLds = kFwTile + 2 * kPatchRadius;         // 26
-constexpr int kFwPitch = kFwLds + 1;                       // 27
+#ifndef APD_FW_TILE_PITCH
+#define APD_FW_TILE_PITCH (kFwLds + 1)
+#endif
+constexpr int kFwPitch = APD_FW_TILE_PITCH;                // 27
+#ifndef APD_K1415_WIN_PITCH
+#define APD_K1415_WIN_PITCH 72  // entries per window row: a 32-lane group reads four rows of eight columns (apd_window.h)
+#endif
+constexpr int kFwWinPitch = APD_K1415_WIN_PITCH;
+static_assert(kFwWinPitch >= kWinW && kFwWinPitch <= 127, "window pitch: at least the wave width; two-address LDS reads need offset1 < 256 dwords");
 #ifndef APD_K14_WIN_H
 #define APD_K14_WIN_H 32  // rows of fetch positions: 8 + 2 * (patch radius 5 + 7 texels of slack)
 #endif
@@ -101,7 +109,7 @@ __device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewCon
         correspond(H, (float)px, (float)py, cx, cy);
         ok = cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf;  // false for NaN
     }
-    return stage_window_around<kQuad, k14_win_h<kQuad>()>(fa, vc, win, ok, cx, cy);
+    return stage_window_around<kQuad, k14_win_h<kQuad>(), kFwWinPitch>(fa, vc, win, ok, cx, cy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,7 +129,7 @@ template <bool kQuad>
 __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32) void k14w_depth_to_weak(FrameArgs fa)
 {
     __shared__ float tile[kFwLds * kFwPitch];
-    __shared__ uint32_t windows[4][window_dwords(kQuad, k14_win_h<kQuad>())];
+    __shared__ uint32_t windows[4][window_dwords(kQuad, k14_win_h<kQuad>(), kFwWinPitch)];
     int px, py;
     fw_pixel(px, py);
     const RefPatchLds<kFwPitch> rp = fw_stage_ref(fa, tile, px, py);
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                     float qx, qy, qz;
                     plane_q(pl, qx, qy, qz);
                     float tc = 0.0f;
-                    tc += ncc_fixed_windowed<kQuad>(fa, vc, w, rp, px, py, qx, qy, qz);
+                    tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
                     if (fa.geom_consistency) {
                         tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
                     }
@@ -271,7 +279,7 @@ template <bool kQuad>
 __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32) void k15w_local_refine(FrameArgs fa)
 {
     __shared__ float tile[kFwLds * kFwPitch];
-    __shared__ uint32_t windows[4][window_dwords(kQuad, k14_win_h<kQuad>())];
+    __shared__ uint32_t windows[4][window_dwords(kQuad, k14_win_h<kQuad>(), kFwWinPitch)];
     int px, py;
     fw_pixel(px, py);
     const RefPatchLds<kFwPitch> rp = fw_stage_ref(fa, tile, px, py);
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
                 pl.w = (i < 0) ? w_now : pw[i];
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                const float c = ncc_fixed_windowed<kQuad>(fa, vc, w, rp, px, py, qx, qy, qz);
+                const float c = ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
                 if (i < 0) {
                     float tc = 0.0f;
                     tc += c;

@@ -287,17 +287,34 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
     }
 
     // ---- PlaneHypothesisRefinementStrong (:837-890): the five hypotheses against every selected view ----
+    // A hypothesis is only ever compared with the running cost (`temp_cost < *cost`, :884), which never exceeds the cost
+    // the refinement starts from, and its weighted sum grows monotonically view by view (weights > 0, costs in [0, 2],
+    // round-to-nearest addition and division are monotone).  Once the partial sum reaches `lost` -- a float just above
+    // cost_now * weight_norm -- the quotient can no longer be below cost_now: the remaining views of that hypothesis are
+    // skipped and the accept test below rejects it exactly as it would reject the full sum.  In converged iterations
+    // that removes most NCCs of the two random-depth hypotheses, which are also the ones that miss the windows.
+    const float lost = refinement_lost_bound(cost_now, weight_norm);
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
         const uint32_t wv = alive ? vw.get(v) : 0u;
-        if (__builtin_amdgcn_ballot_w64(wv > 0) == 0) {
-            continue;  // nobody in the wave selected this view
+        unsigned open = 0;  // hypotheses of this lane that can still win
+        if (wv > 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                open |= (tc[k] >= lost) ? 0u : (1u << k);
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(open != 0) == 0) {
+            continue;  // nobody in the wave has anything left to score in this view
         }
         const ViewConst &vc = fa.views[v];
         const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
-        if (wv > 0) {
+        if (open != 0) {
 #pragma unroll 1
             for (int k = 0; k < 5; ++k) {
+                if (!(open & (1u << k))) {
+                    continue;
+                }
                 float4 pl = ref_normals[k];
                 pl.w = ref_w[k];
                 float qx, qy, qz;

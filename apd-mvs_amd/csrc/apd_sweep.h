@@ -200,6 +200,25 @@ __device__ __forceinline__ void select_views(const FrameArgs &fa, int iter, cons
     weight_norm_out = wn;
 }
 
+// Early-out bound of the refinement loops (K6/K7, K9/K10).  A refinement hypothesis is accepted iff
+// fl(sum / weight_norm) < cost (APD.cu:884, :932, :974) with sum = the weighted costs added view by view.  Every term is
+// >= 0, so the partial sums and their quotients never decrease; if a partial sum has reached a value t with
+// t / weight_norm >= cost in real arithmetic, the final quotient is >= cost as well and the hypothesis is rejected
+// whatever the remaining views cost.  Returns such a t: fl(cost * weight_norm) is within 2^-24 (relative) of the
+// product, two roundings and the factor 1 + 2^-22 put the result strictly above it.  Tiny, zero-weight and non-finite
+// inputs return +inf or NaN (never "lost": the loops then score every view, as the reference does).
+#ifndef APD_REFINE_EARLY_OUT
+#define APD_REFINE_EARLY_OUT 1
+#endif
+__device__ __forceinline__ float refinement_lost_bound(float cost, float weight_norm)
+{
+    const float p = cost * weight_norm;
+    if (!APD_REFINE_EARLY_OUT || !(p >= 0x1p-100f) || !(weight_norm > 0.0f)) {
+        return __builtin_inff();
+    }
+    return p * (1.0f + 0x1p-22f);
+}
+
 // The five refinement hypotheses of APD.cu:855-867 / :939-951 (RNG order: depth, normal, depth, 3 angles).
 __device__ __forceinline__ void make_refinement_set(const FrameArgs &fa, int px, int py, Rng &rng, const float4 plane, float depth,
                                                     float *depths, float4 *normals)

@@ -13,11 +13,15 @@ namespace apd {
 //     differences are exact in binary16 -- lerped with one v_fma_mix_f32 each;
 //   otherwise (float grey values, staged from the float texel-quad image): two binary32 values in 8 bytes, one v_fma_f32 each.
 // A bilinear fetch at (qx, qy) reads the entries (qx, qy) and (qx, qy + 1) with one two-address LDS read: 4 VALU
-// instructions for the whole lerp, same taps, same three fused multiply-adds as the global paths.  The pitch is the wave
-// size, so lane l stages column l of every row.
+// instructions for the whole lerp, same taps, same three fused multiply-adds as the global paths.  A window is as wide
+// as the wave, so lane l stages column l of every row.
+// The row pitch (in entries) is a template parameter: with pitch 64 the entries of one column share an LDS bank, which
+// is free for the 32x4 checkerboard footprint of K6/K7 (a 32-lane group reads two pixel rows of opposite column parity)
+// and a four-way conflict for the 8x8 footprint of K14/K15 (a group reads four rows of the same eight columns); those
+// kernels use pitch 72, which moves consecutive rows by 8 (binary16 pairs) / 16 (binary32 pairs) banks.
 constexpr int kWinW = 64;
 // LDS dwords of a window with WINH rows of fetch positions (+ the row below the last one)
-constexpr int window_dwords(bool quad, int winh) { return kWinW * (winh + 1) * (quad ? 1 : 2); }
+constexpr int window_dwords(bool quad, int winh, int pitch = kWinW) { return pitch * (winh + 1) * (quad ? 1 : 2); }
 static_assert(kQuadShift == 2, "the window is staged from 4-byte quad entries");
 
 template <bool kQuad> struct WinEntry;
@@ -48,7 +52,7 @@ struct WinTaps {
     E top, bot;
 };
 
-template <typename E>
+template <typename E, int kPitch>
 __device__ __forceinline__ WinTaps<E> lds_read_pair(int addr)
 {
     WinTaps<E> t;
@@ -56,7 +60,7 @@ __device__ __forceinline__ WinTaps<E> lds_read_pair(int addr)
     typedef __attribute__((address_space(3))) E *lds_ptr;
     const lds_ptr p = (lds_ptr)(uintptr_t)(uint32_t)addr;
     t.top = p[0];
-    t.bot = p[kWinW];
+    t.bot = p[kPitch];
 #else
     t.top = t.bot = E();
 #endif
@@ -87,7 +91,7 @@ struct SrcWindow {
     int wx0, wy0;     // quad coordinates of window entry (0, 0) (wave-uniform)
     float lo_x, hi_x, lo_y, hi_y;  // a patch whose four corner samples lie in [lo, hi) reads the window only
     int addr0;        // LDS byte address of entry (0, 0) minus the byte offset of quad (wx0, wy0): address(qx, qy) =
-                      // qy * 4 * kWinW + 4 * qx + addr0
+                      // (qy * pitch + qx) * entry bytes + addr0
 };
 
 __device__ __forceinline__ float wave_min(float v)
@@ -110,8 +114,8 @@ __device__ __forceinline__ float wave_max(float v)
 
 // Every lane of the wave calls this (no divergence): centres a window with WINH rows of fetch positions on the bounding
 // box of the points (cx, cy) of the lanes with `ok` and copies it from the quad image.  `win` is this wave's LDS region
-// (window_dwords(kQuad, WINH) dwords).
-template <bool kQuad, int WINH>
+// (window_dwords(kQuad, WINH, kPitch) dwords).
+template <bool kQuad, int WINH, int kPitch = kWinW>
 __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, bool ok, float cx, float cy)
 {
     constexpr int kWinRows = WINH + 1;
@@ -146,7 +150,7 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
         for (int k = 0; k < kWinRows; ++k) {
             const float t0 = (float)(tmp[k] & 0xFFu);
             const float dx = (float)((tmp[k] >> 8) & 0xFFu) - t0;
-            win[k * kWinW + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, dx));
+            win[k * kPitch + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, dx));
         }
     } else {
         // the pair of texel row gy is the first half of float quad (., gy); the row below the image (gy == H, a copy
@@ -162,7 +166,7 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
         }
 #pragma unroll
         for (int k = 0; k < kWinRows; ++k) {
-            winp[k * kWinW + lane] = tmp[k];
+            winp[k * kPitch + lane] = tmp[k];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -178,22 +182,22 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
     w.hi_x = (float)(wx0 + kWinW - 1);
     w.lo_y = (float)(wy0 + 1);
     w.hi_y = (float)(wy0 + WINH - 1);
-    w.addr0 = __builtin_amdgcn_readfirstlane(lds_address(win) - (wy0 * kWinW + wx0) * (1 << kShift));
+    w.addr0 = __builtin_amdgcn_readfirstlane(lds_address(win) - (wy0 * kPitch + wx0) * (1 << kShift));
     return w;
 }
 
 // byte address of window entry (qx, qy): qy * pitch + (qx << shift) + addr0
-template <int kShift>
+template <int kShift, int kPitch>
 __device__ __forceinline__ int win_byte_address(int qx, int qy, int addr0)
 {
     int row, off;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(kWinW << kShift), "v"(addr0));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(kPitch << kShift), "v"(addr0));
     asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(off) : "v"(qx), "v"(row), "n"(kShift));
     return off;
 }
 
 // quad_row_issue / fquad_row_issue for samples known to lie inside the window: no clamps, LDS addresses.
-template <bool kQuad>
+template <bool kQuad, int kPitch>
 __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN], int addr0,
                                               float (&a)[kPatchN], float (&b)[kPatchN],
                                               WinTaps<typename WinEntry<kQuad>::type> (&t)[kPatchN])
@@ -238,12 +242,12 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = win_byte_address<WinEntry<kQuad>::kShift>(qx[j], qy[j], addr0);
+        qx[j] = win_byte_address<WinEntry<kQuad>::kShift, kPitch>(qx[j], qy[j], addr0);
     }
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        t[j] = lds_read_pair<typename WinEntry<kQuad>::type>(qx[j]);
+        t[j] = lds_read_pair<typename WinEntry<kQuad>::type, kPitch>(qx[j]);
     }
 }
 
@@ -276,7 +280,7 @@ __device__ __forceinline__ void win_row_lerp(const WinTaps<typename WinEntry<kQu
 }
 
 // ncc_fixed_moments (fast reciprocal) reading the window.
-template <bool kQuad, typename Ref>
+template <bool kQuad, int kPitch, typename Ref>
 __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homography &H, int px, int py, int addr0, float &sum_s,
                                                    float &sum_ss, float &sum_rs)
 {
@@ -292,7 +296,8 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
     WinTaps<typename WinEntry<kQuad>::type> t[2][kPatchN];
     {
         const float xf = (float)(px - kPatchRadius);
-        win_row_issue<kQuad>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[0], b[0], t[0]);
+        win_row_issue<kQuad, kPitch>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[0], b[0],
+                                     t[0]);
     }
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
@@ -307,8 +312,8 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
         APD_STAGE();
         if (i + 1 < kPatchN) {
             const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
-            win_row_issue<kQuad>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0,
-                                 a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
+            win_row_issue<kQuad, kPitch>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0,
+                                         a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
         }
         APD_STAGE();
         win_row_lerp<kQuad>(t[i & 1], a[i & 1], b[i & 1], v);
@@ -335,7 +340,7 @@ __device__ __forceinline__ void corner_position(const Homography &H, float xf, f
 }
 
 // ComputeBilateralNCCOld (APD.cu:530-614) for plane q = n/d against source view vc, window first.
-template <bool kQuad, typename Ref>
+template <bool kQuad, int kPitch = kWinW, typename Ref>
 __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const ViewConst &vc, const SrcWindow &w, const Ref &rp, int px,
                                                     int py, float qx, float qy, float qz)
 {
@@ -381,7 +386,7 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
 #endif
     float sum_s, sum_ss, sum_rs;
     if (in_window) {
-        ncc_window_moments<kQuad>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
+        ncc_window_moments<kQuad, kPitch>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
     } else if (__builtin_expect(fast_recip, 1)) {
         ncc_fixed_moments<kQuad, true, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else {
