@@ -329,6 +329,12 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
     if (__builtin_amdgcn_ballot_w64(alive) == 0) {
         return;
     }
+    // Two passes over the views.  First the current depth with K14's cost form (:2173-2183), which gives cost_now.  A
+    // depth sample only matters if it is the minimum and fl(cost_now - its cost) exceeds 0.1 (:2227); its weighted sum
+    // never decreases from view to view (weights > 0, costs and geometric terms >= 0, monotone rounding), so once the
+    // partial sum has reached `lost` -- chosen such that sum >= lost implies fl(cost_now - fl(sum / weight_normal)) <=
+    // 0.0999 -- the sample can neither be adopted nor hide an adoptable one, and its remaining views are skipped.  With
+    // cost_now below 0.0999 that is every sample from the start: the kernel then costs one NCC per selected view.
 #pragma unroll 1
     for (int v = 0; v < fa.num_src; ++v) {
         const bool use = alive && bit_test(sel, (unsigned)v) != 0;
@@ -338,30 +344,62 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
         const ViewConst &vc = fa.views[v];
         const float wv = (float)vw.get(v);
         const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use, px, py, origin, w_now);
-        // sample -1: the current depth with K14's cost form (:2173-2183); samples 0..10: LocalRefine's (:2217-2220)
+        if (use) {
+            float4 pl = origin;
+            pl.w = w_now;
+            float qx, qy, qz;
+            plane_q(pl, qx, qy, qz);
+            float tc = 0.0f;
+            tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
+            if (fa.geom_consistency) {
+                tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
+            }
+            acc_now += tc * wv;
+        }
+    }
+    float lost = __builtin_inff();
+#ifndef APD_K15_EARLY_OUT
+#define APD_K15_EARLY_OUT 1
+#endif
+    if (APD_K15_EARLY_OUT && alive && !(fa.geom_factor < 0.0f)) {
+        // bound >= cost_now - 0.0999 in real arithmetic (|cost_now| <= 2 + 3 * geom_factor: two roundings are far below 1e-6)
+        const float bound = (acc_now / weight_normal - 0.0999f) + 1e-6f;
+        if (bound <= 0.0f) {
+            lost = 0.0f;
+        } else if (bound < 16.0f) {  // false for NaN
+            lost = (bound * weight_normal) * (1.0f + 0x1p-22f);  // sum >= lost => sum / weight_normal >= bound
+        }
+    }
 #pragma unroll 1
-        for (int i = -1; i < NP; ++i) {
-            if (use && (i < 0 || ((in_range >> i) & 1u))) {
+    for (int v = 0; v < fa.num_src; ++v) {
+        const bool use = alive && bit_test(sel, (unsigned)v) != 0;
+        uint32_t open = 0;  // depth samples of this lane that can still be adopted
+        if (use) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                open |= (((in_range >> i) & 1u) && !(acc[i] >= lost)) ? (1u << i) : 0u;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(open != 0) == 0) {
+            continue;
+        }
+        const ViewConst &vc = fa.views[v];
+        const float wv = (float)vw.get(v);
+        const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use, px, py, origin, w_now);
+#pragma unroll 1
+        for (int i = 0; i < NP; ++i) {  // LocalRefine's cost form (:2217-2220)
+            if ((open >> i) & 1u) {
                 float4 pl = origin;
-                pl.w = (i < 0) ? w_now : pw[i];
+                pl.w = pw[i];
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
                 const float c = ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
-                if (i < 0) {
-                    float tc = 0.0f;
-                    tc += c;
-                    if (fa.geom_consistency) {
-                        tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
-                    }
-                    acc_now += tc * wv;
-                } else {
-                    float a = acc[i];
-                    a += c * wv;
-                    if (fa.geom_consistency) {
-                        a += fa.geom_factor * geom_cost(fa, vc, px, py, pl) * wv;
-                    }
-                    acc[i] = a;
+                float a = acc[i];
+                a += c * wv;
+                if (fa.geom_consistency) {
+                    a += fa.geom_factor * geom_cost(fa, vc, px, py, pl) * wv;
                 }
+                acc[i] = a;
             }
         }
     }
