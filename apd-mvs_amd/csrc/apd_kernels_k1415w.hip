@@ -193,36 +193,75 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
         return;
     }
 
+    // Two phases.  The classification below is WEAK whenever the lowest local minimum lies more than weak_peak_radius
+    // samples from the centre or costs more than 0.5 (:2120): if every sample within the radius costs more than 0.5, the
+    // pixel is WEAK wherever that minimum is, and the other samples are never needed.  Phase 0 therefore scores the
+    // chunks that cover [RADIUS - weak_peak_radius, RADIUS + weak_peak_radius] against every selected view; lanes that are
+    // WEAK by that argument write their result and drop out, and phase 1 scores the remaining chunks for the others
+    // (a wave of a textureless region ends after phase 0).  Every sample still adds its views in view order.
+#ifndef APD_K14_CENTRE_FIRST
+#define APD_K14_CENTRE_FIRST 1
+#endif
+    const int wr = min(max(fa.weak_peak_radius, 0), RADIUS);
+    const int centre_lo = ((RADIUS - wr) / APD_K14_CHUNK) * APD_K14_CHUNK;                        // first sample of the first centre chunk
+    const int centre_hi = APD_K14_CENTRE_FIRST ? ((RADIUS + wr) / APD_K14_CHUNK + 1) * APD_K14_CHUNK : 0;  // one past the last centre chunk
 #pragma unroll 1
-    for (int v = 0; v < fa.num_src; ++v) {
-        const bool use = alive && bit_test(sel, (unsigned)v) != 0;
-        if (__builtin_amdgcn_ballot_w64(use) == 0) {
-            continue;
-        }
-        const ViewConst &vc = fa.views[v];
-        const float wv = (float)vw.get(v);
+    for (int phase = APD_K14_CENTRE_FIRST ? 0 : 1; phase < 2; ++phase) {
 #pragma unroll 1
-        for (int c0 = 0; c0 < NP; c0 += APD_K14_CHUNK) {
-            const int c1 = min(c0 + APD_K14_CHUNK, NP);
-            if (__builtin_amdgcn_ballot_w64(use && ((in_range >> c0) & ((1ull << (c1 - c0)) - 1ull)) != 0) == 0) {
-                continue;  // nobody has a sample to score in this chunk
+        for (int v = 0; v < fa.num_src; ++v) {
+            const bool use = alive && bit_test(sel, (unsigned)v) != 0;
+            if (__builtin_amdgcn_ballot_w64(use) == 0) {
+                continue;
             }
-            const int mid = (c0 + c1) >> 1;
-            const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use && ((in_range >> mid) & 1ull) != 0, px, py, origin, pw[mid]);
+            const ViewConst &vc = fa.views[v];
+            const float wv = (float)vw.get(v);
 #pragma unroll 1
-            for (int i = c0; i < c1; ++i) {
-                if (use && ((in_range >> i) & 1ull)) {
-                    float4 pl = origin;
-                    pl.w = pw[i];
-                    float qx, qy, qz;
-                    plane_q(pl, qx, qy, qz);
-                    float tc = 0.0f;
-                    tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
-                    if (fa.geom_consistency) {
-                        tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
-                    }
-                    pc[i] += tc * wv;
+            for (int c0 = 0; c0 < NP; c0 += APD_K14_CHUNK) {
+                const bool centre_chunk = c0 >= centre_lo && c0 < centre_hi;
+                if (centre_chunk != (phase == 0)) {
+                    continue;
                 }
+                const int c1 = min(c0 + APD_K14_CHUNK, NP);
+                if (__builtin_amdgcn_ballot_w64(use && ((in_range >> c0) & ((1ull << (c1 - c0)) - 1ull)) != 0) == 0) {
+                    continue;  // nobody has a sample to score in this chunk
+                }
+                const int mid = (c0 + c1) >> 1;
+                const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use && ((in_range >> mid) & 1ull) != 0, px, py, origin, pw[mid]);
+#pragma unroll 1
+                for (int i = c0; i < c1; ++i) {
+                    if (use && ((in_range >> i) & 1ull)) {
+                        float4 pl = origin;
+                        pl.w = pw[i];
+                        float qx, qy, qz;
+                        plane_q(pl, qx, qy, qz);
+                        float tc = 0.0f;
+                        tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
+                        if (fa.geom_consistency) {
+                            tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
+                        }
+                        pc[i] += tc * wv;
+                    }
+                }
+            }
+        }
+        if (phase == 0) {
+            if (alive) {
+                bool all_high = true;
+#pragma unroll 1
+                for (int i = RADIUS - wr; i <= RADIUS + wr; ++i) {
+                    if ((in_range >> i) & 1ull) {
+                        const float p_cost = pc[i] / weight_normal;
+                        const float c = (2.0f > p_cost) ? p_cost : 2.0f;  // the clamp of :2093
+                        all_high = all_high && (c > 0.5f);
+                    }
+                }
+                if (all_high) {
+                    fa.weak_info[center] = APD_WEAK;
+                    alive = false;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(alive) == 0) {
+                return;
             }
         }
     }
