@@ -19,6 +19,7 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
 hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
 hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s);
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s);
+hipError_t launch_weak_index_map(const uint8_t *weak, size_t n, int *map, int *scratch, hipStream_t s);
 hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipStream_t s);
 hipError_t launch_pack_fquads(const float *img, int W, int H, fquad_t *fq, hipStream_t s);
 }  // namespace apd
@@ -496,20 +497,15 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
     }
     c->weak_count = 0;
     if (weak_info) {
-        // weak index map of APD.cpp:526-537 (row-major running count of WEAK pixels)
-        std::vector<uint8_t> wi(n);
-        HIP_TRY(hipMemcpy(wi.data(), weak_info, n, hipMemcpyDefault));
-        std::vector<int> map(n, 0);
+        // weak index map of APD.cpp:526-537 (row-major running count of WEAK pixels), scanned on the device; fit_planes
+        // (zeroed below, on the same stream) lends the scratch for the block sums
+        HIP_TRY(hipMemcpyAsync(c->weak_info, weak_info, n, hipMemcpyDefault, c->stream));
+        int *scratch = reinterpret_cast<int *>(c->fit_planes);
+        HIP_TRY(apd::launch_weak_index_map(c->weak_info, n, c->neighbours_map, scratch, c->stream));
         int count = 0;
-        for (size_t i = 0; i < n; ++i) {
-            if (wi[i] == APD_WEAK) {
-                map[i] = count++;
-            }
-        }
-        c->weak_count = count;
-        HIP_TRY(hipMemcpyAsync(c->weak_info, wi.data(), n, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->neighbours_map, map.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(&count, scratch + (n + 4095) / 4096, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        c->weak_count = count;
     } else {
         HIP_TRY(hipMemsetAsync(c->weak_info, APD_STRONG, n, c->stream));
         HIP_TRY(hipMemsetAsync(c->neighbours_map, 0, n * sizeof(int), c->stream));

@@ -869,6 +869,115 @@ __global__ __launch_bounds__(256) void k_export_depth_normal(FrameArgs fa, float
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weak index map of APD.cpp:526-537 on the device: map[i] = number of WEAK pixels before pixel i in row-major order
+// for a WEAK pixel, 0 for any other.  Three launches: per-block counts (4096 pixels per block, 16 consecutive pixels per
+// lane), one block that turns the counts into offsets (+ the total), per-block exclusive scan + write.
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kMapItems = 16, kMapBlock = 256, kMapChunk = kMapItems * kMapBlock;
+
+__device__ __forceinline__ int weak_bits_of_lane(const uint8_t *__restrict__ weak, size_t n, size_t first)
+{
+    int bits = 0;
+#pragma unroll
+    for (int k = 0; k < kMapItems; ++k) {
+        const size_t i = first + k;
+        if (i < n && weak[i] == APD_WEAK) {
+            bits |= 1 << k;
+        }
+    }
+    return bits;
+}
+
+// exclusive prefix of `v` over the 256 lanes of the block (lane order); *total = block sum
+__device__ __forceinline__ int block_exclusive_scan(int v, int *lds4, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) {
+            incl += o;
+        }
+    }
+    if (lane == 63) {
+        lds4[wave] = incl;
+    }
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kMapBlock / 64; ++w) {
+        const int c = lds4[w];
+        before += (w < wave) ? c : 0;
+        all += c;
+    }
+    *total = all;
+    return before + incl - v;
+}
+
+__global__ __launch_bounds__(kMapBlock) void k_weak_block_counts(const uint8_t *__restrict__ weak, size_t n, int *__restrict__ counts)
+{
+    __shared__ int lds4[kMapBlock / 64];
+    const size_t first = (size_t)blockIdx.x * kMapChunk + (size_t)threadIdx.x * kMapItems;
+    int total;
+    block_exclusive_scan(__popc(weak_bits_of_lane(weak, n, first)), lds4, &total);
+    if (threadIdx.x == 0) {
+        counts[blockIdx.x] = total;
+    }
+}
+
+// counts[0..nblocks) -> exclusive offsets in place, counts[nblocks] = total (one block, sequential over chunks of 256)
+__global__ __launch_bounds__(kMapBlock) void k_weak_block_offsets(int *__restrict__ counts, int nblocks)
+{
+    __shared__ int lds4[kMapBlock / 64];
+    int running = 0;
+    for (int base = 0; base < nblocks; base += kMapBlock) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nblocks) ? counts[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, lds4, &total);
+        if (i < nblocks) {
+            counts[i] = running + ex;
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counts[nblocks] = running;
+    }
+}
+
+__global__ __launch_bounds__(kMapBlock) void k_weak_index_map(const uint8_t *__restrict__ weak, size_t n, const int *__restrict__ offsets,
+                                                              int *__restrict__ map)
+{
+    __shared__ int lds4[kMapBlock / 64];
+    const size_t first = (size_t)blockIdx.x * kMapChunk + (size_t)threadIdx.x * kMapItems;
+    const int bits = weak_bits_of_lane(weak, n, first);
+    int total;
+    int idx = offsets[blockIdx.x] + block_exclusive_scan(__popc(bits), lds4, &total);
+#pragma unroll
+    for (int k = 0; k < kMapItems; ++k) {
+        const size_t i = first + k;
+        if (i < n) {
+            const bool w = (bits >> k) & 1;
+            map[i] = w ? idx : 0;
+            idx += w ? 1 : 0;
+        }
+    }
+}
+
+// scratch: at least ceil(n / 4096) + 1 ints; the total is left in scratch[ceil(n / 4096)]
+hipError_t launch_weak_index_map(const uint8_t *weak, size_t n, int *map, int *scratch, hipStream_t s)
+{
+    const int nblocks = (int)((n + kMapChunk - 1) / kMapChunk);
+    hipLaunchKernelGGL(k_weak_block_counts, dim3(nblocks), dim3(kMapBlock), 0, s, weak, n, scratch);
+    hipLaunchKernelGGL(k_weak_block_offsets, dim3(1), dim3(kMapBlock), 0, s, scratch, nblocks);
+    hipLaunchKernelGGL(k_weak_index_map, dim3(nblocks), dim3(kMapBlock), 0, s, weak, n, (const int *)scratch, map);
+    return hipGetLastError();
+}
+
 hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s)
 {
     hipLaunchKernelGGL(k_export_depth_normal, dim3((fa.W * fa.H + 255) / 256), dim3(256), 0, s, fa, depth, normal);
