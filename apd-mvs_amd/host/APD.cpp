@@ -5,9 +5,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 
 bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height);
@@ -191,21 +194,70 @@ bool ReadGrayImage(const path &stem, Mat &image_float)
         const char *e = getenv("APD_IMAGE_CACHE_MB");
         return (size_t)(e ? atoll(e) : 16384) << 20;
     }();
+    static std::mutex cache_mutex;  // PrefetchGrayImages and RunFusion decode on several threads
     const std::string key = stem.string();
-    auto it = cache.find(key);
-    if (it != cache.end()) {
-        image_float = it->second.clone();
-        return true;
+    {
+        std::lock_guard<std::mutex> lock(cache_mutex);
+        auto it = cache.find(key);
+        if (it != cache.end()) {
+            image_float = it->second.clone();
+            return true;
+        }
     }
     if (!read_gray_image_uncached(stem, image_float)) {
         return false;
     }
     const size_t bytes = (size_t)image_float.rows * image_float.step();
-    if (cached_bytes + bytes <= cap_bytes) {
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    if (cached_bytes + bytes <= cap_bytes && cache.find(key) == cache.end()) {
         cache.emplace(key, image_float.clone());
         cached_bytes += bytes;
     }
     return true;
+}
+
+// Runs job(0) .. job(count - 1) on up to `max_threads` host threads (0: one per core, at most 16).
+void ParallelFor(size_t count, const std::function<void(size_t)> &job, unsigned max_threads)
+{
+    unsigned n = max_threads ? max_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    n = (unsigned)std::min<size_t>(n, count);
+    if (n <= 1) {
+        for (size_t i = 0; i < count; ++i) {
+            job(i);
+        }
+        return;
+    }
+    std::vector<std::thread> pool;
+    std::mutex next_mutex;
+    size_t next = 0;
+    for (unsigned t = 0; t < n; ++t) {
+        pool.emplace_back([&] {
+            for (;;) {
+                size_t i;
+                {
+                    std::lock_guard<std::mutex> lock(next_mutex);
+                    if (next >= count) {
+                        return;
+                    }
+                    i = next++;
+                }
+                job(i);
+            }
+        });
+    }
+    for (auto &th : pool) {
+        th.join();
+    }
+}
+
+// Decodes the given images into the process cache on several threads, so that the first pass does not wait for one
+// decode after another (the reference decodes each of them serially, once per view and pass).
+void PrefetchGrayImages(const path &image_folder, const std::vector<int> &ids)
+{
+    ParallelFor(ids.size(), [&](size_t i) {
+        Mat scratch;
+        ReadGrayImage(image_folder / path(ToFormatIndex(ids[i])), scratch);
+    }, 0);
 }
 
 static bool read_gray_image_uncached(const path &stem, Mat &image_float)

@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstring>
 #include <filesystem>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -132,6 +133,9 @@ template <typename TYPE> void RescaleMatToTargetSize(const Mat &src, Mat &dst, i
 bool ReadGrayImage(const path &image_path_without_ext, Mat &image_float);
 // the same file as cv::imread(IMREAD_COLOR) returns it (fusion colours, APD.cpp:859): MAT_32FC3, blue first
 bool ReadColorImage(const path &image_path_without_ext, Mat &image_bgr);
+// host-side helpers of the drop-in (not in the reference): a small thread pool and a parallel warm-up of the image cache
+void ParallelFor(size_t count, const std::function<void(size_t)> &job, unsigned max_threads = 0);
+void PrefetchGrayImages(const path &image_folder, const std::vector<int> &ids);
 // cv::resize(float, INTER_LINEAR) restated (APD.cpp:474)
 void ResizeLinear(const Mat &src, Mat &dst, int new_cols, int new_rows);
 

@@ -81,12 +81,17 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
     const path block_folder = dense_folder / path("blocks");
     const bool use_block = std::filesystem::exists(block_folder);  // APD.cpp:849-853
     for (size_t i = 0; i < problems.size(); ++i) {
+        std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
+        index_of_id.emplace(problems[i].ref_image_id, (int)i);
+    }
+    // the views are independent here: decode, read and rescale them on several host threads
+    std::vector<int> failed(problems.size(), 0);
+    ParallelFor(problems.size(), [&](size_t i) {
         const Problem &problem = problems[i];
         FusionView &v = views[i];
-        std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
-        index_of_id.emplace(problem.ref_image_id, (int)i);
         if (!ReadColorImage(dense_folder / path("images") / path(ToFormatIndex(problem.ref_image_id)), v.image)) {
-            exit(EXIT_FAILURE);
+            failed[i] = 1;
+            return;
         }
         memset(&v.cam, 0, sizeof(v.cam));
         ReadCamera(dense_folder / path("cams") / path(ToFormatIndex(problem.ref_image_id) + "_cam.txt"), v.cam);
@@ -95,7 +100,8 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
         ReadBinMat(problem.result_folder / path("weak.bin"), v.weak);
         if (v.depth.empty() || v.normal.empty() || v.weak.empty()) {
             std::cerr << "Missing maps of view " << problem.ref_image_id << " in " << problem.result_folder << std::endl;
-            exit(EXIT_FAILURE);
+            failed[i] = 1;
+            return;
         }
         if (v.depth.cols != v.image.cols || v.depth.rows != v.image.rows) {  // RescaleImageAndCamera, APD.cpp:729-750
             const float scale_x = v.depth.cols / static_cast<float>(v.image.cols);
@@ -130,6 +136,11 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
                     v.block.ptr<uint8_t>()[k] = (uint8_t)grey.ptr<float>()[k];
                 }
             }
+        }
+    }, 0);
+    for (int f : failed) {
+        if (f) {
+            exit(EXIT_FAILURE);
         }
     }
     std::vector<std::vector<int>> sources(problems.size());

@@ -6,6 +6,7 @@
 // depths.dmb / normals.dmb / weak.bin / selected_views.bin in <dense>/APD/<%08d>/, then RunFusion ->
 // APD/APD.ply and removal of the four state files (main.cpp:219-230; --keep-maps leaves them in place).
 // Not built: the debug JPEGs of show_medium_result.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -160,6 +161,16 @@ int main(int argc, char **argv)
         }
     }
     std::cout << "There are " << problems.size() << " problems needed to be processed!" << std::endl;
+    {   // every image the passes will read, decoded once, on several host threads (each pass then copies from the cache)
+        std::vector<int> ids;
+        for (const auto &problem : problems) {
+            ids.push_back(problem.ref_image_id);
+            ids.insert(ids.end(), problem.src_image_ids.begin(), problem.src_image_ids.end());
+        }
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        PrefetchGrayImages(dense_folder / path("images"), ids);
+    }
     const int round_num = single_level ? 1 : ComputeRoundNum(problems);
     std::cout << "Round nums: " << round_num << std::endl;
     int iteration_index = 0;

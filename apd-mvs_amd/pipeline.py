@@ -365,8 +365,7 @@ def load_dense_folder(folder, camera_type):
                 srcs.append(sid)
         src_ids.append(srcs)
     index_of = {v: i for i, v in enumerate(ids)}
-    cams, imgs = [], []
-    for v in ids:
+    def load_view(v):
         cam = camera_type()
         if L.apdhost_read_camera(os.path.join(folder, "cams", "%08d_cam.txt" % v).encode(), C.byref(cam)) != 0:
             raise IOError("cannot read camera %d" % v)
@@ -377,8 +376,14 @@ def load_dense_folder(folder, camera_type):
         img = np.empty((rows.value, cols.value), np.float32)
         L.apdhost_read_gray_image(stem, C.byref(rows), C.byref(cols), img.ctypes.data_as(C.POINTER(C.c_float)), img.size)
         cam.width, cam.height = cols.value, rows.value
-        cams.append(cam)
-        imgs.append(img)
+        return cam, img
+
+    # the decoder runs outside the GIL (ctypes) and the host library's image cache is locked: one thread per image
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, max(1, len(ids)))) as pool:
+        loaded = list(pool.map(load_view, ids))
+    cams = [c for c, _ in loaded]
+    imgs = [im for _, im in loaded]
     scene = MvsScene(cams, imgs, [[index_of[s] for s in srcs if s in index_of] for srcs in src_ids])
     scene.ids = ids
     return scene
@@ -408,16 +413,22 @@ def load_colour_images(folder, ids):
     L = host_lib()
     ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
     L.apdhost_read_color_image.argtypes = [C.c_char_p, ip, ip, fp, C.c_size_t]
-    out = []
-    for v in ids:
+    def load(v):
         stem = os.path.join(folder, "images", "%08d" % v).encode()
         r, c = C.c_int(), C.c_int()
-        if L.apdhost_read_color_image(stem, C.byref(r), C.byref(c), None, 0) != 0:
+        # size from the grey read (served from the process cache after load_dense_folder) instead of a second colour decode
+        if not os.path.exists(stem.decode() + ".ppm") and L.apdhost_read_gray_image(stem, C.byref(r), C.byref(c), None, 0) == 0:
+            pass
+        elif L.apdhost_read_color_image(stem, C.byref(r), C.byref(c), None, 0) != 0:
             raise IOError("cannot read image %d of %s" % (v, folder))
         a = np.zeros((r.value, c.value, 3), np.float32)
-        L.apdhost_read_color_image(stem, C.byref(r), C.byref(c), a.ctypes.data_as(fp), a.size)
-        out.append(a)
-    return out
+        if L.apdhost_read_color_image(stem, C.byref(r), C.byref(c), a.ctypes.data_as(fp), a.size) != 0 or a.shape[:2] != (r.value, c.value):
+            raise IOError("cannot read image %d of %s" % (v, folder))
+        return a
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, max(1, len(ids)))) as pool:
+        return list(pool.map(load, ids))
 
 
 def fuse(scene, results, ply_path, device=0, colour_images=None, block_masks=None):
