@@ -161,6 +161,8 @@ static void refresh_frame_args(apd_context *c)
     fa.weak_list_cap = (int)c->weak_list_cap;
     fa.neighbours_map = c->neighbours_map;
     fa.neighbours = c->neighbours;
+    const char *eo = getenv("APD_EARLY_OUT");
+    fa.early_out = (eo && eo[0] == '0') ? 0 : 1;
 }
 
 extern "C" {

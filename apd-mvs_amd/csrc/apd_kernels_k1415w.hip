@@ -204,9 +204,9 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
 #endif
     const int wr = min(max(fa.weak_peak_radius, 0), RADIUS);
     const int centre_lo = ((RADIUS - wr) / APD_K14_CHUNK) * APD_K14_CHUNK;                        // first sample of the first centre chunk
-    const int centre_hi = APD_K14_CENTRE_FIRST ? ((RADIUS + wr) / APD_K14_CHUNK + 1) * APD_K14_CHUNK : 0;  // one past the last centre chunk
+    const int centre_hi = (APD_K14_CENTRE_FIRST && fa.early_out) ? ((RADIUS + wr) / APD_K14_CHUNK + 1) * APD_K14_CHUNK : 0;  // one past the last centre chunk
 #pragma unroll 1
-    for (int phase = APD_K14_CENTRE_FIRST ? 0 : 1; phase < 2; ++phase) {
+    for (int phase = (APD_K14_CENTRE_FIRST && fa.early_out) ? 0 : 1; phase < 2; ++phase) {
 #pragma unroll 1
         for (int v = 0; v < fa.num_src; ++v) {
             const bool use = alive && bit_test(sel, (unsigned)v) != 0;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
 #ifndef APD_K15_EARLY_OUT
 #define APD_K15_EARLY_OUT 1
 #endif
-    if (APD_K15_EARLY_OUT && alive && !(fa.geom_factor < 0.0f)) {
+    if (APD_K15_EARLY_OUT && fa.early_out && alive && !(fa.geom_factor < 0.0f)) {
         // bound >= cost_now - 0.0999 in real arithmetic (|cost_now| <= 2 + 3 * geom_factor: two roundings are far below 1e-6)
         const float bound = (acc_now / weight_normal - 0.0999f) + 1e-6f;
         if (bound <= 0.0f) {

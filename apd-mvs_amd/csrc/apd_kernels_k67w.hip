@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
     // cost_now * weight_norm -- the quotient can no longer be below cost_now: the remaining views of that hypothesis are
     // skipped and the accept test below rejects it exactly as it would reject the full sum.  In converged iterations
     // that removes most NCCs of the two random-depth hypotheses, which are also the ones that miss the windows.
-    const float lost = refinement_lost_bound(cost_now, weight_norm);
+    const float lost = refinement_lost_bound(fa, cost_now, weight_norm);
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
         const uint32_t wv = alive ? vw.get(v) : 0u;

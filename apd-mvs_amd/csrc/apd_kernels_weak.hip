@@ -803,7 +803,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
         // hypotheses 9..14 are only compared with the running cost (:932, :974): a partial sum that has reached `lost`
         // cannot win any more and the remaining views are skipped (refinement_lost_bound, apd_sweep.h; the geometric term
         // is >= 0 for the non-negative geom_factor the bound needs)
-        const float lost = (h <= 14 && !(fa.geom_factor < 0.0f)) ? refinement_lost_bound(cost_now, weight_norm) : __builtin_inff();
+        const float lost = (h <= 14 && !(fa.geom_factor < 0.0f)) ? refinement_lost_bound(fa, cost_now, weight_norm) : __builtin_inff();
 #pragma unroll 1
         for (int v = 0; v < nsrc; ++v) {
             const ViewConst &vc = fa.views[v];

@@ -210,10 +210,10 @@ __device__ __forceinline__ void select_views(const FrameArgs &fa, int iter, cons
 #ifndef APD_REFINE_EARLY_OUT
 #define APD_REFINE_EARLY_OUT 1
 #endif
-__device__ __forceinline__ float refinement_lost_bound(float cost, float weight_norm)
+__device__ __forceinline__ float refinement_lost_bound(const FrameArgs &fa, float cost, float weight_norm)
 {
     const float p = cost * weight_norm;
-    if (!APD_REFINE_EARLY_OUT || !(p >= 0x1p-100f) || !(weight_norm > 0.0f)) {
+    if (!APD_REFINE_EARLY_OUT || !fa.early_out || !(p >= 0x1p-100f) || !(weight_norm > 0.0f)) {
         return __builtin_inff();
     }
     return p * (1.0f + 0x1p-22f);

@@ -581,7 +581,8 @@ void APD::InuputInitialization()
             RescaleMatToTargetSize<float>(depth, depth, width, height);
             RescaleMatToTargetSize<Vec3f>(normal, normal, width, height);
         }
-        for (int row = 0; row < height; ++row) {
+        ParallelFor((size_t)height, [&](size_t r) {
+            const int row = (int)r;
             for (int col = 0; col < width; ++col) {
                 float4 &p = plane_hypotheses_host[(size_t)row * width + col];
                 const Vec3f &n = normal.at<Vec3f>(row, col);
@@ -590,7 +591,7 @@ void APD::InuputInitialization()
                 p.y = n[1];
                 p.z = n[2];
             }
-        }
+        }, 0);
         ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
         if (selected_views_host.cols != width || selected_views_host.rows != height) {
             std::cerr << "Select view doesn't match the images' size!\n";

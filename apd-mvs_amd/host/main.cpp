@@ -91,17 +91,19 @@ void ProcessProblem(const Problem &problem)
     Mat depth(height, width, MAT_32FC1);
     Mat normal(height, width, MAT_32FC3);
     Mat pixel_states = apd.GetPixelStates();
-    for (int r = 0; r < height; ++r) {
+    const float depth_min = apd.GetDepthMin(), depth_max = apd.GetDepthMax();
+    ParallelFor((size_t)height, [&](size_t row) {  // main.cpp:105-115, rows on several host threads
+        const int r = (int)row;
         for (int c = 0; c < width; ++c) {
             const float4 plane_hypothesis = apd.GetPlaneHypothesis(r, c);
             depth.at<float>(r, c) = plane_hypothesis.w;
-            if (depth.at<float>(r, c) < apd.GetDepthMin() || depth.at<float>(r, c) > apd.GetDepthMax()) {
+            if (depth.at<float>(r, c) < depth_min || depth.at<float>(r, c) > depth_max) {
                 depth.at<float>(r, c) = 0;
                 pixel_states.at<uint8_t>(r, c) = UNKNOWN;
             }
             normal.at<Vec3f>(r, c) = Vec3f{{plane_hypothesis.x, plane_hypothesis.y, plane_hypothesis.z}};
         }
-    }
+    });
     WriteBinMat(problem.result_folder / path("depths.dmb"), depth);
     WriteBinMat(problem.result_folder / path("normals.dmb"), normal);
     WriteBinMat(problem.result_folder / path("weak.bin"), pixel_states);

@@ -149,6 +149,46 @@ def test_window_and_global_post_loop_kernels_agree(gpu_pkg, synth, monkeypatch):
     assert out["1"] == out["0"]
 
 
+def test_early_outs_change_no_bit(gpu_pkg, synth, monkeypatch):
+    """The exact early-outs (refinement hypotheses of K6/K7 and K9/K10 that can no longer beat the running cost, K15's depth
+    samples that cannot be adopted, K14's centre-first classification) against APD_EARLY_OUT=0, which
+    evaluates every NCC the reference evaluates: every state array identical after each of the three pass kinds, weak
+    pixels and the geometric term included, at a size the oracle cannot reach."""
+    import torch
+    W, H, N = 1024, 768, 6
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("APD_EARLY_OUT", mode)
+        sc = synth.make_scene(W, H, N, seed=9, device="cuda", textureless=0.25)
+        cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+        dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
+        digests, weak_counts = [], []
+        prior = None
+        passes = [dict(state=gpu_pkg.FIRST_INIT, use_APD=0, weak_peak_radius=6),
+                  dict(state=gpu_pkg.REFINE_INIT, use_APD=1, weak_peak_radius=6, rotate_time=2, ransac_threshold=0.01 - 0.00125),
+                  dict(state=gpu_pkg.REFINE_ITER, use_APD=1, weak_peak_radius=2, rotate_time=2, ransac_threshold=0.01 - 0.00125,
+                       geom_consistency=1)]
+        for pi, extra in enumerate(passes):
+            p = gpu_pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, max_iterations=3, seed=41 + pi, **extra)
+            h = gpu_pkg.Handle(W, H, p, device=0)
+            deps = [sc.gt_depth] * (N + 1) if extra.get("geom_consistency") else None
+            h.upload_views(cams, sc.images, deps)
+            if prior is not None:
+                h.upload_prior(*prior)
+            h.run()
+            weak_counts.append(h.weak_count)
+            planes, weak, views = h.download()
+            digests.append(_digest([planes, weak, views, h.state(gpu_pkg.STATE_COSTS), h.state(gpu_pkg.STATE_RNG),
+                                    h.state(gpu_pkg.STATE_VIEW_WEIGHT)]))
+            prior = common.postprocess(planes, weak, views, np.float32(dmin), np.float32(dmax))
+            h.close()
+        out[mode] = digests
+        assert weak_counts[1] > 1000   # the weak sweep really ran
+        del sc
+        torch.cuda.empty_cache()
+    assert out["1"] == out["0"]
+
+
 def test_recycled_handle_equals_a_new_one(gpu_pkg, synth):
     """apd_reset: a handle that already ran another (view, pass) -- other images, other parameters, geometric term, WEAK
     pixels -- gives the same bits as a freshly created one."""
