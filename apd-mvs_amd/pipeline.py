@@ -271,8 +271,8 @@ def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=
             planes, weak, views = call_backend(W, H, p, [cams[j] for j in order], [imgs[j] for j in order], depths, prior)
             d = planes[..., 3]
             bad = (d < p["depth_min"]) | (d > p["depth_max"])   # main.cpp:109-112 (float32 comparisons)
-            d[bad] = 0
-            weak[bad] = 2
+            d.masked_fill_(bad, 0)      # in place on the strided view; no host synchronisation (unlike d[bad] = 0)
+            weak.masked_fill_(bad, 2)
             state[idx] = (planes, weak, views)
             depth_store[idx] = d.contiguous()
             if log:
