@@ -340,6 +340,13 @@ __global__ __launch_bounds__(256) void k4_neighbour_update(FrameArgs fa)
 
 __global__ __launch_bounds__(256) void k8_ransac_fit_plane(FrameArgs fa)
 {
+    // The up to eight neighbour points of a lane are indexed by random draws: kept in LDS ([slot][lane], conflict free)
+    // instead of private arrays, which the compiler can only place in scratch memory (50 draws x ~11 dependent scratch
+    // loads per WEAK pixel made this kernel latency bound: 9.0 -> 2.6 ms per launch at 4096x3072, 18 % WEAK).  The same change
+    // makes K3 slower (15 -> 33 ms): its 32 candidate slots need 40 KB per wave, four waves per CU.
+    __shared__ float lds_x[8][256], lds_y[8][256], lds_z[8][256];
+    __shared__ int lds_p[8][256];
+    const int lane = threadIdx.x;
     const int center = blockIdx.x * 256 + threadIdx.x;
     const int W = fa.W;
     if (center >= W * fa.H) {
@@ -353,19 +360,19 @@ __global__ __launch_bounds__(256) void k8_ransac_fit_plane(FrameArgs fa)
     const int py = center / W, px = center - py * W;
     Rng rng = rng_load(fa.rng, center);
     const short2 *nb = &fa.neighbours[(size_t)fa.neighbours_map[center] * APD_NEIGHBOUR_NUM];
-    short2 pts[8];
-    float3 pts3d[8];
     int count = 0;
     for (int i = 1; i < APD_NEIGHBOUR_NUM; ++i) {
         const short2 q = nb[i];
         if (q.x == -1 || q.y == -1) {
             continue;
         }
-        pts[count] = q;
+        lds_p[count][lane] = (int)(unsigned short)q.x | ((int)q.y << 16);
         const float depth = depth_from_plane(fa, fa.planes[q.x + q.y * W], q.x, q.y);
         float X, Y, Z;
         point3d(fa, q.x, q.y, depth, X, Y, Z);
-        pts3d[count] = make_float3(X, Y, Z);
+        lds_x[count][lane] = X;
+        lds_y[count][lane] = Y;
+        lds_z[count][lane] = Z;
         count++;
     }
     if (count < 3) {
@@ -383,10 +390,14 @@ __global__ __launch_bounds__(256) void k8_ransac_fit_plane(FrameArgs fa)
         if (a == b || b == c || a == c) {
             continue;
         }
-        if (!point_in_triangle(pts[a], pts[b], pts[c], px, py)) {
+        const int pa = lds_p[a][lane], pb = lds_p[b][lane], pc = lds_p[c][lane];
+        if (!point_in_triangle(make_short2((short)(pa & 0xFFFF), (short)(pa >> 16)), make_short2((short)(pb & 0xFFFF), (short)(pb >> 16)),
+                               make_short2((short)(pc & 0xFFFF), (short)(pc >> 16)), px, py)) {
             continue;
         }
-        const float3 A = pts3d[a], B = pts3d[b], C = pts3d[c];
+        const float3 A = make_float3(lds_x[a][lane], lds_y[a][lane], lds_z[a][lane]);
+        const float3 B = make_float3(lds_x[b][lane], lds_y[b][lane], lds_z[b][lane]);
+        const float3 C = make_float3(lds_x[c][lane], lds_y[c][lane], lds_z[c][lane]);
         const float ACx = A.x - C.x, ACy = A.y - C.y, ACz = A.z - C.z;
         const float BCx = B.x - C.x, BCy = B.y - C.y, BCz = B.z - C.z;
         float nx = ACy * BCz - BCy * ACz;
@@ -402,8 +413,7 @@ __global__ __launch_bounds__(256) void k8_ransac_fit_plane(FrameArgs fa)
             if (k == a || k == b || k == c) {
                 continue;
             }
-            const float3 P = pts3d[k];
-            tc += fabsf(nx * P.x + ny * P.y + nz * P.z + nw);
+            tc += fabsf(nx * lds_x[k][lane] + ny * lds_y[k][lane] + nz * lds_z[k][lane] + nw);
         }
         if (tc < min_cost) {
             min_cost = tc;
