@@ -225,6 +225,8 @@ static int initial_state(apd_context *c)
     return APD_OK;
 }
 
+static int create_buffers(apd_context *c, int width, int height, const apd_params *params);
+
 int apd_create(apd_handle *out, int device, int width, int height, const apd_params *params)
 {
     if (!out || !params || width <= 0 || height <= 0) {
@@ -241,6 +243,18 @@ int apd_create(apd_handle *out, int device, int width, int height, const apd_par
         HIP_TRY(hipSetDevice(device));
     }
     apd_context *c = new apd_context();
+    const int st = create_buffers(c, width, height, params);
+    if (st != APD_OK) {
+        apd_destroy(c);  // frees whatever was allocated before the failure (null pointers are skipped), the stream, the context
+        return st;
+    }
+    *out = c;
+    return APD_OK;
+}
+
+// Allocations of CudaSpaceInitialization (APD.cpp:636-666).  On failure the caller (apd_create) destroys the context.
+static int create_buffers(apd_context *c, int width, int height, const apd_params *params)
+{
     HIP_TRY(hipGetDevice(&c->device));
     c->W = width;
     c->H = height;
@@ -269,7 +283,6 @@ int apd_create(apd_handle *out, int device, int width, int height, const apd_par
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     refresh_frame_args(c);
-    *out = c;
     return APD_OK;
 }
 
@@ -515,6 +528,8 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
     const size_t need = (size_t)(c->weak_count > 0 ? c->weak_count : 1);
     if (need > c->neighbours_cap) {
         hipFree(c->neighbours);
+        c->neighbours = nullptr;  // a failing re-allocation must not leave a dangling pointer for apd_destroy
+        c->neighbours_cap = 0;
         HIP_TRY(hipMalloc(&c->neighbours, need * APD_NEIGHBOUR_NUM * sizeof(short2)));
         c->neighbours_cap = need;
     }
@@ -522,6 +537,7 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
     if (need > c->weak_list_cap) {  // one colour holds at most every WEAK pixel; +1 int for the list length
         hipFree(c->weak_list);
         c->weak_list = nullptr;
+        c->weak_list_cap = 0;
         HIP_TRY(hipMalloc(&c->weak_list, (need + 1) * sizeof(int)));
         c->weak_list_cap = need;
     }

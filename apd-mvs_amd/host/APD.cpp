@@ -516,6 +516,16 @@ void APD::InuputInitialization()
         std::cout << "Scale images and cameras done\n";
     }
     std::cout << "Image size: " << width << " * " << height << std::endl;
+    // The device path keeps every view as width x height floats (apd_upload_views copies exactly that much from every
+    // pointer): a source image of another size than the reference image is refused here, with the message the reference's
+    // CheckImages prints for mismatching reference images (main.cpp:51-70, :158).
+    for (int i = 0; i < num_images; ++i) {
+        if (images[i].cols != width || images[i].rows != height || images[i].type != MAT_32FC1) {
+            std::cerr << "Images may error, check it! (image " << ids[i] << " is " << images[i].cols << " * " << images[i].rows
+                      << ", expected " << width << " * " << height << ")\n";
+            exit(EXIT_FAILURE);
+        }
+    }
     // depth maps of the previous pass for the geometric term (APD.cpp:492-510)
     depths.clear();
     if (params_host.geom_consistency) {
@@ -532,6 +542,10 @@ void APD::InuputInitialization()
                 std::cerr << "Missing depth map of a previous pass\n";
                 exit(EXIT_FAILURE);
             }
+            if (depth.type != MAT_32FC1) {
+                std::cerr << "depths.dmb of a previous pass is not a float map\n";
+                exit(EXIT_FAILURE);
+            }
             if (depth.cols != width || depth.rows != height) {
                 RescaleMatToTargetSize<float>(depth, depth, width, height);
             }
@@ -545,6 +559,10 @@ void APD::InuputInitialization()
             exit(EXIT_FAILURE);
         }
         ReadBinMat(weak_info_path, weak_info_host);
+        if (weak_info_host.empty() || weak_info_host.type != MAT_8UC1) {
+            std::cerr << "Unreadable or mistyped weak info file: " << weak_info_path.string() << std::endl;
+            exit(EXIT_FAILURE);
+        }
         if (weak_info_host.cols != width || weak_info_host.rows != height) {
             std::cerr << "Weak info doesn't match the images' size!\n";
             RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
@@ -572,8 +590,8 @@ void APD::InuputInitialization()
         Mat depth, normal;
         ReadBinMat(problem.result_folder / path("depths.dmb"), depth);
         ReadBinMat(problem.result_folder / path("normals.dmb"), normal);
-        if (depth.empty() || normal.empty()) {
-            std::cerr << "Missing depths.dmb / normals.dmb of a previous pass\n";
+        if (depth.empty() || normal.empty() || depth.type != MAT_32FC1 || normal.type != MAT_32FC3) {
+            std::cerr << "Missing or mistyped depths.dmb / normals.dmb of a previous pass\n";
             exit(EXIT_FAILURE);
         }
         if (depth.cols != width || depth.rows != height || normal.cols != width || normal.rows != height) {
@@ -593,6 +611,10 @@ void APD::InuputInitialization()
             }
         }, 0);
         ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
+        if (selected_views_host.empty() || selected_views_host.type != MAT_32SC1) {
+            std::cerr << "Missing or mistyped selected_views.bin of a previous pass\n";
+            exit(EXIT_FAILURE);
+        }
         if (selected_views_host.cols != width || selected_views_host.rows != height) {
             std::cerr << "Select view doesn't match the images' size!\n";
             RescaleMatToTargetSize<uint32_t>(selected_views_host, selected_views_host, width, height);

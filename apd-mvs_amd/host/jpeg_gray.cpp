@@ -158,7 +158,7 @@ void idct_islow(const int *coef, uint8_t *out, int stride)
     for (int c = 0; c < 8; ++c) {  // columns
         const int *in = coef + c;
         if (in[8] == 0 && in[16] == 0 && in[24] == 0 && in[32] == 0 && in[40] == 0 && in[48] == 0 && in[56] == 0) {
-            const long dc = (long)in[0] << PASS1_BITS;
+            const long dc = (long)in[0] * (1L << PASS1_BITS);
             for (int r = 0; r < 8; ++r) {
                 ws[r * 8 + c] = dc;
             }
@@ -170,8 +170,8 @@ void idct_islow(const int *coef, uint8_t *out, int stride)
         long tmp3 = z1 + z2 * FIX_0_765366865;
         z2 = in[0];
         z3 = in[32];
-        long tmp0 = (z2 + z3) << CONST_BITS;
-        long tmp1 = (z2 - z3) << CONST_BITS;
+        long tmp0 = (z2 + z3) * (1L << CONST_BITS);
+        long tmp1 = (z2 - z3) * (1L << CONST_BITS);
         long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = in[56];
         tmp1 = in[40];
@@ -211,8 +211,8 @@ void idct_islow(const int *coef, uint8_t *out, int stride)
         long z1 = (z2 + z3) * FIX_0_541196100;
         long tmp2 = z1 + z3 * (-FIX_1_847759065);
         long tmp3 = z1 + z2 * FIX_0_765366865;
-        long tmp0 = (w[0] + w[4]) << CONST_BITS;
-        long tmp1 = (w[0] - w[4]) << CONST_BITS;
+        long tmp0 = (w[0] + w[4]) * (1L << CONST_BITS);
+        long tmp1 = (w[0] - w[4]) * (1L << CONST_BITS);
         long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7];
         tmp1 = w[5];
@@ -404,7 +404,8 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
             height = be16(seg + 1);
             width = be16(seg + 3);
             ncomp = seg[5];
-            if ((ncomp != 1 && ncomp != 3) || seglen < 6 + 3 * ncomp || width <= 0 || height <= 0) {
+            if ((ncomp != 1 && ncomp != 3) || seglen < 6 + 3 * ncomp || width <= 0 || height <= 0 ||
+                (long long)width * height > (1LL << 28)) {  // 268 Mpix: ten times the largest ETH3D image; keeps a corrupt header from asking for 4 Gpix
                 return false;
             }
             for (int c = 0; c < ncomp; ++c) {
@@ -412,7 +413,7 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
                 comp[c].h = seg[7 + 3 * c] >> 4;
                 comp[c].v = seg[7 + 3 * c] & 15;
                 comp[c].tq = seg[8 + 3 * c];
-                if (comp[c].h < 1 || comp[c].v < 1 || comp[c].tq > 3) {
+                if (comp[c].h < 1 || comp[c].v < 1 || comp[c].h > 4 || comp[c].v > 4 || comp[c].tq > 3) {  // T.81 B.2.2
                     return false;
                 }
                 hmax = comp[c].h > hmax ? comp[c].h : hmax;
@@ -447,6 +448,9 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
                 }
                 comp[ci].td = seg[2 + 2 * s] >> 4;
                 comp[ci].ta = seg[2 + 2 * s] & 15;
+                if (comp[ci].td > 3 || comp[ci].ta > 3) {
+                    return false;  // baseline allows table ids 0..3 (T.81 B.2.3); anything else would index past dc[] / ac[]
+                }
                 scan_comp[s] = ci;
             }
             pos += len;

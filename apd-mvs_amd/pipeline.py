@@ -365,6 +365,15 @@ def load_dense_folder(folder, camera_type):
                 srcs.append(sid)
         src_ids.append(srcs)
     index_of = {v: i for i, v in enumerate(ids)}
+    # A source needs an entry of its own: geometric passes read its depth map (APD.cpp:492-509) and the fusion looks its view
+    # up by id (APD.cpp:899; an unknown id silently becomes view 0 there).  The drop-in binary refuses such folders with the
+    # same message (host/main.cpp), so the two schedulers cannot diverge on them.
+    for v, srcs in zip(ids, src_ids):
+        for s_id in srcs:
+            if s_id not in index_of:
+                raise ValueError("pair.txt: view %d lists source %d, which has no entry of its own" % (v, s_id))
+            if s_id == v:
+                raise ValueError("pair.txt: view %d lists itself as a source" % v)
     def load_view(v):
         cam = camera_type()
         if L.apdhost_read_camera(os.path.join(folder, "cams", "%08d_cam.txt" % v).encode(), C.byref(cam)) != 0:
@@ -384,7 +393,7 @@ def load_dense_folder(folder, camera_type):
         loaded = list(pool.map(load_view, ids))
     cams = [c for c, _ in loaded]
     imgs = [im for _, im in loaded]
-    scene = MvsScene(cams, imgs, [[index_of[s] for s in srcs if s in index_of] for srcs in src_ids])
+    scene = MvsScene(cams, imgs, [[index_of[s] for s in srcs] for srcs in src_ids])
     scene.ids = ids
     return scene
 

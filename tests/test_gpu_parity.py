@@ -173,7 +173,7 @@ def test_randomised_three_pass_cases(gpu_pkg, ob, synth, case):
 
 
 @pytest.mark.parametrize("W,H,N,float_images", [(80, 60, 20, False), (72, 56, 12, True), (64, 48, 31, False)])
-def test_many_source_views(gpu_pkg, ob, synth, W, H, N, float_images):
+def test_many_source_views_three_pass(gpu_pkg, ob, synth, W, H, N, float_images):
     """The 16- and 32-view instantiations of the sweep kernels (the reference allows MAX_IMAGES = 32 including the
     reference view, main.h:8) through the three pass kinds, bit-identical after every pass."""
     sc, imgs = common.scene_inputs(synth, W, H, N, seed=2, textureless=0.2)

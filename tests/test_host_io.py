@@ -210,3 +210,69 @@ def test_colour_jpeg_decode_matches_libjpeg(host, tmp_path, size):
     assert host.apdhost_read_color_image(stem.encode(), C.byref(r), C.byref(c), out.ctypes.data_as(fp), out.size) == 0
     ref = np.asarray(Image.open(stem + ".jpg")).astype(np.float32)
     assert np.array_equal(out[..., 0], ref) and np.array_equal(out[..., 1], ref) and np.array_equal(out[..., 2], ref)
+
+
+def test_malformed_jpegs_never_leave_their_buffers(tmp_path):
+    """The decoder replaces libjpeg for every input image of the drop-in binary, so dataset files reach it directly: corrupt
+    files may be refused or decoded to garbage, never read or written out of bounds.  The decoder is built with
+    AddressSanitizer + UBSan (CPU) around tests/helpers/jpeg_fuzz.cpp and fed truncated files, random byte flips and the
+    crafted SOS header whose Huffman table selectors (0..15 in the file) used to index dc[4] / ac[4] unchecked."""
+    import subprocess
+    Image = pytest.importorskip("PIL.Image")
+    here = os.path.dirname(os.path.abspath(__file__))
+    out_dir = os.path.join(here, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "jpeg_fuzz_asan")
+    srcs = [os.path.join(here, "helpers", "jpeg_fuzz.cpp"), os.path.join(ROOT, "apd-mvs_amd", "host", "jpeg_gray.cpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-fno-omit-frame-pointer"] + srcs + ["-o", exe])
+    rng = np.random.RandomState(5)
+    seeds = []
+    for k, (mode, sub, size, extra) in enumerate([("L", 0, (40, 30), {}), ("RGB", 2, (37, 29), {}), ("RGB", 1, (48, 16), {}),
+                                                   ("RGB", 0, (24, 24), {"optimize": True})]):
+        w, h = size
+        img = (rng.rand(h, w, 3) * 255).astype(np.uint8)
+        p = tmp_path / ("seed%d.jpg" % k)
+        kw = dict(extra)
+        if mode == "RGB":
+            kw["subsampling"] = sub
+        Image.fromarray(img if mode == "RGB" else img[..., 0], mode).save(p, quality=85, **kw)
+        seeds.append(p.read_bytes())
+    files = []
+
+    def emit(data):
+        p = tmp_path / ("m%04d.jpg" % len(files))
+        p.write_bytes(bytes(data))
+        files.append(str(p))
+
+    for data in seeds:
+        emit(data)  # the intact file must decode
+        sos = data.find(b"\xff\xda")
+        assert sos > 0
+        ns = data[sos + 4]
+        for s in range(ns):  # table selectors beyond 3, one component at a time and all at once
+            for val in (0x40, 0x04, 0xF0, 0x0F, 0xFF):
+                d = bytearray(data)
+                d[sos + 6 + 2 * s] = val
+                emit(d)
+        d = bytearray(data)
+        for s in range(ns):
+            d[sos + 6 + 2 * s] = 0xFF
+        emit(d)
+        for cut in (2, 10, sos, sos + 5, sos + 12, len(data) // 2, len(data) - 2):  # truncations
+            emit(data[:cut])
+        for _ in range(60):  # random flips in the headers (before the scan data) and in the entropy-coded segment
+            d = bytearray(data)
+            for _ in range(rng.randint(1, 4)):
+                lo, hi = (2, sos + 14) if rng.rand() < 0.7 else (sos + 14, len(d))
+                d[rng.randint(lo, hi)] = rng.randint(0, 256)
+            emit(d)
+    r = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, "sanitizer report:\n" + r.stderr[-4000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(files)
+    intact = [ln for ln in lines if "seed" not in ln and ln.split()[0].endswith(("m0000.jpg",))]
+    assert intact and "grey=1 colour=1" in intact[0]
+    refused = sum("grey=0" in ln for ln in lines)
+    assert refused > 20, "the crafted selector / truncated files must be refused"
