@@ -56,6 +56,11 @@ struct orc_state {
     int32_t *neighbours_map;
     int16_t *neighbours; /* 2*9 per weak pixel */
     int weak_count;
+    /* Region of interest of the kernel loops (orc_set_roi): [rx0, rx1) x [ry0, ry1), the whole image by default.
+     * The arrays always have full size; a kernel only visits (and only writes) the pixels of the region.  Every kernel
+     * of the path computes a pixel from state the same launch does not write (red/black colouring, APD.cu:1510-1585;
+     * per-pixel kernels read their own pixel and read-only maps), so the region's results equal the full run's. */
+    int rx0, ry0, rx1, ry1;
 };
 
 static int g_threads = 0;
@@ -828,13 +833,16 @@ static void k1_init_random_states(orc_state *s) /* :791-804: curand_init(seed, r
 {
     const int W = s->width, H = s->height;
     xorwow_tables();
+    (void)H;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(orc_get_threads())
-    for (int y = 0; y < H; ++y) {
+    for (int y = s->ry0; y < s->ry1; ++y) {
         uint32_t st[6];
         orc_xorwow_init(s->params.seed, (uint64_t)y, 0, st);
-        for (int x = 0; x < W; ++x) {
+        for (int x = 0; x < s->rx1; ++x) {
             /* offset x = x steps of the xorshift part; Weyl term advanced alike */
-            memcpy(&s->rng[6 * ((size_t)y * W + x)], st, sizeof(st));
+            if (x >= s->rx0) {
+                memcpy(&s->rng[6 * ((size_t)y * W + x)], st, sizeof(st));
+            }
             xs_step(st);
             st[5] += 362437u;
         }
@@ -843,12 +851,12 @@ static void k1_init_random_states(orc_state *s) /* :791-804: curand_init(seed, r
 
 static void k5_random_initialization(orc_state *s) /* :806-835 */
 {
-    const int W = s->width, H = s->height;
+    const int W = s->width;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(orc_get_threads())
-    for (int y = 0; y < H; ++y) {
-        for (int x = 0; x < W; ++x) {
+    for (int y = s->ry0; y < s->ry1; ++y) {
+        for (int x = s->rx0; x < s->rx1; ++x) {
             const int center = y * W + x;
-            float *pl = &s->planes[4 * center];
+            float *pl = &s->planes[4 * (size_t)center];
             if (s->params.state == ORC_FIRST_INIT) {
                 random_plane(&s->cams[0], x, y, &s->rng[6 * (size_t)center], s->params.depth_min, s->params.depth_max, pl);
                 s->costs[center] = initial_cost_and_views(s, x, y);
@@ -1305,11 +1313,12 @@ static inline int half_launch_rows(int H) { return ((H / 2 + 15) / 16) * 16; }
 #define ORC_FOR_COLOUR(s, colour, BODY)                                                         \
     {                                                                                           \
         const int W_ = (s)->width, H_ = (s)->height, GY_ = half_launch_rows(H_);                \
+        const int G0_ = (s)->ry0 / 2, G1_ = ((s)->ry1 + 1) / 2 < GY_ ? ((s)->ry1 + 1) / 2 : GY_;   \
         _Pragma("omp parallel for schedule(dynamic, 2) num_threads(orc_get_threads())")         \
-        for (int gy_ = 0; gy_ < GY_; ++gy_) {                                                   \
-            for (int x = 0; x < W_; ++x) {                                                      \
+        for (int gy_ = G0_; gy_ < G1_; ++gy_) {                                                 \
+            for (int x = (s)->rx0; x < (s)->rx1; ++x) {                                         \
                 const int y = 2 * gy_ + (((x & 1) == 0) ? (colour) : 1 - (colour));             \
-                if (y >= H_) {                                                                  \
+                if (y >= H_ || y < (s)->ry0 || y >= (s)->ry1) {                                 \
                     continue;                                                                   \
                 }                                                                               \
                 BODY                                                                            \
@@ -1341,14 +1350,15 @@ static void k910_update_weak(orc_state *s, int colour, int iter) /* :1510-1545 *
 
 static void k11_depth_and_normal(orc_state *s) /* :1587-1602 */
 {
-    const int n = s->width * s->height;
 #pragma omp parallel for num_threads(orc_get_threads())
-    for (int center = 0; center < n; ++center) {
-        float *pl = &s->planes[4 * (size_t)center];
-        pl[3] = orc_depth_from_plane(&s->cams[0], pl, center % s->width, center / s->width);
-        float t[4];
-        normal_cam_to_world(&s->cams[0], pl, t);
-        memcpy(pl, t, sizeof(t));
+    for (int y = s->ry0; y < s->ry1; ++y) {
+        for (int x = s->rx0; x < s->rx1; ++x) {
+            float *pl = &s->planes[4 * ((size_t)y * s->width + x)];
+            pl[3] = orc_depth_from_plane(&s->cams[0], pl, x, y);
+            float t[4];
+            normal_cam_to_world(&s->cams[0], pl, t);
+            memcpy(pl, t, sizeof(t));
+        }
     }
 }
 
@@ -1396,10 +1406,10 @@ static void k1213_filter(orc_state *s, int colour) /* :1716-1748 */
 
 static void k2_find_nearest_strong(orc_state *s) /* :2234-2270 */
 {
-    const int W = s->width, H = s->height;
+    const int W = s->width;
 #pragma omp parallel for schedule(dynamic, 2) num_threads(orc_get_threads())
-    for (int py = 0; py < H; ++py) {
-        for (int px = 0; px < W; ++px) {
+    for (int py = s->ry0; py < s->ry1; ++py) {
+        for (int px = s->rx0; px < s->rx1; ++px) {
             const int center = px + py * W;
             int16_t *out = &s->nearest_strong[2 * (size_t)center];
             out[0] = -1;
@@ -1643,10 +1653,10 @@ static void gen_neighbours_pixel(orc_state *s, int px, int py) /* :1750-1969 */
 
 static void k3_gen_neighbours(orc_state *s)
 {
-    const int W = s->width, H = s->height;
+    const int W = s->width;
 #pragma omp parallel for schedule(dynamic, 2) num_threads(orc_get_threads())
-    for (int y = 0; y < H; ++y) {
-        for (int x = 0; x < W; ++x) {
+    for (int y = s->ry0; y < s->ry1; ++y) {
+        for (int x = s->rx0; x < s->rx1; ++x) {
             if (s->weak_info[x + y * W] == ORC_WEAK) {
                 gen_neighbours_pixel(s, x, y);
             }
@@ -1656,10 +1666,12 @@ static void k3_gen_neighbours(orc_state *s)
 
 static void k4_neighbour_update(orc_state *s) /* :1971-1987 */
 {
-    const int n = s->width * s->height;
-    for (int c = 0; c < n; ++c) {
-        if (s->weak_info[c] == ORC_WEAK && s->weak_reliable[c] != 1) {
-            s->weak_info[c] = ORC_UNKNOWN;
+    for (int y = s->ry0; y < s->ry1; ++y) {
+        for (int x = s->rx0; x < s->rx1; ++x) {
+            const size_t c = (size_t)y * s->width + x;
+            if (s->weak_info[c] == ORC_WEAK && s->weak_reliable[c] != 1) {
+                s->weak_info[c] = ORC_UNKNOWN;
+            }
         }
     }
 }
@@ -1757,10 +1769,9 @@ static void ransac_fit_pixel(orc_state *s, int px, int py) /* :2272-2384 */
 
 static void k8_ransac_fit_plane(orc_state *s)
 {
-    const int W = s->width, H = s->height;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(orc_get_threads())
-    for (int y = 0; y < H; ++y) {
-        for (int x = 0; x < W; ++x) {
+    for (int y = s->ry0; y < s->ry1; ++y) {
+        for (int x = s->rx0; x < s->rx1; ++x) {
             ransac_fit_pixel(s, x, y);
         }
     }
@@ -1945,10 +1956,9 @@ static void local_refine_pixel(orc_state *s, int px, int py) /* :2146-2232 */
 
 static void k14_depth_to_weak(orc_state *s)
 {
-    const int W = s->width, H = s->height;
 #pragma omp parallel for schedule(dynamic, 2) num_threads(orc_get_threads())
-    for (int y = 0; y < H; ++y) {
-        for (int x = 0; x < W; ++x) {
+    for (int y = s->ry0; y < s->ry1; ++y) {
+        for (int x = s->rx0; x < s->rx1; ++x) {
             depth_to_weak_pixel(s, x, y);
         }
     }
@@ -1956,10 +1966,9 @@ static void k14_depth_to_weak(orc_state *s)
 
 static void k15_local_refine(orc_state *s)
 {
-    const int W = s->width, H = s->height;
 #pragma omp parallel for schedule(dynamic, 2) num_threads(orc_get_threads())
-    for (int y = 0; y < H; ++y) {
-        for (int x = 0; x < W; ++x) {
+    for (int y = s->ry0; y < s->ry1; ++y) {
+        for (int x = s->rx0; x < s->rx1; ++x) {
             local_refine_pixel(s, x, y);
         }
     }
@@ -1980,6 +1989,9 @@ orc_state *orc_create(int width, int height, const orc_params *params, const orc
     const size_t n = (size_t)width * height;
     s->width = width;
     s->height = height;
+    s->rx0 = s->ry0 = 0;
+    s->rx1 = width;
+    s->ry1 = height;
     s->num_images = params->num_images;
     s->params = *params;
     for (int i = 0; i < s->num_images; ++i) {
@@ -2044,6 +2056,14 @@ void orc_destroy(orc_state *s)
     free(s->neighbours_map);
     free(s->neighbours);
     free(s);
+}
+
+void orc_set_roi(orc_state *s, int x0, int y0, int x1, int y1)
+{
+    s->rx0 = x0 < 0 ? 0 : x0;
+    s->ry0 = y0 < 0 ? 0 : y0;
+    s->rx1 = x1 > s->width ? s->width : x1;
+    s->ry1 = y1 > s->height ? s->height : y1;
 }
 
 void orc_run_kernel(orc_state *s, int kernel_id, int iter)

@@ -110,6 +110,11 @@ void orc_destroy(orc_state *s);
 void orc_set_threads(int n);
 int orc_get_threads(void);
 
+/* Region of interest: the kernels only visit (and write) pixels of [x0, x1) x [y0, y1); arrays keep their full size.
+ * Used by the full-resolution parity tests: the HIP path runs the whole image, the oracle a few windows of it, from the
+ * same pre-kernel state.  Default: the whole image. */
+void orc_set_roi(orc_state *s, int x0, int y0, int x1, int y1);
+
 void orc_run_kernel(orc_state *s, int kernel_id, int iter);
 /* Whole schedule of APD.cu:2386-2495. */
 void orc_run(orc_state *s);

@@ -95,6 +95,7 @@ def lib():
     L.orc_destroy.argtypes = [C.c_void_p]
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_get_threads.restype = C.c_int
+    L.orc_set_roi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_run_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_run.argtypes = [C.c_void_p]
     L.orc_run_sweeps.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -195,6 +196,10 @@ class Oracle:
 
     def run_kernel(self, kid, it=0):
         lib().orc_run_kernel(self._h, kid, it)
+
+    def set_roi(self, x0=0, y0=0, x1=None, y1=None):
+        """Kernels visit only the pixels of [x0, x1) x [y0, y1) from now on (default: the whole image again)."""
+        lib().orc_set_roi(self._h, x0, y0, self.W if x1 is None else x1, self.H if y1 is None else y1)
 
     def run(self):
         lib().orc_run(self._h)

@@ -80,3 +80,72 @@ def fake_depth_maps(W, H, n):
         d[(xs % 17 == 0) & (ys % 13 == 0)] = 0.0
         out.append(d)
     return out
+
+
+# ---- full-resolution lock-step against the oracle's region-of-interest mode ----------------------------------------------
+
+def download_all(pkg, h):
+    """Every state array of the handle as numpy, keyed like ORACLE_STATES."""
+    out = {}
+    for name, hs, _ in ORACLE_STATES:
+        if name == "neighbours" and h.weak_count == 0:
+            continue
+        out[name] = h.state(getattr(pkg, hs))
+    return out
+
+
+def load_into_oracle(o, snap):
+    """Overwrites the oracle's state arrays with a snapshot of the HIP state (the pre-kernel state of the next step)."""
+    for name, _, oa in ORACLE_STATES:
+        if name in snap:
+            getattr(o, oa)[...] = snap[name]
+
+
+def assert_windows_equal(o, snap, windows, where, weak_before=None):
+    """HIP snapshot vs oracle, bit for bit, on every window (x0, y0, x1, y1).  The neighbour table is indexed by WEAK pixel:
+    its rows are compared for the pixels of the window that were WEAK when the table was allocated (`weak_before`)."""
+    nmap = o.neighbours_map
+    for (x0, y0, x1, y1) in windows:
+        for name, _, oa in ORACLE_STATES:
+            if name not in snap:
+                continue
+            a, b = snap[name], getattr(o, oa)
+            if name == "neighbours":
+                if weak_before is None:
+                    continue
+                rows = nmap[y0:y1, x0:x1][weak_before[y0:y1, x0:x1] == 0]
+                a, b = a[rows], b[rows]
+            else:
+                a, b = a[y0:y1, x0:x1], b[y0:y1, x0:x1]
+            if not np.array_equal(bits(a), bits(b)):
+                diff = (bits(a).reshape(a.shape[0], -1) != bits(b).reshape(a.shape[0], -1)).sum()
+                raise AssertionError("%s: HIP and oracle differ in `%s` on window %s (%d bytes)" % (where, name, (x0, y0, x1, y1), int(diff)))
+
+
+def fullsize_lockstep(pkg, h, o, schedule, windows, label, log=None):
+    """The HIP path runs every kernel of `schedule` over the whole image; the oracle runs the same kernel on the windows
+    only, from the HIP path's own pre-kernel state (copied in once per kernel), and the windows are compared bit for bit
+    after every kernel.  Launches never read what they write (red/black colouring), so a window's result does not depend on
+    what happens outside it in the same launch (tests/test_oracle_roi.py checks that property of the oracle)."""
+    import time
+    snap = download_all(pkg, h)
+    load_into_oracle(o, snap)
+    weak_alloc = snap["weak"].copy()  # the WEAK map the neighbour table was laid out for (before K4 demotes pixels)
+    compared = 0
+    for kid, it in schedule:
+        t0 = time.perf_counter()
+        h.run_kernel(kid, it)
+        t1 = time.perf_counter()
+        for (x0, y0, x1, y1) in windows:
+            o.set_roi(x0, y0, x1, y1)
+            o.run_kernel(kid, it)
+        o.set_roi()
+        t2 = time.perf_counter()
+        snap = download_all(pkg, h)
+        assert_windows_equal(o, snap, windows, "%s after K%d(iter %d)" % (label, kid, it), weak_alloc)
+        load_into_oracle(o, snap)
+        compared += 1
+        if log is not None:
+            log.append("K%d(iter %d): HIP %.0f ms, oracle windows %.1f s, download+compare+sync %.1f s"
+                       % (kid, it, (t1 - t0) * 1e3, t2 - t1, time.perf_counter() - t2))
+    return compared

@@ -1,0 +1,136 @@
+"""HIP path vs CPU oracle at the FULL sizes of BASELINE.json's configs, bit for bit, kernel by kernel.
+
+The oracle cannot sweep 25.6 Mpix in a test's time budget (0.3 Mpix*iter/s on 128 threads), so it runs in region-of-interest
+mode (orc_set_roi, oracle/apd_oracle.h): after every kernel of the HIP path -- launched over the whole image, with the
+XCD-banded grids, LDS windows and 16/32-bit index arithmetic of the real size -- the same kernel runs on the CPU on a few
+windows from the HIP path's own pre-kernel state, and every state array is compared inside the windows as raw bits.
+Windows: the image corner (clamped patches, the 6-pixel UNKNOWN border), the centre, a window across the seam between the
+tile bands of two XCDs, the bottom-right corner (last partial tile, HALF-launch rows), and for the APD configs windows
+inside and on the rim of a textureless region, where K3's neighbour search walks hundreds of pixels (APD.cu:1750-1969)."""
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _schedule(iters, weak, tail=True):
+    s = [(1, 0), (2, 0)] + ([(3, 0), (4, 0)] if weak else []) + [(5, 0)]
+    for i in range(iters):
+        s += [(6, i), (7, i), (8, i)] + ([(9, i), (10, i)] if weak else [])
+    return s + ([(11, 0), (12, 0), (13, 0), (14, 0), (15, 0)] if tail else [])
+
+
+def _fixed_windows(W, H, w=256, hh=160):
+    """corner, centre, XCD band seam (tile rows are split into 8 contiguous bands, apd_sweep.h), bottom-right corner, top-right
+    and bottom-left corners (narrower), and two windows at pseudo-random interior positions."""
+    tiles_y = (H + 15) // 16
+    seam_y = ((tiles_y + 7) // 8) * 16  # first tile row of the second band
+    rng = np.random.RandomState(W * 7 + H)
+    wins = [(0, 0, w, hh), (W // 2 - w // 2, H // 2 - hh // 2, W // 2 + w // 2, H // 2 + hh // 2),
+            (W // 3, max(seam_y - hh // 2, 0), W // 3 + w, seam_y + hh // 2), (W - w, H - hh, W, H),
+            (W - w // 2, 0, W, hh // 2), (0, H - hh // 2, w // 2, H)]
+    for _ in range(2):
+        x0, y0 = int(rng.randint(0, W - w)), int(rng.randint(0, H - hh))
+        wins.append((x0, y0, x0 + w, y0 + hh))
+    return [(max(x0, 0), max(y0, 0), min(x1, W), min(y1, H)) for (x0, y0, x1, y1) in wins]
+
+
+def _weak_windows(weak, w=128, hh=80):
+    """Two windows chosen from the WEAK map: around the WEAK pixel deepest inside a WEAK region (largest distance to a
+    non-WEAK pixel along its row) and around the first WEAK pixel in raster order (a rim, mixed STRONG / WEAK)."""
+    H, W = weak.shape
+    is_weak = weak == 0
+    ys, xs = np.nonzero(is_weak)
+    assert len(ys) > 1000, "the scene must have WEAK pixels"
+    # run length of WEAK pixels to the left, per row (vectorised), as a cheap "depth inside the region"
+    run = np.zeros((H, W), np.int32)
+    acc = np.zeros(H, np.int32)
+    for x in range(W):
+        acc = np.where(is_weak[:, x], acc + 1, 0)
+        run[:, x] = acc
+    cy, cx = np.unravel_index(int(np.argmax(run)), run.shape)
+    cx = max(cx - int(run[cy, cx]) // 2, 0)
+    wins = []
+    for (px, py) in ((cx, cy), (int(xs[0]), int(ys[0]))):
+        x0, y0 = min(max(px - w // 2, 0), W - w), min(max(py - hh // 2, 0), H - hh)
+        wins.append((x0, y0, x0 + w, y0 + hh))
+    return wins
+
+
+def _scene(synth, W, H, N, textureless=0.0):
+    import torch
+    sc = synth.make_scene(W, H, N, seed=0, device=torch.device("cuda", 0), textureless=textureless)
+    imgs = sc.images_numpy()
+    del sc.images[:]
+    torch.cuda.empty_cache()
+    return sc, imgs
+
+
+def test_configs1_office_fullres_8src_first_pass(gpu_pkg, ob, synth, record_property):
+    """configs[1]: 6200x4130, 8 source views, FIRST_INIT: the whole pass (K1, K2, K5, three iterations of K6, K7, K8,
+    K11..K15), i.e. the metric's sweep from random planes into the converged regime where the LDS windows serve most NCCs."""
+    W, H, N = 6200, 4130, 8
+    sc, imgs = _scene(synth, W, H, N)
+    p = common.base_params(sc, N, max_iterations=3, seed=12345, weak_peak_radius=6)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p)
+    o = common.make_oracle(ob, sc, imgs, N, p)
+    log = []
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(3, False), _fixed_windows(W, H), "configs[1]", log)
+    record_property("kernels_compared", n)
+    print("\n".join(log))
+    assert n == 17
+    h.close()
+    o.close()
+
+
+def test_configs2_pipes_fullres_10src_apd_pass(gpu_pkg, ob, synth, record_property):
+    """configs[2]: 6200x4130, 10 source views, adaptive patch deformation on: the REFINE_INIT + APD pass (K1..K5, two
+    iterations of K6..K10, K11..K15) on the WEAK map a complete FIRST_INIT pass leaves on a scene with 20 % textureless area."""
+    W, H, N = 6200, 4130, 10
+    sc, imgs = _scene(synth, W, H, N, textureless=0.2)
+    p0 = common.base_params(sc, N, max_iterations=3, seed=12345, weak_peak_radius=6)
+    h0 = common.make_handle(gpu_pkg, sc, imgs, N, p0)
+    h0.run()
+    planes, weak, views = h0.download()
+    h0.close()
+    prior = common.postprocess(planes, weak, views, p0["depth_min"], p0["depth_max"])
+    weak_fraction = float((prior[2] == 0).mean())
+    assert 0.05 < weak_fraction < 0.5, weak_fraction
+    p = common.base_params(sc, N, max_iterations=2, seed=12346, state=1, use_APD=1, weak_peak_radius=6, rotate_time=4,
+                           ransac_threshold=0.01 - 0.00125 * 3)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p, prior=prior)
+    o = common.make_oracle(ob, sc, imgs, N, p, prior=prior)
+    assert h.weak_count == o.weak_count > 0
+    assert np.array_equal(h.state(gpu_pkg.STATE_NEIGHBOURS_MAP), o.neighbours_map)
+    windows = _fixed_windows(W, H, 160, 96) + _weak_windows(prior[2], 192, 128)
+    log = []
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(2, True), windows, "configs[2]", log)
+    print("\n".join(log))
+    # the neighbour search must really have walked far: some accepted neighbour lies > 100 px from its pixel
+    nb = h.state(gpu_pkg.STATE_NEIGHBOURS).astype(np.int32)
+    valid = nb[:, 1:, 0] >= 0
+    far = np.abs(nb[:, 1:, :] - nb[:, :1, :]).max(-1)[valid]
+    record_property("weak_fraction", weak_fraction)
+    record_property("max_neighbour_distance_px", int(far.max()))
+    assert far.max() > 100
+    assert n == 20
+    h.close()
+    o.close()
+
+
+def test_configs4_synthetic_4096x3072_16src(gpu_pkg, ob, synth):
+    """configs[4]: 4096x3072, 16 source views (the NMAX = 16 kernels at full size), FIRST_INIT, two iterations + the
+    post-loop kernels."""
+    W, H, N = 4096, 3072, 16
+    sc, imgs = _scene(synth, W, H, N)
+    p = common.base_params(sc, N, max_iterations=2, seed=777, weak_peak_radius=6)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p)
+    o = common.make_oracle(ob, sc, imgs, N, p)
+    log = []
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(2, False), _fixed_windows(W, H, 192, 128), "configs[4]", log)
+    print("\n".join(log))
+    assert n == 14
+    h.close()
+    o.close()
