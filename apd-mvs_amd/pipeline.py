@@ -277,7 +277,7 @@ def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=
             depth_store[idx] = d.contiguous()
             if log:
                 log("pass %d (round %d, scale %d) view %d done on rank %d" % (spec.iteration_index, spec.round_index, spec.scale_size, idx, rank))
-        if world > 1:
+        if distributed:  # also with one rank under an initialised process group: the collective path is the only path then
             gathered = sharding.allgather_maps({v: depth_store[v][..., None] for v in mine}, V, group=group)
             for v in range(V):
                 if v not in state:
@@ -289,7 +289,7 @@ def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=
                          np.ascontiguousarray(views.cpu().numpy()).view(np.uint32))
 
     # before fusion: everybody gets every view's depth + normal + weak (+ selected views)
-    if world > 1:
+    if distributed:
         packed = {}
         for v in mine:
             planes, weak, views = state[v]

@@ -71,7 +71,6 @@ _FUSION_LIB_PATH = os.path.join(_HERE, "_build", "libapd_fusion_oracle.so")
 
 def build(force=False):
     src = [os.path.join(_HERE, f) for f in ("apd_oracle.c", "apd_oracle.h", "fusion_oracle.cpp", "Makefile")]
-    src.append(os.path.join(_HERE, "..", "apd-mvs_amd", "csrc", "apd_fusion_math.h"))
     if (not force and os.path.exists(_LIB_PATH) and os.path.exists(_FUSION_LIB_PATH)
             and all(min(os.path.getmtime(_LIB_PATH), os.path.getmtime(_FUSION_LIB_PATH)) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH

@@ -149,3 +149,27 @@ def fullsize_lockstep(pkg, h, o, schedule, windows, label, log=None):
             log.append("K%d(iter %d): HIP %.0f ms, oracle windows %.1f s, download+compare+sync %.1f s"
                        % (kid, it, (t1 - t0) * 1e3, t2 - t1, time.perf_counter() - t2))
     return compared
+
+
+class OracleBackend:
+    """The CPU oracle behind the pipeline's backend interface (tests only): one (view, pass) == orc_run."""
+    device = None
+
+    def __init__(self, threads=2):
+        from oracle import binding as ob
+        self.ob = ob
+        ob.lib().orc_set_threads(threads)
+
+    @property
+    def camera_type(self):
+        return self.ob.Camera
+
+    def run_pass(self, width, height, params, cameras, images, depths, prior):
+        ob = self.ob
+        pr = prior or (None, None, None)
+        o = ob.Oracle(width, height, ob.default_params(**params), cameras, images, depths=depths, prior_planes=pr[0],
+                      prior_views=pr[1], prior_weak=pr[2])
+        o.run()
+        out = o.planes.copy(), o.weak_info.copy(), o.selected_views.copy()
+        o.close()
+        return out

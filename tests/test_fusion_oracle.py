@@ -30,3 +30,36 @@ def test_sequential_fusion_on_exact_maps(pkg, ob, synth, tmp_path):
     n3 = ob.fuse(cams_r, [scene.images[v] for v in rev], [results[v].depth for v in rev], [results[v].normal for v in rev],
                  [results[v].weak for v in rev], pairs_r, tmp_path / "c.ply")
     assert (tmp_path / "c.ply").read_bytes() != (tmp_path / "a.ply").read_bytes() and abs(n3 - n) < 0.5 * n
+
+
+def test_oracle_kernels_against_libm_and_against_the_products_kernels(pkg, ob):
+    """The fusion oracle restates acosf (fdlibm) and exp (contract C5) on its own (oracle/fusion_oracle.cpp includes nothing
+    from the product).  Known answers: within a few ulp of libm; NaN outside [-1, 1].  Cross-check: the product's separately
+    written kernels (csrc/apd_fusion_math.h, reached through libapd_host.so) give the same bits on a dense sample -- the
+    byte-exact APD.ply comparison of the GPU tests rests on that agreement, and a slip in either copy shows up here."""
+    import ctypes as C
+    import os
+    ob.build()
+    L = C.CDLL(os.path.join(os.path.dirname(ob.__file__), "_build", "libapd_fusion_oracle.so"))
+    for f in (L.orc_fusion_acos, L.orc_fusion_exp):
+        f.restype = C.c_float
+        f.argtypes = [C.c_float]
+    pkg.lib()
+    host = C.CDLL(os.path.join(os.path.dirname(pkg.library_path()), "libapd_host.so"))
+    fp = C.POINTER(C.c_float)
+    host.apdhost_fusion_math.argtypes = [fp, C.c_int, C.c_int, fp]
+    rng = np.random.RandomState(11)
+    xs = np.concatenate([np.linspace(-1, 1, 40001), rng.uniform(-1, 1, 20000), 1 - np.logspace(-8, -1, 2000), np.logspace(-8, -1, 2000) - 1,
+                         [1.0, -1.0, 0.0, -0.0, 0.5, -0.5, 0.49999997, 0.50000006, 1e-9, -1e-9, 1.0000001, -1.0000001, 3.0, np.nan]]).astype(np.float32)
+    es = np.concatenate([np.linspace(-30, 0, 40001), -rng.uniform(0, 25, 20000), [-87.5, -100.0, 0.0, 1.0, 89.0, np.nan]]).astype(np.float32)
+    for which, fn, inp, ref_fn in ((0, L.orc_fusion_acos, xs, np.arccos), (1, L.orc_fusion_exp, es, np.exp)):
+        mine = np.array([fn(float(v)) for v in inp], np.float32)
+        theirs = np.zeros_like(inp)
+        host.apdhost_fusion_math(inp.ctypes.data_as(fp), len(inp), which, theirs.ctypes.data_as(fp))
+        assert np.array_equal(mine.view(np.uint32) | (np.isnan(mine) * 0x7fffffff).astype(np.uint32),
+                              theirs.view(np.uint32) | (np.isnan(theirs) * 0x7fffffff).astype(np.uint32)), which
+        with np.errstate(invalid="ignore", over="ignore"):
+            ref = ref_fn(inp.astype(np.float64))
+        ok = np.isfinite(ref) & (ref != 0) & (np.abs(ref) < 3e38) & (np.abs(ref) > 1e-37)
+        assert (np.abs(mine[ok] - ref[ok]) <= 3 * np.spacing(np.abs(ref[ok]).astype(np.float32))).all(), which
+        assert np.array_equal(np.isnan(mine), np.isnan(ref)), which

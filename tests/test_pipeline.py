@@ -10,6 +10,8 @@ import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from common import OracleBackend  # the CPU oracle behind the pipeline's backend interface
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST_LIB = os.path.join(ROOT, "apd-mvs_amd", "_build", "libapd_host.so")
 
@@ -50,30 +52,6 @@ def test_resampling_matches_cpp_host(pkg, rows, cols, nr, nc):
         L.apdhost_rescale_nearest_f32(src.ctypes.data_as(fp), rows, cols, want.ctypes.data_as(fp), tr, tc)
         got = pipeline.rescale_nearest(src, tc, tr)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tr, tc)
-
-
-class OracleBackend:
-    """The CPU oracle behind the pipeline's backend interface (tests only)."""
-    device = None
-
-    def __init__(self):
-        from oracle import binding as ob
-        self.ob = ob
-        ob.lib().orc_set_threads(2)
-
-    @property
-    def camera_type(self):
-        return self.ob.Camera
-
-    def run_pass(self, width, height, params, cameras, images, depths, prior):
-        ob = self.ob
-        pr = prior or (None, None, None)
-        o = ob.Oracle(width, height, ob.default_params(**params), cameras, images, depths=depths, prior_planes=pr[0],
-                      prior_views=pr[1], prior_weak=pr[2])
-        o.run()
-        out = o.planes.copy(), o.weak_info.copy(), o.selected_views.copy()
-        o.close()
-        return out
 
 
 def _free_port():

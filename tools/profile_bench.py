@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Counter profile of one bench.py command line, reduced to what bench.py's `roofline` object needs (runs on the GPU box).
+
+    python tools/profile_bench.py <out_dir> [bench.py flags, e.g. --steps 20 --warmup 5 --workload ...]
+
+Five rocprofv3 runs of the same command (bench.py <flags> --no-cpu-baseline), counters in their own passes as the guide
+prescribes (kernel trace only; never combined with other trace domains):
+    1. --kernel-trace --stats                                   launch durations, kernel_stats
+    2. --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VMEM_RD
+    3. --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum   (L1 tag look-ups, L1 -> L2 requests, L2 hits / misses)
+    4. --pmc FETCH_SIZE                                          (KiB; x2 on gfx950, MI355X_MICROARCH.md "HBM")
+    5. --pmc WRITE_SIZE                                          (KiB)
+For the sweep kernels (k67*, k910*) only the launches of the TIMED region are reduced: bench.py launches each of them twice
+per iteration (black, red), warm-up first, so the timed launches are the last 2 x steps dispatches of the kernel.
+
+Writes into <out_dir>:
+    pmc_bench_<workload>_s<steps>_w<warmup>.json     what bench.py reads (per-launch means + the per-dispatch values)
+    pmc_bench_<workload>_s<steps>_w<warmup>.csv      per-dispatch rows of every pass for the sweep kernels (committed evidence)
+    kernel_stats_<workload>_s<steps>_w<warmup>.csv   rocprofv3 --stats table of pass 1
+    bench_<workload>_s<steps>_w<warmup>_pass<k>.json the bench line of every pass
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PASSES = [
+    ("trace", ["--kernel-trace", "--stats"]),
+    ("sq", ["--kernel-trace", "--pmc", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+            "SQ_WAIT_ANY", "SQ_WAVES", "SQ_INSTS_VMEM_RD"]),
+    ("tcp", ["--kernel-trace", "--pmc", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"]),
+    ("fetch", ["--kernel-trace", "--pmc", "FETCH_SIZE"]),
+    ("write", ["--kernel-trace", "--pmc", "WRITE_SIZE"]),
+]
+SWEEP_KERNELS = {"k67": "k67", "k910": "k910_update_weak"}
+
+
+def flag(flags, name, default):
+    return type(default)(flags[flags.index(name) + 1]) if name in flags else default
+
+
+def main():
+    out_dir, flags = sys.argv[1], sys.argv[2:]
+    steps, warmup = flag(flags, "--steps", 6), flag(flags, "--warmup", 1)
+    workload = flag(flags, "--workload", "eth3d_office_fullres_8src")
+    tag = "%s_s%d_w%d" % (workload, steps, warmup)
+    os.makedirs(out_dir, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    per_dispatch = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel key -> counter -> [values in launch order]
+    meta = {}
+    rows_csv = []
+    for name, prof_flags in PASSES:
+        raw = os.path.join("/tmp", "apd_prof_%s_%s" % (tag, name))
+        subprocess.call(["rm", "-rf", raw])
+        cmd = ["rocprofv3"] + prof_flags + ["--output-format", "csv", "-d", raw, "-o", name, "--", sys.executable,
+                                           os.path.join(ROOT, "bench.py")] + flags + ["--no-cpu-baseline"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, timeout=1500)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            sys.stderr.write("pass %s failed (rc %d):\n%s\n" % (name, r.returncode, r.stderr[-2000:]))
+            return 1
+        with open(os.path.join(out_dir, "bench_%s_pass_%s.json" % (tag, name)), "w") as f:
+            f.write(line[-1] + "\n")
+        # launch durations of this pass (every pass has the kernel trace)
+        for path in glob.glob(os.path.join(raw, "**", "*kernel_trace.csv"), recursive=True):
+            rows = sorted(csv.DictReader(open(path)), key=lambda r_: int(r_["Start_Timestamp"]))
+            for r_ in rows:
+                for key, sub in SWEEP_KERNELS.items():
+                    if sub in r_["Kernel_Name"]:
+                        per_dispatch[key]["duration_ns@" + name].append(float(r_["End_Timestamp"]) - float(r_["Start_Timestamp"]))
+        for path in glob.glob(os.path.join(raw, "**", "*counter_collection.csv"), recursive=True):
+            rows = list(csv.DictReader(open(path)))
+            rows.sort(key=lambda r_: int(r_.get("Dispatch_Id", 0)))
+            for r_ in rows:
+                for key, sub in SWEEP_KERNELS.items():
+                    if sub in r_["Kernel_Name"]:
+                        per_dispatch[key][r_["Counter_Name"]].append(float(r_["Counter_Value"]))
+                        meta[key] = {"kernel_name": r_["Kernel_Name"], "grid": r_["Grid_Size"], "workgroup": r_["Workgroup_Size"],
+                                     "lds_bytes": r_["LDS_Block_Size"], "scratch_bytes_per_lane": r_["Scratch_Size"],
+                                     "vgpr": r_["VGPR_Count"], "sgpr": r_["SGPR_Count"]}
+        if name == "trace":
+            for path in glob.glob(os.path.join(raw, "**", "*kernel_stats.csv"), recursive=True):
+                with open(path) as f, open(os.path.join(out_dir, "kernel_stats_%s.csv" % tag), "w") as g:
+                    g.write(f.read())
+        subprocess.call(["rm", "-rf", raw])
+
+    out = {"config": {"workload": workload, "steps": steps, "warmup": warmup, "flags": flags},
+           "method": "rocprofv3 --kernel-trace + one --pmc pass per counter group; timed launches = last 2*steps dispatches of the kernel; "
+                     "FETCH_SIZE in KiB doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE in KiB as reported",
+           "kernels": {}}
+    for key, counters in per_dispatch.items():
+        n_timed = 2 * steps
+        k = dict(meta.get(key, {}))
+        k["launches_timed"] = n_timed
+        k["per_dispatch_timed"] = {}
+        for cname, vals in sorted(counters.items()):
+            timed = vals[-n_timed:]
+            k["per_dispatch_timed"][cname] = timed
+            for i, v in enumerate(timed):
+                rows_csv.append([key, cname, i, v])
+
+        def mean(cname):
+            v = k["per_dispatch_timed"].get(cname)
+            return sum(v) / len(v) if v else None
+        k["launch_ms"] = None if mean("duration_ns@trace") is None else mean("duration_ns@trace") / 1e6
+        k["launch_ms_sq_pass"] = None if mean("duration_ns@sq") is None else mean("duration_ns@sq") / 1e6
+        k["valu_insts_per_launch"] = mean("SQ_INSTS_VALU")
+        k["active_inst_valu_per_launch"] = mean("SQ_ACTIVE_INST_VALU")
+        k["wave_cycles_per_launch"] = mean("SQ_WAVE_CYCLES")
+        k["wait_inst_any_per_launch"] = mean("SQ_WAIT_INST_ANY")
+        k["wait_any_per_launch"] = mean("SQ_WAIT_ANY")
+        k["vmem_rd_insts_per_launch"] = mean("SQ_INSTS_VMEM_RD")
+        k["tcp_tag_accesses_per_launch"] = mean("TCP_TOTAL_CACHE_ACCESSES_sum")
+        k["tcp_to_l2_read_requests_per_launch"] = mean("TCP_TCC_READ_REQ_sum")
+        k["l2_hits_per_launch"], k["l2_misses_per_launch"] = mean("TCC_HIT_sum"), mean("TCC_MISS_sum")
+        fe, wr = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+        k["fetch_bytes_per_launch"] = None if fe is None else fe * 1024 * 2
+        k["write_bytes_per_launch"] = None if wr is None else wr * 1024
+        k["hbm_bytes_per_launch"] = None if fe is None or wr is None else fe * 1024 * 2 + wr * 1024
+        out["kernels"][key] = k
+    with open(os.path.join(out_dir, "pmc_bench_%s.json" % tag), "w") as f:
+        json.dump(out, f, indent=1)
+    with open(os.path.join(out_dir, "pmc_bench_%s.csv" % tag), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "timed_launch_index", "value"])
+        w.writerows(rows_csv)
+    for key, k in out["kernels"].items():
+        print("%s: %s launches, %.3f ms/launch, VALU %.4g/launch, fetch %.4g B, write %.4g B, scratch %s B/lane, vgpr %s" % (
+            key, k["launches_timed"], k["launch_ms"] or 0, k["valu_insts_per_launch"] or 0, k["fetch_bytes_per_launch"] or 0,
+            k["write_bytes_per_launch"] or 0, k.get("scratch_bytes_per_lane"), k.get("vgpr")))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
