@@ -20,6 +20,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+# Per-file flags.  K6/K7: let LLVM keep the kernel's small per-lane arrays (arm positions, refinement hypotheses, view
+# priors / probabilities -- indexed by wave-uniform loop counters) in registers instead of scratch memory; measured on
+# configs[1]: 303.5 -> 311.4 Mpix*iter/s (profiles/r02/tune_scratch.txt).  The 9 x N cost table stays in scratch: 72
+# registers more do not fit four waves per SIMD, and three waves per SIMD are 8 % slower (same file).
+FILE_FLAGS = {"apd_kernels_k67w.hip": ["-mllvm", "-amdgpu-promote-alloca-to-vector-limit=2048"]}
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -37,7 +44,7 @@ def build_library(force=False, verbose=False, extra_flags=()):
         o = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + list(extra_flags) + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + list(extra_flags) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -21,6 +21,7 @@ hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s);
 hipError_t launch_weak_index_map(const uint8_t *weak, size_t n, int *map, int *scratch, hipStream_t s);
 hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipStream_t s);
+hipError_t launch_pack_quads_tiled(const float *img, int W, int H, quad_t *quad, hipStream_t s);
 hipError_t launch_pack_fquads(const float *img, int W, int H, fquad_t *fq, hipStream_t s);
 }  // namespace apd
 
@@ -62,9 +63,11 @@ struct apd_context {
     std::vector<float *> images;
     std::vector<float *> depths;
     std::vector<apd::quad_t *> quads;
+    std::vector<apd::quad_t *> quads_tiled;  // second copy in 8 x 4 tiles (FIRST_INIT passes: random first iteration)
     std::vector<apd::fquad_t *> fquads;
     int *flag_dev = nullptr;
     bool use_quads = false;
+    bool have_tiled = false;
     ViewConst *views_dev = nullptr;
     float4 *planes = nullptr, *fit_planes = nullptr;
     float *costs = nullptr;
@@ -128,6 +131,7 @@ static void refresh_frame_args(apd_context *c)
     fa.num_src = c->num_images > 0 ? c->num_images - 1 : 0;
     fa.half_rows = 2 * (((c->H / 2) + 15) / 16) * 16;
     fa.use_quads = c->use_quads ? 1 : 0;
+    fa.have_tiled = c->have_tiled ? 1 : 0;
     fa.top_k = p.top_k;
     fa.depth_min = p.depth_min;
     fa.depth_max = p.depth_max;
@@ -323,6 +327,9 @@ int apd_destroy(apd_handle c)
     for (apd::quad_t *p : c->quads) {
         hipFree(p);
     }
+    for (apd::quad_t *p : c->quads_tiled) {
+        hipFree(p);
+    }
     for (apd::fquad_t *p : c->fquads) {
         hipFree(p);
     }
@@ -393,10 +400,12 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     release(c->images, std::min(c->images.size(), (size_t)num_images));
     release(c->depths, depths ? std::min(c->depths.size(), (size_t)num_images) : 0);
     release(c->quads, 0);
+    release(c->quads_tiled, 0);
     release(c->fquads, 0);
     c->images.resize(num_images, nullptr);
     c->depths.resize(num_images, nullptr);
     c->quads.assign(num_images, nullptr);
+    c->quads_tiled.assign(num_images, nullptr);
     c->fquads.assign(num_images, nullptr);
     for (int i = 0; i < num_images; ++i) {
         if (cameras[i].width != c->W || cameras[i].height != c->H) {
@@ -449,6 +458,23 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
                 return fail(APD_ERR_HIP, "k_pack_quads failed: %s", hipGetErrorString(e));
             }
         }
+        // the tiled copy serves the gathers of planes that are still random: the first iteration of a FIRST_INIT pass
+        // (APD_K67_TILED=2 uses it in every pass; =0 never builds it)
+        const char *tm = getenv("APD_K67_TILED");
+        const int tiled_mode = tm ? atoi(tm) : 1;
+        c->have_tiled = tiled_mode == 2 || (tiled_mode == 1 && c->params.state == APD_FIRST_INIT);
+        if (c->have_tiled) {
+            const size_t tn = apd::quad_tiled_entries(c->W, c->H);
+            for (int i = 1; i < num_images; ++i) {
+                HIP_TRY(hipMalloc(&c->quads_tiled[i], tn * sizeof(apd::quad_t)));
+                hipError_t e = apd::launch_pack_quads_tiled(c->images[i], c->W, c->H, c->quads_tiled[i], c->stream);
+                if (e != hipSuccess) {
+                    return fail(APD_ERR_HIP, "k_pack_quads_tiled failed: %s", hipGetErrorString(e));
+                }
+            }
+        }
+    } else {
+        c->have_tiled = false;
     }
     c->num_images = num_images;
     c->params.num_images = num_images;
@@ -480,6 +506,7 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         vc.img = c->images[v + 1];
         vc.depth = c->depths[v + 1];
         vc.quad = c->quads[v + 1];
+        vc.quad_tiled = c->quads_tiled[v + 1];
         vc.fquad = c->fquads[v + 1];
 #ifdef APD_EXPERIMENT_ALIAS_VIEWS  // timing experiment only (wrong results): every source view reads the first one's image
         vc.quad = c->quads[1];

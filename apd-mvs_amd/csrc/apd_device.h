@@ -57,6 +57,7 @@ struct ViewConst {
     // scale 1): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], holds the four clamped taps
     // {I(qx,qy), I(qx+1,qy), I(qx,qy+1), I(qx+1,qy+1)} of one bilinear fetch (quad_t below).
     const quad_t *quad;  // (H+1)*(W+1) entries or nullptr
+    const quad_t *quad_tiled;  // the same entries in 8 x 4 tiles (quad_tiled_index) or nullptr
     // Float texel-quad image (every other input: float grey values, e.g. the resampled images of the coarse pyramid
     // levels, APD.cpp:474): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], holds the two texel pairs
     // {I(qx,qy), I(qx+1,qy) - I(qx,qy), I(qx,qy+1), I(qx+1,qy+1) - I(qx,qy+1)} with clamped coordinates (fquad_t below):
@@ -69,6 +70,7 @@ struct FrameArgs {
     int num_src;       // num_images - 1
     int half_rows;     // rows reachable by the reference HALF launch: 2*ceil((H/2)/16)*16 (APD.cu:2402)
     int use_quads;     // 1: source images are also available as texel quads (ViewConst::quad)
+    int have_tiled;    // 1: ... and as the tiled copy (ViewConst::quad_tiled)
     // params (main.h:75-94)
     int top_k;
     float depth_min, depth_max;
@@ -504,6 +506,26 @@ __device__ __forceinline__ int med3_i32(int x, int lo, int hi)
     return r;
 }
 
+// Second copy of the byte-quad image in tiles of 8 x 4 entries = one 128-byte line, for gathers that land anywhere in the
+// source image (first iteration of a FIRST_INIT pass: every lane warps its patch with another random plane).  An 11 x 11 px
+// warped patch touches ~8 tiles against ~14 lines of the row-major image (32 x 1 entries per line): L1 -> L2 requests per
+// gather 16.5 -> 9.7, first black launch of configs[1] 129 -> 94 ms (profiles/r02/tiled_vs_rowmajor.txt).  Rows are read
+// better from the row-major copy (window staging, the 3 x 3 stride-5 sub-patches of the weak sweep), which stays.
+// Entry (t, u) = (qx + 1, qy + 1) lives at ((u / 4) * tiles_x + t / 8) * 32 + (u % 4) * 8 + t % 8.  Same entries: same bits.
+__host__ __device__ __forceinline__ unsigned quad_tiles_x(int W) { return ((unsigned)(W + 1) + 7u) >> 3; }
+__host__ __device__ __forceinline__ size_t quad_tiled_entries(int W, int H)
+{
+    return (size_t)quad_tiles_x(W) * 8u * ((((size_t)H + 1u) + 3u) & ~(size_t)3u);
+}
+__host__ __device__ __forceinline__ unsigned quad_tiled_index(unsigned t, unsigned u, unsigned tiles_x)
+{
+    return (((u >> 2) * tiles_x + (t >> 3)) << 5) | ((u & 3u) << 3) | (t & 7u);
+}
+__device__ __forceinline__ unsigned quad_tiled_byte_offset(int qx, int qy, unsigned tiles_x)
+{
+    return quad_tiled_index((unsigned)(qx + 1), (unsigned)(qy + 1), tiles_x) << kQuadShift;
+}
+
 // byte offset of quad entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1]: qy*pitch + (pitch + entry) + entry*qx with
 // pitch = (W+1)*entry bytes, two instructions
 __device__ __forceinline__ unsigned quad_byte_offset(int qx, int qy, int pitch, int origin)
@@ -589,7 +611,7 @@ __device__ __forceinline__ unsigned fquad_byte_offset(int qx, int qy, int pitch,
 }
 
 // Sample positions of one patch row (fixed x, six y) -> bilinear weights + texel-quad gathers in flight.
-template <bool kFastRecip>
+template <bool kFastRecip, bool kTiled = false>
 __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN],
                                                global_quad_ptr srcq, unsigned pitch, int wm1, int hm1,
                                                float (&a)[kPatchN], float (&b)[kPatchN], quad_t (&t)[kPatchN])
@@ -647,7 +669,11 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = (int)quad_byte_offset(qx[j], qy[j], (int)pitch, (int)(pitch + kQuadBytes));
+        if constexpr (kTiled) {
+            qx[j] = (int)quad_tiled_byte_offset(qx[j], qy[j], pitch);  // `pitch` = tiles per tile row here
+        } else {
+            qx[j] = (int)quad_byte_offset(qx[j], qy[j], (int)pitch, (int)(pitch + kQuadBytes));
+        }
     }
     APD_STAGE();
 #ifdef APD_EXPERIMENT_QUAD_SAME_ADDR  // timing experiment only (wrong results): the 4 lanes of a quad gather one address
@@ -813,7 +839,7 @@ __device__ __forceinline__ void fquad_row_lerp(const fquad_t (&t)[kPatchN], cons
 // The 36 warped source samples of one fixed patch and their three moments (APD.cu:561-583), summed in the
 // reference's order (row partial sums, then total).  kFastRecip: every denominator is known to be in the
 // range where recip_fast is the correctly rounded reciprocal.
-template <bool kQuad, bool kFastRecip, typename Ref>
+template <bool kQuad, bool kFastRecip, bool kTiled, typename Ref>
 __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H_in,
                                                   int px_in, int py_in, float &sum_s, float &sum_ss, float &sum_rs)
 {
@@ -827,9 +853,9 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     const Homography &H = H_in;
     const int px = px_in, py = py_in;
 #endif
-    const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
+    const global_quad_ptr srcq = (global_quad_ptr)(kTiled ? vc.quad_tiled : vc.quad);
     const int W = fa.W, Hh = fa.H;
-    const unsigned qpitch = kQuadBytes * (unsigned)(W + 1);
+    const unsigned qpitch = kTiled ? quad_tiles_x(W) : kQuadBytes * (unsigned)(W + 1);
     const unsigned fpitch = 16u * (unsigned)(W + 1);
     const global_fquad_ptr srcf = (global_fquad_ptr)vc.fquad;
     const int wm1 = W - 1, hm1 = Hh - 1;
@@ -855,7 +881,7 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
         const float xf = (float)(px + kPatchStep * r - kPatchRadius);
         const float bx = fmaf(H.h[0], xf, H.h[2]), by = fmaf(H.h[3], xf, H.h[5]), bz = fmaf(H.h[6], xf, H.h[8]);
         if constexpr (kQuad) {
-            quad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[r], b[r], t[r]);
+            quad_row_issue<kFastRecip, kTiled>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[r], b[r], t[r]);
         } else {
             fquad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcf, fpitch, wm1, hm1, a[r], b[r], tf[r]);
         }
@@ -868,7 +894,7 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
             const float xf = (float)(px + kPatchStep * (i + kDepth) - kPatchRadius);
             const float bx = fmaf(H.h[0], xf, H.h[2]), by = fmaf(H.h[3], xf, H.h[5]), bz = fmaf(H.h[6], xf, H.h[8]);
             if constexpr (kQuad) {
-                quad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[n], b[n], t[n]);
+                quad_row_issue<kFastRecip, kTiled>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[n], b[n], t[n]);
             } else {
                 fquad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcf, fpitch, wm1, hm1, a[n], b[n], tf[n]);
             }
@@ -911,7 +937,7 @@ __device__ __forceinline__ bool denominators_fast(const Homography &H, float x0,
 }
 
 // The fixed-patch cost for an already projected centre (the caller has done the bounds test of APD.cu:546).
-template <bool kQuad, typename Ref>
+template <bool kQuad, typename Ref, bool kTiled = false>
 __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H,
                                                   int px, int py)
 {
@@ -919,13 +945,19 @@ __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const Vie
     if (rp.var < kMinVar) {
         return 2.0f;  // the reference tests this after sampling; the result is the same
     }
-    const bool fast_recip = denominators_fast(H, (float)(px - kPatchRadius), (float)(px + kPatchRadius), (float)(py - kPatchRadius),
-                                              (float)(py + kPatchRadius));
+    bool fast_recip = denominators_fast(H, (float)(px - kPatchRadius), (float)(px + kPatchRadius), (float)(py - kPatchRadius),
+                                        (float)(py + kPatchRadius));
+#ifndef APD_RECIP_DIVERGENT
+    // One 36-sample body per wave and NCC.  The IEEE division gives the bits of the fast reciprocal wherever that one is
+    // valid, so when a single lane of the wave needs it, every lane takes it (random normals produce such lanes: a wave
+    // with one of them used to run both bodies in turn).
+    fast_recip = __builtin_amdgcn_ballot_w64(!fast_recip) == 0;
+#endif
     float sum_s, sum_ss, sum_rs;
     if (__builtin_expect(fast_recip, 1)) {
-        ncc_fixed_moments<kQuad, true, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, true, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else {
-        ncc_fixed_moments<kQuad, false, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, false, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     }
     const float inv_w = 1.0f / 36.0f;
     sum_s *= inv_w;
@@ -941,7 +973,7 @@ __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const Vie
 }
 
 // ComputeBilateralNCCOld for plane q = n/d against source view vc.  kQuad selects the texel-quad image.
-template <bool kQuad, typename Ref>
+template <bool kQuad, typename Ref, bool kTiled = false>
 __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, int px, int py,
                                            float qx, float qy, float qz)
 {
@@ -951,7 +983,7 @@ __device__ __forceinline__ float ncc_fixed(const FrameArgs &fa, const ViewConst 
     if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
         return 2.0f;
     }
-    return ncc_fixed_from_h<kQuad, Ref>(fa, vc, rp, H, px, py);
+    return ncc_fixed_from_h<kQuad, Ref, kTiled>(fa, vc, rp, H, px, py);
 }
 
 // ------------------------------------------------------------------------------------------------

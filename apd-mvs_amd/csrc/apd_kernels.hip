@@ -96,7 +96,8 @@ __device__ __forceinline__ RefPatchLds<kFullPitch> stage_full_frame_ref(const Fr
     return rp;
 }
 
-template <bool kQuad>
+// kTiled: the NCCs of the random planes (FIRST_INIT) gather from the tiled copy of the quad image
+template <bool kQuad, bool kTiled>
 __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
 {
     __shared__ float tile[kFullLdsH * kFullPitch];
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
         int valid = 0;
 #pragma unroll 1
         for (int v = 0; v < fa.num_src; ++v) {
-            const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
+            const float c = ncc_fixed<kQuad, RefPatchLds<kFullPitch>, kTiled>(fa, fa.views[v], rp, px, py, qx, qy, qz);
             sorted[v] = c;
             orig[v] = c;
             if (c < 2.0f) {
@@ -707,6 +708,19 @@ __global__ __launch_bounds__(256) void k_pack_quads(const float *__restrict__ im
 #endif
 }
 
+// the byte quads again, in 8 x 4 tiles (quad_tiled_index); same entries as k_pack_quads writes
+__global__ __launch_bounds__(256) void k_pack_quads_tiled(const float *__restrict__ img, int W, int H, quad_t *__restrict__ quad)
+{
+    const int qx = blockIdx.x * 32 + (threadIdx.x & 31);  // 0..W  <-> image x = qx - 1
+    const int qy = blockIdx.y * 8 + (threadIdx.x >> 5);   // 0..H
+    if (qx > W || qy > H) {
+        return;
+    }
+    const uint32_t t00 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy - 1), t10 = (uint32_t)fetch_texel(img, W, H, qx, qy - 1);
+    const uint32_t t01 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy), t11 = (uint32_t)fetch_texel(img, W, H, qx, qy);
+    quad[quad_tiled_index((unsigned)qx, (unsigned)qy, quad_tiles_x(W))] = t00 | (t10 << 8) | (t01 << 16) | (t11 << 24);
+}
+
 // float texel quads of a float image: entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1] (clamped coordinates)
 __global__ __launch_bounds__(256) void k_pack_fquads(const float *__restrict__ img, int W, int H, fquad_t *__restrict__ fq)
 {
@@ -736,6 +750,16 @@ hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipSt
 {
     hipLaunchKernelGGL(k_pack_quads, dim3((W + 1 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, quad);
     return hipGetLastError();
+}
+
+hipError_t launch_pack_quads_tiled(const float *img, int W, int H, quad_t *quad, hipStream_t s)
+{
+#ifdef APD_QUAD_F16
+    return hipErrorNotSupported;
+#else
+    hipLaunchKernelGGL(k_pack_quads_tiled, dim3((W + 1 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, quad);
+    return hipGetLastError();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -793,9 +817,13 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
     }
     case APD_K5_RANDOM_INITIALIZATION:
         if (fa.use_quads) {
-            hipLaunchKernelGGL(k5_random_initialization<true>, grid_full_frame(fa), dim3(256), 0, s, fa);
+            if (fa.have_tiled && fa.state == APD_FIRST_INIT) {
+                hipLaunchKernelGGL((k5_random_initialization<true, true>), grid_full_frame(fa), dim3(256), 0, s, fa);
+            } else {
+                hipLaunchKernelGGL((k5_random_initialization<true, false>), grid_full_frame(fa), dim3(256), 0, s, fa);
+            }
         } else {
-            hipLaunchKernelGGL(k5_random_initialization<false>, grid_full_frame(fa), dim3(256), 0, s, fa);
+            hipLaunchKernelGGL((k5_random_initialization<false, false>), grid_full_frame(fa), dim3(256), 0, s, fa);
         }
         break;
     case APD_K6_BLACK_UPDATE_STRONG:

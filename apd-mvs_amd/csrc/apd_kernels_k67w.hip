@@ -118,6 +118,9 @@ __device__ __forceinline__ bool arm_pos(const FrameArgs &fa, int px, int py, int
 #ifndef APD_WIN_TRUST
 #define APD_WIN_TRUST 0.5f
 #endif
+#ifndef APD_WIN_FROM_ITER
+#define APD_WIN_FROM_ITER 1  // first iteration of a FIRST_INIT pass that stages windows; configs[1] Mpix*iter/s: 0: 207, 1: 216
+#endif
 constexpr float kTrustedCost = APD_WIN_TRUST;
 
 #ifndef APD_K67W_WAVES
@@ -126,7 +129,8 @@ constexpr float kTrustedCost = APD_WIN_TRUST;
 #ifndef APD_K67W_WAVES_F32
 #define APD_K67W_WAVES_F32 3  // float windows are twice the size: three workgroups per CU
 #endif
-template <int NMAX, bool kQuad>
+// kTiled: NCCs that miss the window (all of them while the windows are off) gather from the tiled copy of the quad image
+template <int NMAX, bool kQuad, bool kTiled>
 __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) void k67w_update_strong(FrameArgs fa, int colour, int iter)
 {
     __shared__ float tile[kLdsH * kLdsPitch];
@@ -186,13 +190,9 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 
     // After K5's random initialisation nearly every hypothesis of the first iteration lands somewhere else in the
     // source image (10 % of the NCCs could read a window, 60 % of the waves are mixed): no windows in that iteration.
-#ifndef APD_WIN_FROM_ITER
-#define APD_WIN_FROM_ITER 1  // configs[1] Mpix*iter/s: 0: 207, 1: 216
-#endif
     const bool use_windows = !(fa.state == APD_FIRST_INIT && iter < APD_WIN_FROM_ITER);
     bool trusted = false;  // window placement only: the plane from the previous update has a low cost
     if (alive) {
-        rng = rng_load(fa.rng, center);
         plane_now = fa.planes[center];
         trusted = fa.costs[center] < kTrustedCost;
 #pragma unroll 1
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
                 const float4 pl = (h < 8) ? fa.planes[positions[h]] : plane_now;
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                cost_array[h][v] = ncc_fixed_windowed<kQuad>(fa, vc, w, rp, px, py, qx, qy, qz);
+                cost_array[h][v] = ncc_fixed_windowed<kQuad, kWinW, kTiled>(fa, vc, w, rp, px, py, qx, qy, qz);
             }
         }
     }
@@ -239,6 +239,8 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
                 }
             }
         }
+        // the random stream is only drawn from between here and make_refinement_set: six registers less through both NCC phases
+        rng = rng_load(fa.rng, center);
         select_views<NMAX>(fa, iter, cost_array, priors, rng, vw, sel, weight_norm);
         vw.store(fa, center);
         float final_costs[8];
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
         float ref_depths[5];
         trusted = cost_now < kTrustedCost;
         make_refinement_set(fa, px, py, rng, plane_now, depth_now, ref_depths, ref_normals);
+        rng_store(fa.rng, center, rng);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             ref_w[k] = distance_to_origin(fa, px, py, ref_depths[k], ref_normals[k].x, ref_normals[k].y, ref_normals[k].z);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
                 pl.w = ref_w[k];
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                tc[k] += (float)wv * ncc_fixed_windowed<kQuad>(fa, vc, w, rp, px, py, qx, qy, qz);
+                tc[k] += (float)wv * ncc_fixed_windowed<kQuad, kWinW, kTiled>(fa, vc, w, rp, px, py, qx, qy, qz);
             }
         }
     }
@@ -339,7 +342,6 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
             cost_now = c;
         }
     }
-    rng_store(fa.rng, center, rng);
     if (fa.state == APD_REFINE_INIT) {  // :1311-1316, double comparison
         if ((double)cost_now < (double)cost_committed - 0.1) {
             fa.costs[center] = cost_now;
@@ -354,25 +356,41 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 }
 
 
-template <bool kQuad>
+template <bool kQuad, bool kTiled>
 static void launch_k67w(const FrameArgs &fa, int tiles, int colour, int iter, hipStream_t s)
 {
     if (fa.num_src <= 8) {
-        hipLaunchKernelGGL((k67w_update_strong<8, kQuad>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+        hipLaunchKernelGGL((k67w_update_strong<8, kQuad, kTiled>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
     } else if (fa.num_src <= 16) {
-        hipLaunchKernelGGL((k67w_update_strong<16, kQuad>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+        hipLaunchKernelGGL((k67w_update_strong<16, kQuad, kTiled>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
     } else {
-        hipLaunchKernelGGL((k67w_update_strong<32, kQuad>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+        hipLaunchKernelGGL((k67w_update_strong<32, kQuad, kTiled>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
     }
+}
+
+// Which launches gather from the tiled copy (APD_K67_TILED in the environment; same results either way):
+//   0 never, 1 (default) while the windows are off, i.e. the random first iteration of a FIRST_INIT pass, 2 always.
+// Measured on configs[1] (profiles/r02/tiled_vs_rowmajor.txt): the first black launch 129 -> 94 ms; from the second
+// iteration on the row-major copy is faster (three extra address instructions per sample on a VALU-bound kernel).
+static int k67_tiled_mode()
+{
+    const char *e = getenv("APD_K67_TILED");
+    return e ? atoi(e) : 1;
 }
 
 hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
     const int tiles = ((fa.W + kTileW - 1) / kTileW) * ((fa.H + kTileH - 1) / kTileH);
     if (fa.use_quads) {
-        launch_k67w<true>(fa, tiles, colour, iter, s);
+        const int mode = k67_tiled_mode();
+        const bool windows_off = fa.state == APD_FIRST_INIT && iter < APD_WIN_FROM_ITER;
+        if (fa.have_tiled && (mode == 2 || (mode == 1 && windows_off))) {
+            launch_k67w<true, true>(fa, tiles, colour, iter, s);
+        } else {
+            launch_k67w<true, false>(fa, tiles, colour, iter, s);
+        }
     } else {
-        launch_k67w<false>(fa, tiles, colour, iter, s);
+        launch_k67w<false, false>(fa, tiles, colour, iter, s);
     }
     return hipGetLastError();
 }

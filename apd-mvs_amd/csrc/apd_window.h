@@ -340,7 +340,7 @@ __device__ __forceinline__ void corner_position(const Homography &H, float xf, f
 }
 
 // ComputeBilateralNCCOld (APD.cu:530-614) for plane q = n/d against source view vc, window first.
-template <bool kQuad, int kPitch = kWinW, typename Ref>
+template <bool kQuad, int kPitch = kWinW, bool kTiled = false, typename Ref>
 __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const ViewConst &vc, const SrcWindow &w, const Ref &rp, int px,
                                                     int py, float qx, float qy, float qz)
 {
@@ -384,13 +384,19 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
     // one path per wave and NCC: lanes inside and outside the window would otherwise run both 36-sample bodies in turn
     in_window = in_window && __builtin_amdgcn_ballot_w64(!in_window) == 0;
 #endif
+#ifndef APD_RECIP_DIVERGENT
+    // the same for the two global bodies: if one lane needs the IEEE division, every lane of the wave takes it (same bits)
+    const bool fast_body = __builtin_amdgcn_ballot_w64(!fast_recip) == 0;
+#else
+    const bool fast_body = fast_recip;
+#endif
     float sum_s, sum_ss, sum_rs;
     if (in_window) {
         ncc_window_moments<kQuad, kPitch>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
-    } else if (__builtin_expect(fast_recip, 1)) {
-        ncc_fixed_moments<kQuad, true, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+    } else if (__builtin_expect(fast_body, 1)) {
+        ncc_fixed_moments<kQuad, true, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else {
-        ncc_fixed_moments<kQuad, false, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, false, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     }
     const float inv_w = 1.0f / 36.0f;
     sum_s *= inv_w;
