@@ -178,9 +178,11 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
     w.wx0 = wx0;
     w.wy0 = wy0;
     // one entry of margin on every side absorbs the rounding of the samples between the corners
-    w.lo_x = (float)(wx0 + 1);
+    // (samples left of / above the image, where both taps are the clamped edge texel, take the global path: the window
+    // path computes its LDS addresses in binary32 and relies on X, Y >= 0)
+    w.lo_x = (float)max(wx0 + 1, 0);
     w.hi_x = (float)(wx0 + kWinW - 1);
-    w.lo_y = (float)(wy0 + 1);
+    w.lo_y = (float)max(wy0 + 1, 0);
     w.hi_y = (float)(wy0 + WINH - 1);
     w.addr0 = __builtin_amdgcn_readfirstlane(lds_address(win) - (wy0 * kPitch + wx0) * (1 << kShift));
     return w;
@@ -231,23 +233,45 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
         Y[j] *= r[j];
     }
     APD_STAGE();
-    int qx[kPatchN], qy[kPatchN];
+    // LDS address of entry (floor X, floor Y) in binary32.  On gfx950 the plain binary32 multiply / add / FMA issue in 2
+    // cycles per wave, everything else (v_fract, conversions, integer multiply-add, shift-add) in 4 (tools/valu_issue.hip),
+    // so the two floor conversions + v_mad_i32_i24 + v_lshl_add_u32 (16 cycles) become two subtractions, two FMAs and one
+    // conversion (13 cycles).  Exact: samples of the window path have X, Y >= 0 (SrcWindow::lo_x / lo_y), where
+    // v_fract_f32(X) == X - floor(X) exactly, so X - fract(X) is floor(X); the address is an integer below 2^24 at every step.
+    constexpr float kEntryBytes = (float)(1 << WinEntry<kQuad>::kShift), kPitchBytes = (float)(kPitch << WinEntry<kQuad>::kShift);
+    const float addr0f = (float)addr0;
+    float fx[kPatchN], fy[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
         a[j] = __builtin_amdgcn_fractf(X[j]);
         b[j] = __builtin_amdgcn_fractf(Y[j]);
-        qx[j] = cvt_floor_i32(X[j]);
-        qy[j] = cvt_floor_i32(Y[j]);
     }
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = win_byte_address<WinEntry<kQuad>::kShift, kPitch>(qx[j], qy[j], addr0);
+        fx[j] = X[j] - a[j];
+        fy[j] = Y[j] - b[j];
     }
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        t[j] = lds_read_pair<typename WinEntry<kQuad>::type, kPitch>(qx[j]);
+        fx[j] = fmaf(fx[j], kEntryBytes, addr0f);
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        fx[j] = fmaf(fy[j], kPitchBytes, fx[j]);
+    }
+    APD_STAGE();
+    int addr[kPatchN];
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        addr[j] = (int)fx[j];
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        t[j] = lds_read_pair<typename WinEntry<kQuad>::type, kPitch>(addr[j]);
     }
 }
 
