@@ -477,8 +477,11 @@ __device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
 #else
 __device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
 {
-    const float t00 = (float)(t & 0xFFu), t10 = (float)((t >> 8) & 0xFFu);
-    const float t01 = (float)((t >> 16) & 0xFFu), t11 = (float)(t >> 24);
+    float t00, t10, t01, t11;  // four v_cvt_f32_ubyte<k>; the differences below stay binary32 subtractions (see quad_row_lerp)
+    asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(t));
+    asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(t));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(t));
+    asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(t));
     const float top = fmaf(a, t10 - t00, t00);
     const float bot = fmaf(a, t11 - t01, t01);
     return fmaf(b, bot - top, top);
@@ -720,13 +723,21 @@ __device__ __forceinline__ void quad_row_lerp(const quad_t (&t)[kPatchN], const 
         t01[j] = lerp_f16_pair(a[j], t[j].y);
     }
 #else
+    // byte k -> float with v_cvt_f32_ubyte<k> (4 cycles), the two differences as binary32 subtractions (2 cycles): left to
+    // itself the compiler subtracts the bytes as integers (SDWA) and converts the difference, two 4-cycle instructions each
     float d0[kPatchN], d1[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        t00[j] = (float)(t[j] & 0xFFu);
-        t01[j] = (float)((t[j] >> 16) & 0xFFu);
-        d0[j] = (float)((t[j] >> 8) & 0xFFu) - t00[j];
-        d1[j] = (float)(t[j] >> 24) - t01[j];
+        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00[j]) : "v"(t[j]));
+        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d0[j]) : "v"(t[j]));
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01[j]) : "v"(t[j]));
+        asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d1[j]) : "v"(t[j]));
+    }
+    APD_STAGE();
+#pragma unroll
+    for (int j = 0; j < kPatchN; ++j) {
+        d0[j] -= t00[j];
+        d1[j] -= t01[j];
     }
     APD_STAGE();
 #pragma unroll

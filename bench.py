@@ -27,12 +27,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-# Vector-ALU issue ceiling of the chip: 256 CUs x 4 SIMDs, 2.4 GHz max clock, VALU_CYCLES_PER_WAVE_INST cycles per wave64
-# instruction on one SIMD (tools/valu_issue.hip, profiles/r02/valu_issue.csv: the plateau of v_fma_f32 / v_mul_f32 /
-# v_fract_f32 ... over 1..8 waves per SIMD; packed binary32 instructions cost twice that).
+# Vector-ALU issue ceiling of the chip: 256 CUs x 4 SIMDs at the 2.4 GHz maximum clock, one wave64 binary32 multiply / add /
+# FMA per 2 cycles per SIMD (MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc"; tools/valu_issue.hip measures a plateau of
+# 2.2 cycles, profiles/r02/valu_issue.csv).  That is the fastest instruction class: v_fract / conversions / v_fma_mix /
+# integer multiply-add issue in 4 cycles, v_rcp_f32 in 8, packed binary32 in 4 -- so `frac` against this peak is a LOWER
+# bound of how busy the pipe is; `valu_busy_estimate` weights the instruction count with the mean issue cost of the
+# kernel's own 36-sample body (tools/valu_mix.py -> profiles/r02/valu_mix_k67w.json).
 NUM_SIMDS = 1024
 MAX_CLOCK_GHZ = 2.4
-VALU_CYCLES_PER_WAVE_INST = 4.0
+VALU_CYCLES_PER_WAVE_INST = 2.0
 VALU_PEAK_GINST = NUM_SIMDS * MAX_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INST  # G wave64 instructions / s
 
 WORKLOADS = {
@@ -294,6 +297,13 @@ def main():
                     "bytes_per_launch": traffic, "note": "2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction of the guide)"},
             "pmc_source": pmc["source"], "pmc_launch_ms": pmc.get("launch_ms"),
         })
+        mix = load_valu_mix()
+        if mix is not None:
+            busy = insts * mix["mean_cycles_per_inst"] / (NUM_SIMDS * MAX_CLOCK_GHZ * 1e9 * avg_ms * 1e-3)
+            roofline["valu_busy_estimate"] = {
+                "frac": round(busy, 4), "mean_issue_cycles_per_inst": mix["mean_cycles_per_inst"], "source": mix["source"],
+                "note": "VALU instructions per launch x mean issue cycles of the kernel's LDS-window body (static mix, measured "
+                        "per-class costs) / (1024 SIMDs x 2.4 GHz x launch time); an estimate, the counters do not split by class"}
     else:
         roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s steps=%d warmup=%d under profiles/: "
                                 "achieved / frac / traffic are null rather than borrowed from another configuration"
@@ -407,6 +417,19 @@ def load_pmc_profile(workload, steps, warmup, kernel):
             continue
         best = {"valu_insts_per_launch": k["valu_insts_per_launch"], "hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
                 "launch_ms": k.get("launch_ms"), "source": os.path.relpath(path, ROOT)}
+    return best
+
+
+def load_valu_mix():
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "valu_mix_k67w.json"))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            best = {"mean_cycles_per_inst": rec["window_body"]["mean_cycles_per_inst"], "source": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
     return best
 
 
