@@ -132,6 +132,10 @@ static void refresh_frame_args(apd_context *c)
     fa.half_rows = 2 * (((c->H / 2) + 15) / 16) * 16;
     fa.use_quads = c->use_quads ? 1 : 0;
     fa.have_tiled = c->have_tiled ? 1 : 0;
+    {   // optional tolerance mode (default off: the parity target is the exact mode); read when the handle is (re)armed
+        const char *e = getenv("APD_FAST_RCP");
+        fa.approx_rcp = (e && e[0] == '1') ? 1 : 0;
+    }
     fa.top_k = p.top_k;
     fa.depth_min = p.depth_min;
     fa.depth_max = p.depth_max;

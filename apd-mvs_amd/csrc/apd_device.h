@@ -71,6 +71,7 @@ struct FrameArgs {
     int half_rows;     // rows reachable by the reference HALF launch: 2*ceil((H/2)/16)*16 (APD.cu:2402)
     int use_quads;     // 1: source images are also available as texel quads (ViewConst::quad)
     int have_tiled;    // 1: ... and as the tiled copy (ViewConst::quad_tiled)
+    int approx_rcp;    // 1: tolerance mode APD_FAST_RCP=1 (K6/K7 sample loops stop at v_rcp_f32; results are NOT the oracle's bits)
     // params (main.h:75-94)
     int top_k;
     float depth_min, depth_max;
@@ -614,7 +615,13 @@ __device__ __forceinline__ unsigned fquad_byte_offset(int qx, int qy, int pitch,
 }
 
 // Sample positions of one patch row (fixed x, six y) -> bilinear weights + texel-quad gathers in flight.
-template <bool kFastRecip, bool kTiled = false>
+// Reciprocal of the sample loops: kRecipIeee -- IEEE division (any denominator); kRecipExact -- v_rcp_f32 + one Newton step,
+// the correctly rounded reciprocal on the range denominators_fast() checks (the default path); kRecipApprox -- the bare
+// v_rcp_f32 (<= 1 ulp), what the reference's own --use_fast_math build does (CMakeLists.txt:20): the optional tolerance
+// mode APD_FAST_RCP=1, NOT bit-identical to the oracle (tests/test_gpu_fast_rcp.py states what it keeps).
+enum { kRecipIeee = 0, kRecipExact = 1, kRecipApprox = 2 };
+
+template <int kRecip, bool kTiled = false>
 __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN],
                                                global_quad_ptr srcq, unsigned pitch, int wm1, int hm1,
                                                float (&a)[kPatchN], float (&b)[kPatchN], quad_t (&t)[kPatchN])
@@ -627,7 +634,12 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
         Y[j] = fmaf(H.h[4], yf[j], by);
     }
     APD_STAGE();
-    if (kFastRecip) {
+    if (kRecip == kRecipApprox) {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = __builtin_amdgcn_rcpf(z[j]);
+        }
+    } else if (kRecip == kRecipExact) {
 #pragma unroll
         for (int j = 0; j < kPatchN; ++j) {
             r[j] = __builtin_amdgcn_rcpf(z[j]);
@@ -759,7 +771,7 @@ __device__ __forceinline__ void quad_row_lerp(const quad_t (&t)[kPatchN], const 
 }
 
 // The same two stages for float texel-quad images (float grey values).
-template <bool kFastRecip>
+template <int kRecip>
 __device__ __forceinline__ void fquad_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN],
                                                 global_fquad_ptr fq, unsigned pitch, int wm1, int hm1, float (&a)[kPatchN],
                                                 float (&b)[kPatchN], fquad_t (&t)[kPatchN])
@@ -772,7 +784,12 @@ __device__ __forceinline__ void fquad_row_issue(const Homography &H, float bx, f
         Y[j] = fmaf(H.h[4], yf[j], by);
     }
     APD_STAGE();
-    if (kFastRecip) {
+    if (kRecip == kRecipApprox) {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = __builtin_amdgcn_rcpf(z[j]);
+        }
+    } else if (kRecip == kRecipExact) {
 #pragma unroll
         for (int j = 0; j < kPatchN; ++j) {
             r[j] = __builtin_amdgcn_rcpf(z[j]);
@@ -848,9 +865,9 @@ __device__ __forceinline__ void fquad_row_lerp(const fquad_t (&t)[kPatchN], cons
 }
 
 // The 36 warped source samples of one fixed patch and their three moments (APD.cu:561-583), summed in the
-// reference's order (row partial sums, then total).  kFastRecip: every denominator is known to be in the
+// reference's order (row partial sums, then total).  kRecip (see quad_row_issue); kRecipExact: every denominator is known to be in the
 // range where recip_fast is the correctly rounded reciprocal.
-template <bool kQuad, bool kFastRecip, bool kTiled, typename Ref>
+template <bool kQuad, int kRecip, bool kTiled, typename Ref>
 __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H_in,
                                                   int px_in, int py_in, float &sum_s, float &sum_ss, float &sum_rs)
 {
@@ -892,9 +909,9 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
         const float xf = (float)(px + kPatchStep * r - kPatchRadius);
         const float bx = fmaf(H.h[0], xf, H.h[2]), by = fmaf(H.h[3], xf, H.h[5]), bz = fmaf(H.h[6], xf, H.h[8]);
         if constexpr (kQuad) {
-            quad_row_issue<kFastRecip, kTiled>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[r], b[r], t[r]);
+            quad_row_issue<kRecip, kTiled>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[r], b[r], t[r]);
         } else {
-            fquad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcf, fpitch, wm1, hm1, a[r], b[r], tf[r]);
+            fquad_row_issue<kRecip>(H, bx, by, bz, yf, srcf, fpitch, wm1, hm1, a[r], b[r], tf[r]);
         }
     }
 #pragma unroll
@@ -905,9 +922,9 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
             const float xf = (float)(px + kPatchStep * (i + kDepth) - kPatchRadius);
             const float bx = fmaf(H.h[0], xf, H.h[2]), by = fmaf(H.h[3], xf, H.h[5]), bz = fmaf(H.h[6], xf, H.h[8]);
             if constexpr (kQuad) {
-                quad_row_issue<kFastRecip, kTiled>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[n], b[n], t[n]);
+                quad_row_issue<kRecip, kTiled>(H, bx, by, bz, yf, srcq, qpitch, wm1, hm1, a[n], b[n], t[n]);
             } else {
-                fquad_row_issue<kFastRecip>(H, bx, by, bz, yf, srcf, fpitch, wm1, hm1, a[n], b[n], tf[n]);
+                fquad_row_issue<kRecip>(H, bx, by, bz, yf, srcf, fpitch, wm1, hm1, a[n], b[n], tf[n]);
             }
         }
         APD_STAGE();
@@ -966,9 +983,9 @@ __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const Vie
 #endif
     float sum_s, sum_ss, sum_rs;
     if (__builtin_expect(fast_recip, 1)) {
-        ncc_fixed_moments<kQuad, true, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, kRecipExact, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else {
-        ncc_fixed_moments<kQuad, false, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, kRecipIeee, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     }
     const float inv_w = 1.0f / 36.0f;
     sum_s *= inv_w;

@@ -130,7 +130,8 @@ constexpr float kTrustedCost = APD_WIN_TRUST;
 #define APD_K67W_WAVES_F32 3  // float windows are twice the size: three workgroups per CU
 #endif
 // kTiled: NCCs that miss the window (all of them while the windows are off) gather from the tiled copy of the quad image
-template <int NMAX, bool kQuad, bool kTiled>
+// kApprox: tolerance mode APD_FAST_RCP=1 (bare v_rcp_f32 in the sample loops; not bit-identical to the oracle)
+template <int NMAX, bool kQuad, bool kTiled, bool kApprox>
 __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) void k67w_update_strong(FrameArgs fa, int colour, int iter)
 {
     __shared__ float tile[kLdsH * kLdsPitch];
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
                 const float4 pl = (h < 8) ? fa.planes[positions[h]] : plane_now;
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                cost_array[h][v] = ncc_fixed_windowed<kQuad, kWinW, kTiled>(fa, vc, w, rp, px, py, qx, qy, qz);
+                cost_array[h][v] = ncc_fixed_windowed<kQuad, kWinW, kTiled, kApprox>(fa, vc, w, rp, px, py, qx, qy, qz);
             }
         }
     }
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
                 pl.w = ref_w[k];
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                tc[k] += (float)wv * ncc_fixed_windowed<kQuad, kWinW, kTiled>(fa, vc, w, rp, px, py, qx, qy, qz);
+                tc[k] += (float)wv * ncc_fixed_windowed<kQuad, kWinW, kTiled, kApprox>(fa, vc, w, rp, px, py, qx, qy, qz);
             }
         }
     }
@@ -356,15 +357,25 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 }
 
 
+template <bool kQuad, bool kTiled, bool kApprox>
+static void launch_k67w_n(const FrameArgs &fa, int tiles, int colour, int iter, hipStream_t s)
+{
+    if (fa.num_src <= 8) {
+        hipLaunchKernelGGL((k67w_update_strong<8, kQuad, kTiled, kApprox>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    } else if (fa.num_src <= 16) {
+        hipLaunchKernelGGL((k67w_update_strong<16, kQuad, kTiled, kApprox>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    } else {
+        hipLaunchKernelGGL((k67w_update_strong<32, kQuad, kTiled, kApprox>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    }
+}
+
 template <bool kQuad, bool kTiled>
 static void launch_k67w(const FrameArgs &fa, int tiles, int colour, int iter, hipStream_t s)
 {
-    if (fa.num_src <= 8) {
-        hipLaunchKernelGGL((k67w_update_strong<8, kQuad, kTiled>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
-    } else if (fa.num_src <= 16) {
-        hipLaunchKernelGGL((k67w_update_strong<16, kQuad, kTiled>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    if (fa.approx_rcp) {
+        launch_k67w_n<kQuad, kTiled, true>(fa, tiles, colour, iter, s);
     } else {
-        hipLaunchKernelGGL((k67w_update_strong<32, kQuad, kTiled>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+        launch_k67w_n<kQuad, kTiled, false>(fa, tiles, colour, iter, s);
     }
 }
 

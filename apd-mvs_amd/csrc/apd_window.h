@@ -199,7 +199,7 @@ __device__ __forceinline__ int win_byte_address(int qx, int qy, int addr0)
 }
 
 // quad_row_issue / fquad_row_issue for samples known to lie inside the window: no clamps, LDS addresses.
-template <bool kQuad, int kPitch>
+template <bool kQuad, int kPitch, bool kApprox = false>
 __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN], int addr0,
                                               float (&a)[kPatchN], float (&b)[kPatchN],
                                               WinTaps<typename WinEntry<kQuad>::type> (&t)[kPatchN])
@@ -217,16 +217,18 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
         r[j] = __builtin_amdgcn_rcpf(z[j]);
     }
     APD_STAGE();
+    if constexpr (!kApprox) {  // Newton step: the correctly rounded reciprocal (tolerance mode APD_FAST_RCP=1 stops at v_rcp_f32)
 #pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        z[j] = fmaf(-z[j], r[j], 1.0f);
-    }
-    APD_STAGE();
+        for (int j = 0; j < kPatchN; ++j) {
+            z[j] = fmaf(-z[j], r[j], 1.0f);
+        }
+        APD_STAGE();
 #pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        r[j] = fmaf(z[j], r[j], r[j]);
+        for (int j = 0; j < kPatchN; ++j) {
+            r[j] = fmaf(z[j], r[j], r[j]);
+        }
+        APD_STAGE();
     }
-    APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
         X[j] *= r[j];
@@ -304,7 +306,7 @@ __device__ __forceinline__ void win_row_lerp(const WinTaps<typename WinEntry<kQu
 }
 
 // ncc_fixed_moments (fast reciprocal) reading the window.
-template <bool kQuad, int kPitch, typename Ref>
+template <bool kQuad, int kPitch, bool kApprox, typename Ref>
 __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homography &H, int px, int py, int addr0, float &sum_s,
                                                    float &sum_ss, float &sum_rs)
 {
@@ -320,8 +322,8 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
     WinTaps<typename WinEntry<kQuad>::type> t[2][kPatchN];
     {
         const float xf = (float)(px - kPatchRadius);
-        win_row_issue<kQuad, kPitch>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0, a[0], b[0],
-                                     t[0]);
+        win_row_issue<kQuad, kPitch, kApprox>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0,
+                                              a[0], b[0], t[0]);
     }
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
@@ -336,8 +338,8 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
         APD_STAGE();
         if (i + 1 < kPatchN) {
             const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
-            win_row_issue<kQuad, kPitch>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0,
-                                         a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
+            win_row_issue<kQuad, kPitch, kApprox>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf,
+                                                  addr0, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
         }
         APD_STAGE();
         win_row_lerp<kQuad>(t[i & 1], a[i & 1], b[i & 1], v);
@@ -355,16 +357,18 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
 }
 
 // Sample position of patch corner (xf, yf), computed exactly like the samples themselves (fast reciprocal).
+template <bool kApprox = false>
 __device__ __forceinline__ void corner_position(const Homography &H, float xf, float yf, float &X, float &Y)
 {
     const float z = fmaf(H.h[7], yf, fmaf(H.h[6], xf, H.h[8]));
-    const float r = recip_fast(z);
+    const float r = kApprox ? __builtin_amdgcn_rcpf(z) : recip_fast(z);
     X = fmaf(H.h[1], yf, fmaf(H.h[0], xf, H.h[2])) * r;
     Y = fmaf(H.h[4], yf, fmaf(H.h[3], xf, H.h[5])) * r;
 }
 
 // ComputeBilateralNCCOld (APD.cu:530-614) for plane q = n/d against source view vc, window first.
-template <bool kQuad, int kPitch = kWinW, bool kTiled = false, typename Ref>
+// kApprox: tolerance mode (bare v_rcp_f32 everywhere, no IEEE body); see quad_row_issue
+template <bool kQuad, int kPitch = kWinW, bool kTiled = false, bool kApprox = false, typename Ref>
 __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const ViewConst &vc, const SrcWindow &w, const Ref &rp, int px,
                                                     int py, float qx, float qy, float qz)
 {
@@ -380,16 +384,17 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
     }
     const float x0 = (float)(px - kPatchRadius), x1 = (float)(px + kPatchRadius);
     const float y0 = (float)(py - kPatchRadius), y1 = (float)(py + kPatchRadius);
+    // tolerance mode: every denominator goes through v_rcp_f32; the corner test below still needs one sign
     const bool fast_recip = denominators_fast(H, x0, x1, y0, y1);
     bool in_window = false;
     if (fast_recip && w.valid) {
         // x/z and y/z are monotone along every row and every column of the sample grid while z keeps its sign, so the
         // four corner samples bound all 36
         float X00, Y00, X01, Y01, X10, Y10, X11, Y11;
-        corner_position(H, x0, y0, X00, Y00);
-        corner_position(H, x0, y1, X01, Y01);
-        corner_position(H, x1, y0, X10, Y10);
-        corner_position(H, x1, y1, X11, Y11);
+        corner_position<kApprox>(H, x0, y0, X00, Y00);
+        corner_position<kApprox>(H, x0, y1, X01, Y01);
+        corner_position<kApprox>(H, x1, y0, X10, Y10);
+        corner_position<kApprox>(H, x1, y1, X11, Y11);
         const float xl = fminf(fminf(X00, X01), fminf(X10, X11)), xh = fmaxf(fmaxf(X00, X01), fmaxf(X10, X11));
         const float yl = fminf(fminf(Y00, Y01), fminf(Y10, Y11)), yh = fmaxf(fmaxf(Y00, Y01), fmaxf(Y10, Y11));
         in_window = xl >= w.lo_x && xh < w.hi_x && yl >= w.lo_y && yh < w.hi_y;
@@ -416,11 +421,13 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
 #endif
     float sum_s, sum_ss, sum_rs;
     if (in_window) {
-        ncc_window_moments<kQuad, kPitch>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
+        ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
+    } else if constexpr (kApprox) {
+        ncc_fixed_moments<kQuad, kRecipApprox, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else if (__builtin_expect(fast_body, 1)) {
-        ncc_fixed_moments<kQuad, true, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, kRecipExact, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else {
-        ncc_fixed_moments<kQuad, false, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments<kQuad, kRecipIeee, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     }
     const float inv_w = 1.0f / 36.0f;
     sum_s *= inv_w;

@@ -276,3 +276,41 @@ def test_malformed_jpegs_never_leave_their_buffers(tmp_path):
     assert intact and "grey=1 colour=1" in intact[0]
     refused = sum("grey=0" in ln for ln in lines)
     assert refused > 20, "the crafted selector / truncated files must be refused"
+
+
+@pytest.mark.parametrize("rows,cols,scale", [(4130, 6200, 8), (4130, 6200, 4), (4130, 6200, 2), (1080, 1920, 2), (517, 775, 2), (33, 47, 4)])
+def test_resize_linear_matches_independent_bilinear_at_the_pyramid_ratios(host, rows, cols, scale):
+    """ResizeLinear (host/APD.cpp) restates cv::resize(float, INTER_LINEAR) (APD.cpp:464-474: new size = round(old / scale), so
+    the ratios are NOT integers: 4130 / 8 -> 516 rows).  OpenCV is not in the image; two independent implementations of the
+    same definition -- half-pixel centres, taps floor(fx) and floor(fx) + 1 clamped to the image, no antialiasing -- are:
+    scipy.ndimage.zoom(order=1, mode='nearest', grid_mode=True) (double arithmetic) and torch's bilinear interpolate
+    (align_corners=False, antialias=False).  Agreement to float rounding at the sizes the four-level pyramid of a
+    6200 x 4130 image really uses; the power-of-two special case is covered above."""
+    import math
+    import scipy.ndimage as ndi
+    import torch
+    rng = np.random.RandomState(rows + cols + scale)
+    coarse = rng.rand(rows // 16 + 2, cols // 16 + 2) * 255
+    a = np.kron(coarse, np.ones((16, 16)))[:rows, :cols].astype(np.float32)
+    a += (rng.rand(rows, cols) * 8).astype(np.float32)
+    new_rows = int(math.floor(rows / scale + 0.5))   # std::round of a positive value
+    new_cols = int(math.floor(cols / scale + 0.5))
+    out = np.zeros((new_rows, new_cols), np.float32)
+    fp = C.POINTER(C.c_float)
+    host.apdhost_resize_linear(a.ctypes.data_as(fp), rows, cols, out.ctypes.data_as(fp), new_rows, new_cols)
+    ref1 = ndi.zoom(a.astype(np.float64), (new_rows / rows, new_cols / cols), order=1, mode="nearest", grid_mode=True)
+    assert ref1.shape == out.shape
+    ref2 = torch.nn.functional.interpolate(torch.from_numpy(a)[None, None].double(), size=(new_rows, new_cols), mode="bilinear",
+                                           align_corners=False, antialias=False)[0, 0].numpy()
+    assert np.abs(ref1 - ref2).max() < 1e-9          # the two references agree with each other
+    # cv::resize keeps the source coordinate in binary32: fx = (float)((dx + 0.5) * scale - 0.5).  At x ~ 6000 one ulp of fx is
+    # 4.9e-4 px, so against double coordinates the result may move by up to ~ulp/2 x local contrast (0.03 grey levels on this
+    # deliberately blocky image) -- a property of the definition, not of this implementation ...
+    assert np.abs(out - ref1).max() < 0.1 and np.abs(out - ref1).mean() < 5e-4
+    # ... so the sharp check interpolates, in double and with another engine (scipy.ndimage.map_coordinates), at exactly the
+    # binary32 coordinates OpenCV defines: what is left is the binary32 rounding of the three lerps
+    fy = ((np.arange(new_rows) + 0.5) * (rows / new_rows) - 0.5).astype(np.float32).astype(np.float64)
+    fx = ((np.arange(new_cols) + 0.5) * (cols / new_cols) - 0.5).astype(np.float32).astype(np.float64)
+    yy, xx = np.meshgrid(np.clip(fy, 0, rows - 1), np.clip(fx, 0, cols - 1), indexing="ij")
+    ref3 = ndi.map_coordinates(a.astype(np.float64), [yy, xx], order=1, mode="nearest")
+    assert np.abs(out - ref3).max() < 1e-4, np.abs(out - ref3).max()
