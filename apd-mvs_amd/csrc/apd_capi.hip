@@ -454,9 +454,9 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         }
     }
     if (c->use_quads) {
-        const size_t qn = (size_t)(c->W + 1) * (c->H + 1);
+        const size_t qbytes = apd::quad_image_bytes(c->W, c->H);
         for (int i = 1; i < num_images; ++i) {
-            HIP_TRY(hipMalloc(&c->quads[i], qn * sizeof(apd::quad_t)));
+            HIP_TRY(hipMalloc(&c->quads[i], qbytes));
             hipError_t e = apd::launch_pack_quads(c->images[i], c->W, c->H, c->quads[i], c->stream);
             if (e != hipSuccess) {
                 return fail(APD_ERR_HIP, "k_pack_quads failed: %s", hipGetErrorString(e));

@@ -32,6 +32,25 @@ constexpr int kQuadShift = 2;
 #endif
 constexpr unsigned kQuadBytes = 1u << kQuadShift;
 
+// Row-major copy of the 8-bit source images ("texel quads").  Default: 2-byte COLUMN PAIRS -- entry (t, u) = (qx + 1, qy + 1)
+// holds {I(qx, qy), I(qx, qy + 1)} (clamped coordinates) and the dword at byte 2 * (u * (W + 2) + t) is therefore
+// {I(qx,qy), I(qx,qy+1), I(qx+1,qy), I(qx+1,qy+1)}: all four taps of a bilinear fetch in ONE gather, as with 4-byte quads, at
+// half the footprint (twice the pixels per 128-byte line, per L1, per L2).  Half of these gathers are not dword aligned,
+// which costs nothing on gfx950 (tools/unaligned_gather.hip: 18.67 vs 18.85 ms for 1.07e9 lines).  -DAPD_QUAD4 builds the
+// round-1 layout (4-byte entries {I(qx,qy), I(qx+1,qy), I(qx,qy+1), I(qx+1,qy+1)}, pitch W + 1) for A/B runs.
+// The tiled copy (quad_tiled_index) keeps 4-byte entries; both copies use the byte order of the row-major dword, so there
+// is one decode: kPair2: bytes {t00, t01, t10, t11}, else {t00, t10, t01, t11}.
+#ifndef APD_QUAD4
+constexpr bool kPair2 = true;
+#else
+constexpr bool kPair2 = false;
+#endif
+constexpr int kRowEntryShift = kPair2 ? 1 : 2;
+constexpr unsigned kRowEntryBytes = 1u << kRowEntryShift;
+__host__ __device__ __forceinline__ unsigned quad_row_pitch_bytes(int W) { return kPair2 ? 2u * (unsigned)(W + 2) : 4u * (unsigned)(W + 1); }
+// + 4: the dword of the last entry reads two bytes past it
+__host__ __device__ __forceinline__ size_t quad_image_bytes(int W, int H) { return (size_t)quad_row_pitch_bytes(W) * (size_t)(H + 1) + 4u; }
+
 // One texel pair: the texel and the (rounded) difference to its right neighbour -- the two numbers the horizontal
 // lerp fmaf(a, t10 - t00, t00) needs, as binary32.  A float texel quad is the pair of a texel and the pair of the texel
 // below it: same taps, same three fused multiply-adds as a four-tap float sampler, one 16-byte gather instead of four
@@ -455,9 +474,11 @@ __device__ __forceinline__ fquad_t fquad_fetch(global_fquad_ptr fq, unsigned off
 // A NaN/Inf coordinate gives a NaN weight, so the sample is NaN whatever texel is read and the index clamp only
 // has to keep the address in range.  Fetch and interpolation are separate so a caller can put several gathers
 // in flight before consuming the first one (quad_row_issue / quad_row_lerp, subpatch_cost_quad).
+typedef quad_t quad_unaligned_t __attribute__((aligned(2)));
 __device__ __forceinline__ quad_t quad_fetch(global_quad_ptr quad, unsigned off)
 {
-    return *(global_quad_ptr)((const __attribute__((address_space(1))) char *)quad + off);
+    // one global_load_dword; with 2-byte column pairs the address is only 2-byte aligned
+    return *(const __attribute__((address_space(1))) quad_unaligned_t *)((const __attribute__((address_space(1))) char *)quad + off);
 }
 
 // fmaf(a, (float)hi16(p), (float)lo16(p)) in one instruction: p = {binary16 base, binary16 delta}
@@ -480,9 +501,14 @@ __device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
 {
     float t00, t10, t01, t11;  // four v_cvt_f32_ubyte<k>; the differences below stay binary32 subtractions (see quad_row_lerp)
     asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(t));
-    asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(t));
-    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(t));
     asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(t));
+    if (kPair2) {
+        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t01) : "v"(t));
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t10) : "v"(t));
+    } else {
+        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(t));
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(t));
+    }
     const float top = fmaf(a, t10 - t00, t00);
     const float bot = fmaf(a, t11 - t01, t01);
     return fmaf(b, bot - top, top);
@@ -536,7 +562,7 @@ __device__ __forceinline__ unsigned quad_byte_offset(int qx, int qy, int pitch, 
 {
     int row, off;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row) : "v"(qy), "v"(pitch), "v"(origin));
-    asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(off) : "v"(qx), "v"(row), "n"(kQuadShift));
+    asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(off) : "v"(qx), "v"(row), "n"(kRowEntryShift));
     return (unsigned)off;
 }
 
@@ -687,7 +713,7 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
         if constexpr (kTiled) {
             qx[j] = (int)quad_tiled_byte_offset(qx[j], qy[j], pitch);  // `pitch` = tiles per tile row here
         } else {
-            qx[j] = (int)quad_byte_offset(qx[j], qy[j], (int)pitch, (int)(pitch + kQuadBytes));
+            qx[j] = (int)quad_byte_offset(qx[j], qy[j], (int)pitch, (int)(pitch + kRowEntryBytes));
         }
     }
     APD_STAGE();
@@ -741,9 +767,14 @@ __device__ __forceinline__ void quad_row_lerp(const quad_t (&t)[kPatchN], const 
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
         asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00[j]) : "v"(t[j]));
-        asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d0[j]) : "v"(t[j]));
-        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01[j]) : "v"(t[j]));
         asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d1[j]) : "v"(t[j]));
+        if (kPair2) {
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t01[j]) : "v"(t[j]));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d0[j]) : "v"(t[j]));
+        } else {
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d0[j]) : "v"(t[j]));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01[j]) : "v"(t[j]));
+        }
     }
     APD_STAGE();
 #pragma unroll
@@ -883,7 +914,7 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
 #endif
     const global_quad_ptr srcq = (global_quad_ptr)(kTiled ? vc.quad_tiled : vc.quad);
     const int W = fa.W, Hh = fa.H;
-    const unsigned qpitch = kTiled ? quad_tiles_x(W) : kQuadBytes * (unsigned)(W + 1);
+    const unsigned qpitch = kTiled ? quad_tiles_x(W) : quad_row_pitch_bytes(W);
     const unsigned fpitch = 16u * (unsigned)(W + 1);
     const global_fquad_ptr srcf = (global_fquad_ptr)vc.fquad;
     const int wm1 = W - 1, hm1 = Hh - 1;
@@ -1084,7 +1115,7 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
     APD_STAGE();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)qpitch, (int)(qpitch + kQuadBytes));
+        qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)qpitch, (int)(qpitch + kRowEntryBytes));
     }
     APD_STAGE();
 #ifdef APD_EXPERIMENT_SUB_ADDR_ZERO  // timing experiment only: every sub-patch gather hits the same L1 line

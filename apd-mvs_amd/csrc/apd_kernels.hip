@@ -708,6 +708,19 @@ __global__ __launch_bounds__(256) void k_pack_quads(const float *__restrict__ im
 #endif
 }
 
+// 2-byte column pairs (the default row-major copy, apd_device.h): entry (t, u), t in [0, W + 1], u in [0, H], =
+// {I(t - 1, u - 1), I(t - 1, u)} with clamped coordinates
+__global__ __launch_bounds__(256) void k_pack_pairs(const float *__restrict__ img, int W, int H, uint16_t *__restrict__ pairs)
+{
+    const int t = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int u = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (t > W + 1 || u > H) {
+        return;
+    }
+    const uint32_t top = (uint32_t)fetch_texel(img, W, H, t - 1, u - 1), bot = (uint32_t)fetch_texel(img, W, H, t - 1, u);
+    pairs[(size_t)u * (W + 2) + t] = (uint16_t)(top | (bot << 8));
+}
+
 // the byte quads again, in 8 x 4 tiles (quad_tiled_index); same entries as k_pack_quads writes
 __global__ __launch_bounds__(256) void k_pack_quads_tiled(const float *__restrict__ img, int W, int H, quad_t *__restrict__ quad)
 {
@@ -718,7 +731,8 @@ __global__ __launch_bounds__(256) void k_pack_quads_tiled(const float *__restric
     }
     const uint32_t t00 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy - 1), t10 = (uint32_t)fetch_texel(img, W, H, qx, qy - 1);
     const uint32_t t01 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy), t11 = (uint32_t)fetch_texel(img, W, H, qx, qy);
-    quad[quad_tiled_index((unsigned)qx, (unsigned)qy, quad_tiles_x(W))] = t00 | (t10 << 8) | (t01 << 16) | (t11 << 24);
+    quad[quad_tiled_index((unsigned)qx, (unsigned)qy, quad_tiles_x(W))] =
+        kPair2 ? (t00 | (t01 << 8) | (t10 << 16) | (t11 << 24)) : (t00 | (t10 << 8) | (t01 << 16) | (t11 << 24));  // one decode for both copies
 }
 
 // float texel quads of a float image: entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1] (clamped coordinates)
@@ -748,7 +762,11 @@ hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s)
 
 hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pack_quads, dim3((W + 1 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, quad);
+    if (kPair2) {
+        hipLaunchKernelGGL(k_pack_pairs, dim3((W + 2 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, reinterpret_cast<uint16_t *>(quad));
+    } else {
+        hipLaunchKernelGGL(k_pack_quads, dim3((W + 1 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, quad);
+    }
     return hipGetLastError();
 }
 

@@ -547,7 +547,7 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
     const float center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
 #endif
     const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
-    const unsigned qpitch = kQuadBytes * (unsigned)(fa.W + 1);
+    const unsigned qpitch = quad_row_pitch_bytes(fa.W);
     const unsigned fpitch = 16u * (unsigned)(fa.W + 1);
     const global_fquad_ptr srcf = (global_fquad_ptr)vc.fquad;
     const int wm1 = fa.W - 1, hm1 = fa.H - 1;

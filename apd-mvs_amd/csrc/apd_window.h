@@ -22,7 +22,7 @@ namespace apd {
 constexpr int kWinW = 64;
 // LDS dwords of a window with WINH rows of fetch positions (+ the row below the last one)
 constexpr int window_dwords(bool quad, int winh, int pitch = kWinW) { return pitch * (winh + 1) * (quad ? 1 : 2); }
-static_assert(kQuadShift == 2, "the window is staged from 4-byte quad entries");
+static_assert(kQuadShift == 2, "the window is staged from dword fetches of the quad image");
 
 template <bool kQuad> struct WinEntry;
 template <> struct WinEntry<true> {
@@ -140,17 +140,41 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
     const int col = med3_i32(wx0 + lane, -1, fa.W - 1) + 1;
     if constexpr (kQuad) {
         const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
-        uint32_t tmp[kWinRows];
+        const unsigned rpitch = quad_row_pitch_bytes(fa.W);
+        if constexpr (kPair2) {
+            // a column-pair dword holds the texels of rows gy and gy + 1 (clamping built in): one gather stages two window rows
+            constexpr int kLoads = (kWinRows + 1) / 2;
+            uint32_t tmp[kLoads];
 #pragma unroll
-        for (int k = 0; k < kWinRows; ++k) {
-            const int gy = min(max(wy0 + k, -1), fa.H - 1);  // wave-uniform
-            tmp[k] = srcq[(unsigned)((gy + 1) * qp + col)];
-        }
+            for (int k = 0; k < kLoads; ++k) {
+                const int gy = min(max(wy0 + 2 * k, -1), fa.H - 1);  // wave-uniform
+                tmp[k] = quad_fetch(srcq, (unsigned)(gy + 1) * rpitch + ((unsigned)col << kRowEntryShift));
+            }
 #pragma unroll
-        for (int k = 0; k < kWinRows; ++k) {
-            const float t0 = (float)(tmp[k] & 0xFFu);
-            const float dx = (float)((tmp[k] >> 8) & 0xFFu) - t0;
-            win[k * kPitch + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, dx));
+            for (int k = 0; k < kLoads; ++k) {
+                float t0, t1, x0, x1;  // bytes {I(x,gy), I(x,gy+1), I(x+1,gy), I(x+1,gy+1)}
+                asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t0) : "v"(tmp[k]));
+                asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t1) : "v"(tmp[k]));
+                asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(x0) : "v"(tmp[k]));
+                asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(x1) : "v"(tmp[k]));
+                win[(2 * k) * kPitch + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, x0 - t0));
+                if (2 * k + 1 < kWinRows) {
+                    win[(2 * k + 1) * kPitch + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t1, x1 - t1));
+                }
+            }
+        } else {
+            uint32_t tmp[kWinRows];
+#pragma unroll
+            for (int k = 0; k < kWinRows; ++k) {
+                const int gy = min(max(wy0 + k, -1), fa.H - 1);  // wave-uniform
+                tmp[k] = quad_fetch(srcq, (unsigned)(gy + 1) * rpitch + ((unsigned)col << kRowEntryShift));
+            }
+#pragma unroll
+            for (int k = 0; k < kWinRows; ++k) {
+                const float t0 = (float)(tmp[k] & 0xFFu);
+                const float dx = (float)((tmp[k] >> 8) & 0xFFu) - t0;
+                win[k * kPitch + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, dx));
+            }
         }
     } else {
         // the pair of texel row gy is the first half of float quad (., gy); the row below the image (gy == H, a copy
