@@ -1056,6 +1056,8 @@ constexpr int kSubStep = 5;
 
 // Nine warped samples in lock step (same stages as quad_row_issue), reduced in the reference's order.
 // ref_rows[i] packs the three reference texels of x offset i (y offset j in byte j).
+// kRecip: kRecipExact (every denominator in the fast range) or kRecipIeee (any denominator; same bits where both are valid).
+template <int kRecip = kRecipExact>
 __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_quad_ptr srcq, unsigned qpitch, int wm1, int hm1,
                                                     int cx, int cy, const uint32_t (&ref_rows)[kSubN], float mean_r, float var_r)
 {
@@ -1076,19 +1078,26 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
         }
     }
     APD_STAGE();
+    if constexpr (kRecip == kRecipExact) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        r[k] = __builtin_amdgcn_rcpf(z[k]);
-    }
-    APD_STAGE();
+        for (int k = 0; k < N; ++k) {
+            r[k] = __builtin_amdgcn_rcpf(z[k]);
+        }
+        APD_STAGE();
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        z[k] = fmaf(-z[k], r[k], 1.0f);
-    }
-    APD_STAGE();
+        for (int k = 0; k < N; ++k) {
+            z[k] = fmaf(-z[k], r[k], 1.0f);
+        }
+        APD_STAGE();
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        r[k] = fmaf(z[k], r[k], r[k]);
+        for (int k = 0; k < N; ++k) {
+            r[k] = fmaf(z[k], r[k], r[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            r[k] = 1.0f / z[k];
+        }
     }
     APD_STAGE();
 #pragma unroll
@@ -1167,6 +1176,7 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
 }
 
 // The same sub-patch on a float texel-quad image (float grey values); ref[i * 3 + j] is read with stride `ref_stride` floats.
+template <int kRecip = kRecipExact>
 __device__ __forceinline__ float subpatch_cost_fquad(const Homography &H, global_fquad_ptr fq, unsigned fpitch, int wm1, int hm1,
                                                      int cx, int cy, const float *ref, int ref_stride, float mean_r, float var_r)
 {
@@ -1187,19 +1197,26 @@ __device__ __forceinline__ float subpatch_cost_fquad(const Homography &H, global
         }
     }
     APD_STAGE();
+    if constexpr (kRecip == kRecipExact) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        r[k] = __builtin_amdgcn_rcpf(z[k]);
-    }
-    APD_STAGE();
+        for (int k = 0; k < N; ++k) {
+            r[k] = __builtin_amdgcn_rcpf(z[k]);
+        }
+        APD_STAGE();
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        z[k] = fmaf(-z[k], r[k], 1.0f);
-    }
-    APD_STAGE();
+        for (int k = 0; k < N; ++k) {
+            z[k] = fmaf(-z[k], r[k], 1.0f);
+        }
+        APD_STAGE();
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        r[k] = fmaf(z[k], r[k], r[k]);
+        for (int k = 0; k < N; ++k) {
+            r[k] = fmaf(z[k], r[k], r[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            r[k] = 1.0f / z[k];
+        }
     }
     APD_STAGE();
 #pragma unroll

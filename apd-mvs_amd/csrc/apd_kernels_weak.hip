@@ -579,16 +579,25 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
             continue;
         }
         float c;
-        if (denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep))) {
+        // one nine-sample body per wave and sub-patch: the IEEE division gives the bits of the fast reciprocal wherever that
+        // one is valid, so if one lane needs it (a sign change or an extreme denominator under a random normal) all take it
+        const bool fast = denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep));
+        if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
             if constexpr (kQuad) {
                 const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-                c = subpatch_cost_quad(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+                c = subpatch_cost_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
             } else {
-                c = subpatch_cost_fquad(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
-                                        lds.var[k][lane]);
+                c = subpatch_cost_fquad<kRecipExact>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
+                                                     lds.var[k][lane]);
             }
         } else {
-            c = patch_cost_generic(fa, vc, H, nbx, nby, 5, 5);
+            if constexpr (kQuad) {
+                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
+                c = subpatch_cost_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+            } else {
+                c = subpatch_cost_fquad<kRecipIeee>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
+                                                    lds.var[k][lane]);
+            }
         }
         strong_cost += c;
         strong_count++;
@@ -636,12 +645,12 @@ template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, const int *__restrict__ count)
 {
     __shared__ WeakLdsT<kQuad> lds;
-    // The kernel is bound by the L1/L2 traffic of its scattered sub-patch gathers, not by latency: with six waves per
-    // CU instead of the eight the registers allow, the waves evict each other's lines less (ms per launch at 4096x3072,
-    // 18 % WEAK: 8 waves 38.9, 7: 37.4, 6: 36.8, 5: 38.0, 4: 39.9, 3: 48.8).  Unused LDS is what caps the count: 14.6 + 10
-    // KiB per wave in texel-quad mode; the float mode's 24.8 KiB already give six.
+    // Round 1 (4-byte quads): bound by the L1/L2 traffic of the scattered sub-patch gathers, and six waves per CU evicted each
+    // other's lines less than the eight the registers allow, so an LDS pad capped the count (ms per launch at 4096x3072,
+    // 18 % WEAK: 8 waves 38.9, 7: 37.4, 6: 36.8, 5: 38.0, 4: 39.9, 3: 48.8).  With the 2-byte column-pair copy (half the
+    // footprint, L2 hit rate 56 -> 70 %) the kernel is latency-bound instead and the pad is gone (configs[2]: 76.9 -> 71.6 ms).
 #ifndef APD_K910_LDS_PAD_KB
-#define APD_K910_LDS_PAD_KB 10
+#define APD_K910_LDS_PAD_KB 0  // round 2: with the 2-byte column-pair source copy eight waves per CU no longer thrash (76.9 -> 71.6 ms)
 #endif
     constexpr int kPadBytes = kQuad ? APD_K910_LDS_PAD_KB * 1024 : 0;
     if constexpr (kPadBytes > 0) {
