@@ -1,13 +1,17 @@
-// jpeg_gray.cpp -- dependency-free baseline JPEG decoder that returns the LUMA plane as 8-bit grey.
+// jpeg_gray.cpp -- dependency-free JPEG decoder of the drop-in host: the LUMA plane as 8-bit grey (DecodeJpegGray) or
+// interleaved BGR (DecodeJpegBGR), byte for byte what libjpeg -- i.e. cv::imread -- returns.
 //
 // The reference reads `images/%08d.jpg` with cv::imread(IMREAD_GRAYSCALE) (APD.cpp:410-427), i.e.
 // libjpeg decoding straight to one channel: the Y component of a YCbCr file, no RGB round trip
-// (SURVEY.md Appendix E).  Neither OpenCV nor libjpeg headers exist in this image, so this file
-// restates the published algorithm: ITU-T T.81 baseline sequential Huffman decoding + the
-// "islow" accurate integer inverse DCT (Loeffler-Ligtenberg-Moschytz, 13-bit constants) that libjpeg
-// uses by default.  Chroma blocks are entropy-decoded (to keep the bit stream in step) and dropped.
-// Supported: SOF0/SOF1 8-bit, 1 or 3 components, any sampling factors, restart intervals.
-// Not supported (returns false): progressive (SOF2), arithmetic coding, 12-bit.
+// (SURVEY.md Appendix E), and with IMREAD_COLOR for the fusion's point colours (APD.cpp:859).  Neither OpenCV nor libjpeg
+// headers exist in this image, so this file restates the published algorithms: ITU-T T.81 Huffman decoding, sequential
+// (Annex F) and progressive (Annex G: spectral selection + successive approximation), the "islow" accurate integer inverse
+// DCT (Loeffler-Ligtenberg-Moschytz, 13-bit constants) that libjpeg uses by default, its fancy chroma upsampling and its
+// fixed-point YCbCr -> RGB conversion.  For grey output the chroma blocks of a sequential file are entropy-decoded (to keep
+// the bit stream in step) and dropped.
+// Supported: SOF0/SOF1/SOF2 8-bit, 1 or 3 components, sampling factors 1..4, restart intervals.
+// Not supported (returns false): arithmetic coding, lossless / hierarchical frames, 12-bit samples.
+// Every table index that comes from the file is bounds-checked; tests/test_host_io.py fuzzes the decoder under ASan + UBSan.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -338,9 +342,58 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
     int ncomp = 0, restart_interval = 0;
     int hmax = 1, vmax = 1;
     bool have_sof = false;
+    bool progressive = false;  // SOF2: coefficients are collected over several scans, the IDCT runs after the last one
+    std::vector<int16_t> coefs[4];          // progressive only: [block][64] in natural order, blocks_w x blocks_h per component
+    int blocks_w[4] = {0, 0, 0, 0}, blocks_h[4] = {0, 0, 0, 0};
+    uint16_t latched_qt[4][64];             // quantisation table of a component as of its first scan (jdinput.c latch_quant_tables)
+    bool qt_latched[4] = {false, false, false, false};
     bool scanned[4] = {false, false, false, false};
     int plane_w[4] = {0, 0, 0, 0}, plane_h[4] = {0, 0, 0, 0};
     static thread_local std::vector<uint8_t> planes[4];
+    // grey or BGR pixels from the decoded component planes (shared by the sequential and the progressive path)
+    const int yc = 0;  // component 0 is Y by JFIF convention
+    auto finish = [&]() -> bool {
+        if (!want_colour || ncomp == 1) {
+            const int ch = want_colour ? 3 : 1;
+            pixels.resize((size_t)width * height * ch);
+            for (int y = 0; y < height; ++y) {
+                const uint8_t *src = &planes[yc][(size_t)y * plane_w[yc]];
+                if (ch == 1) {
+                    memcpy(&pixels[(size_t)y * width], src, (size_t)width);
+                } else {
+                    for (int x = 0; x < width; ++x) {  // grey file read as colour: B = G = R = Y
+                        pixels[((size_t)y * width + x) * 3 + 0] = pixels[((size_t)y * width + x) * 3 + 1] =
+                            pixels[((size_t)y * width + x) * 3 + 2] = src[x];
+                    }
+                }
+            }
+            return true;
+        }
+        // YCbCr -> BGR: upsample the chroma planes (jdsample.c), then libjpeg's 16-bit fixed-point conversion
+        // (jdcolor.c: build_ycc_rgb_table / ycc_rgb_convert), stored blue first like cv::imread(IMREAD_COLOR)
+        std::vector<uint8_t> full[3];
+        for (int c = 0; c < 3; ++c) {
+            if (hmax % comp[c].h != 0 || vmax % comp[c].v != 0) {
+                return false;  // fractional sampling ratios: not built
+            }
+            const int cw = (width * comp[c].h + hmax - 1) / hmax, chh = (height * comp[c].v + vmax - 1) / vmax;
+            upsample_component(planes[c], plane_w[c], cw, chh, hmax / comp[c].h, vmax / comp[c].v, width, height, full[c]);
+        }
+        pixels.resize((size_t)width * height * 3);
+        const int kScale = 16, kHalf = 1 << 15;
+        const int f_1_40200 = (int)(1.40200 * 65536 + 0.5), f_1_77200 = (int)(1.77200 * 65536 + 0.5);
+        const int f_0_71414 = (int)(0.71414 * 65536 + 0.5), f_0_34414 = (int)(0.34414 * 65536 + 0.5);
+        for (size_t i = 0; i < (size_t)width * height; ++i) {
+            const int y = full[0][i], cb = full[1][i] - 128, cr = full[2][i] - 128;
+            const int r = y + ((f_1_40200 * cr + kHalf) >> kScale);
+            const int g = y + (((-f_0_34414) * cb + kHalf + (-f_0_71414) * cr) >> kScale);
+            const int b = y + ((f_1_77200 * cb + kHalf) >> kScale);
+            pixels[3 * i + 0] = clamp_u8(b);
+            pixels[3 * i + 1] = clamp_u8(g);
+            pixels[3 * i + 2] = clamp_u8(r);
+        }
+        return true;
+    };
     size_t pos = 2;
     while (pos + 4 <= size) {
         if (data[pos] != 0xFF) {
@@ -397,7 +450,8 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
                 }
                 i += 17 + n;
             }
-        } else if (marker == 0xC0 || marker == 0xC1) {  // SOF0 / SOF1
+        } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {  // SOF0 / SOF1 (sequential), SOF2 (progressive)
+            progressive = marker == 0xC2;
             if (seglen < 6 || seg[0] != 8) {
                 return false;
             }
@@ -420,8 +474,8 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
                 vmax = comp[c].v > vmax ? comp[c].v : vmax;
             }
             have_sof = true;
-        } else if (marker >= 0xC2 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) {
-            return false;  // progressive / lossless / arithmetic: not built
+        } else if (marker >= 0xC3 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) {
+            return false;  // lossless / hierarchical / arithmetic coding: not built
         } else if (marker == 0xDD) {  // DRI
             if (seglen < 2) {
                 return false;
@@ -457,7 +511,6 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
             // component planes padded to whole MCUs (grey output decodes the luma plane only)
             const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
             const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
-            const int yc = 0;  // component 0 is Y by JFIF convention
             for (int c = 0; c < ncomp; ++c) {
                 plane_w[c] = mcus_x * comp[c].h * 8;
                 plane_h[c] = mcus_y * comp[c].v * 8;
@@ -468,6 +521,178 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
             BitReader br{data + pos, data + size};
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].dc_pred = 0;
+            }
+            if (progressive) {
+                // T.81 Annex G: one scan = one spectral band [Ss, Se] at one successive-approximation step (Ah -> Al) of the
+                // listed components; DC scans may interleave components, AC scans carry exactly one.
+                const int Ss = seg[1 + 2 * ns], Se = seg[2 + 2 * ns], Ah = seg[3 + 2 * ns] >> 4, Al = seg[3 + 2 * ns] & 15;
+                if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1)) {
+                    return false;
+                }
+                for (int c = 0; c < ncomp; ++c) {
+                    blocks_w[c] = mcus_x * comp[c].h;
+                    blocks_h[c] = mcus_y * comp[c].v;
+                    if (coefs[c].empty()) {
+                        coefs[c].assign((size_t)blocks_w[c] * blocks_h[c] * 64, 0);
+                    }
+                }
+                for (int s2 = 0; s2 < ns; ++s2) {
+                    const int c = scan_comp[s2];
+                    if (!qt_latched[c]) {
+                        if (!qt_present[comp[c].tq]) {
+                            return false;
+                        }
+                        memcpy(latched_qt[c], qt[comp[c].tq], sizeof(latched_qt[c]));
+                        qt_latched[c] = true;
+                    }
+                    if ((Ss == 0 && Ah == 0 && !dc[comp[c].td].present) || (Ss > 0 && !ac[comp[c].ta].present)) {
+                        return false;
+                    }
+                }
+                const bool interleaved_scan = ns > 1;
+                int units_x, units_y;
+                if (interleaved_scan) {
+                    units_x = mcus_x;
+                    units_y = mcus_y;
+                } else {  // a one-component scan walks the component's own blocks: only those that hold image samples
+                    const Component &cc = comp[scan_comp[0]];
+                    units_x = ((width * cc.h + hmax - 1) / hmax + 7) / 8;
+                    units_y = ((height * cc.v + vmax - 1) / vmax + 7) / 8;
+                }
+                int eobrun = 0;
+                const int p1 = 1 << Al, m1 = -(1 << Al);
+                const long total_units = (long)units_x * units_y;
+                for (long u = 0; u < total_units; ++u) {
+                    if (restart_interval && u > 0 && (u % restart_interval) == 0) {
+                        br.reset();
+                        const uint8_t *q = br.p;
+                        while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) {
+                            ++q;
+                        }
+                        if (q + 1 >= br.end) {
+                            return false;
+                        }
+                        br.p = q + 2;
+                        for (int c = 0; c < ncomp; ++c) {
+                            comp[c].dc_pred = 0;
+                        }
+                        eobrun = 0;
+                    }
+                    for (int s2 = 0; s2 < ns; ++s2) {
+                        Component &cc = comp[scan_comp[s2]];
+                        const int c = scan_comp[s2];
+                        const int nbh = interleaved_scan ? cc.h : 1, nbv = interleaved_scan ? cc.v : 1;
+                        for (int by = 0; by < nbv; ++by) {
+                            for (int bx = 0; bx < nbh; ++bx) {
+                                const long col = interleaved_scan ? (u % units_x) * cc.h + bx : (u % units_x);
+                                const long row = interleaved_scan ? (u / units_x) * cc.v + by : (u / units_x);
+                                if (col >= blocks_w[c] || row >= blocks_h[c]) {
+                                    return false;
+                                }
+                                int16_t *blk = &coefs[c][((size_t)row * blocks_w[c] + col) * 64];
+                                if (Ss == 0) {
+                                    if (Ah == 0) {  // DC first scan (G.1.2.1)
+                                        const int t = decode_symbol(br, dc[cc.td]);
+                                        if (t < 0 || t > 15) {
+                                            return false;
+                                        }
+                                        cc.dc_pred += extend(br.get_bits(t), t);
+                                        blk[0] = (int16_t)(cc.dc_pred * (1 << Al));
+                                    } else if (br.get_bit()) {  // DC refinement: one more bit
+                                        blk[0] = (int16_t)(blk[0] | p1);
+                                    }
+                                    continue;
+                                }
+                                const HuffTable &tab = ac[cc.ta];
+                                if (Ah == 0) {  // AC first scan (G.1.2.2)
+                                    if (eobrun > 0) {
+                                        --eobrun;
+                                        continue;
+                                    }
+                                    for (int k = Ss; k <= Se; ++k) {
+                                        const int rs = decode_symbol(br, tab);
+                                        if (rs < 0) {
+                                            return false;
+                                        }
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz == 0) {
+                                            if (r == 15) {
+                                                k += 15;
+                                                continue;
+                                            }
+                                            eobrun = (1 << r) - 1;
+                                            if (r) {
+                                                eobrun += br.get_bits(r);
+                                            }
+                                            break;
+                                        }
+                                        k += r;
+                                        if (k > Se) {
+                                            return false;
+                                        }
+                                        blk[kZigZag[k]] = (int16_t)(extend(br.get_bits(sz), sz) * (1 << Al));
+                                    }
+                                    continue;
+                                }
+                                // AC refinement scan (G.1.2.3), the control flow of libjpeg's decode_mcu_AC_refine
+                                int k = Ss;
+                                if (eobrun == 0) {
+                                    for (; k <= Se; ++k) {
+                                        const int rs = decode_symbol(br, tab);
+                                        if (rs < 0) {
+                                            return false;
+                                        }
+                                        int r = rs >> 4, sval = rs & 15;
+                                        if (sval) {
+                                            if (sval != 1) {
+                                                return false;
+                                            }
+                                            sval = br.get_bit() ? p1 : m1;
+                                        } else if (r != 15) {
+                                            eobrun = 1 << r;
+                                            if (r) {
+                                                eobrun += br.get_bits(r);
+                                            }
+                                            break;
+                                        }
+                                        do {  // pass the already non-zero coefficients (one correction bit each) and r zero ones
+                                            int16_t &cf = blk[kZigZag[k]];
+                                            if (cf != 0) {
+                                                if (br.get_bit() && (cf & p1) == 0) {
+                                                    cf = (int16_t)(cf >= 0 ? cf + p1 : cf + m1);
+                                                }
+                                            } else if (--r < 0) {
+                                                break;
+                                            }
+                                            ++k;
+                                        } while (k <= Se);
+                                        if (sval && k <= Se) {
+                                            blk[kZigZag[k]] = (int16_t)sval;
+                                        }
+                                    }
+                                }
+                                if (eobrun > 0) {
+                                    for (; k <= Se; ++k) {
+                                        int16_t &cf = blk[kZigZag[k]];
+                                        if (cf != 0 && br.get_bit() && (cf & p1) == 0) {
+                                            cf = (int16_t)(cf >= 0 ? cf + p1 : cf + m1);
+                                        }
+                                    }
+                                    --eobrun;
+                                }
+                            }
+                        }
+                    }
+                }
+                const uint8_t *q = br.p;
+                while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0x00 && !(q[1] >= 0xD0 && q[1] <= 0xD7))) {
+                    ++q;
+                }
+                pos = (size_t)(q - data);
+                for (int s2 = 0; s2 < ns; ++s2) {
+                    scanned[scan_comp[s2]] = true;
+                }
+                continue;  // more scans follow; the planes are produced after the last one
             }
             int restart_count = 0;
             const bool interleaved = ns > 1;
@@ -568,48 +793,31 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
             if (!done) {
                 continue;
             }
-            if (!want_colour || ncomp == 1) {
-                const int ch = want_colour ? 3 : 1;
-                pixels.resize((size_t)width * height * ch);
-                for (int y = 0; y < height; ++y) {
-                    const uint8_t *src = &planes[yc][(size_t)y * plane_w[yc]];
-                    if (ch == 1) {
-                        memcpy(&pixels[(size_t)y * width], src, (size_t)width);
-                    } else {
-                        for (int x = 0; x < width; ++x) {  // grey file read as colour: B = G = R = Y
-                            pixels[((size_t)y * width + x) * 3 + 0] = pixels[((size_t)y * width + x) * 3 + 1] =
-                                pixels[((size_t)y * width + x) * 3 + 2] = src[x];
-                        }
-                    }
-                }
-                return true;
-            }
-            // YCbCr -> BGR: upsample the chroma planes (jdsample.c), then libjpeg's 16-bit fixed-point conversion
-            // (jdcolor.c: build_ycc_rgb_table / ycc_rgb_convert), stored blue first like cv::imread(IMREAD_COLOR)
-            std::vector<uint8_t> full[3];
-            for (int c = 0; c < 3; ++c) {
-                if (hmax % comp[c].h != 0 || vmax % comp[c].v != 0) {
-                    return false;  // fractional sampling ratios: not built
-                }
-                const int cw = (width * comp[c].h + hmax - 1) / hmax, chh = (height * comp[c].v + vmax - 1) / vmax;
-                upsample_component(planes[c], plane_w[c], cw, chh, hmax / comp[c].h, vmax / comp[c].v, width, height, full[c]);
-            }
-            pixels.resize((size_t)width * height * 3);
-            const int kScale = 16, kHalf = 1 << 15;
-            const int f_1_40200 = (int)(1.40200 * 65536 + 0.5), f_1_77200 = (int)(1.77200 * 65536 + 0.5);
-            const int f_0_71414 = (int)(0.71414 * 65536 + 0.5), f_0_34414 = (int)(0.34414 * 65536 + 0.5);
-            for (size_t i = 0; i < (size_t)width * height; ++i) {
-                const int y = full[0][i], cb = full[1][i] - 128, cr = full[2][i] - 128;
-                const int r = y + ((f_1_40200 * cr + kHalf) >> kScale);
-                const int g = y + (((-f_0_34414) * cb + kHalf + (-f_0_71414) * cr) >> kScale);
-                const int b = y + ((f_1_77200 * cb + kHalf) >> kScale);
-                pixels[3 * i + 0] = clamp_u8(b);
-                pixels[3 * i + 1] = clamp_u8(g);
-                pixels[3 * i + 2] = clamp_u8(r);
-            }
-            return true;
+            return finish();
         }
         pos += len;
+    }
+    if (progressive && have_sof && scanned[yc]) {
+        // all scans read (EOI, or the end of a truncated file: libjpeg shows what it has as well): dequantise + IDCT
+        for (int c = 0; c < ncomp; ++c) {
+            if (!(c == yc || want_colour)) {
+                continue;
+            }
+            if (!scanned[c] || !qt_latched[c] || coefs[c].empty()) {
+                return false;
+            }
+            int block[64];
+            for (int by = 0; by < blocks_h[c]; ++by) {
+                for (int bx = 0; bx < blocks_w[c]; ++bx) {
+                    const int16_t *blk = &coefs[c][((size_t)by * blocks_w[c] + bx) * 64];
+                    for (int k = 0; k < 64; ++k) {
+                        block[k] = blk[k] * latched_qt[c][k];
+                    }
+                    idct_islow(block, &planes[c][(size_t)by * 8 * plane_w[c] + (size_t)bx * 8], plane_w[c]);
+                }
+            }
+        }
+        return finish();
     }
     return false;
 }

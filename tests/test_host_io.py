@@ -119,12 +119,53 @@ def test_baseline_jpeg_luma_matches_libjpeg(host, tmp_path, mode, subsampling, s
     assert np.array_equal(out, ref)
 
 
-def test_progressive_jpeg_is_refused_not_misdecoded(host, tmp_path):
-    PIL = pytest.importorskip("PIL.Image")
-    im = PIL.fromarray((np.random.RandomState(0).rand(32, 32) * 255).astype(np.uint8), "L")
-    im.save(tmp_path / "00000004.jpg", progressive=True)
-    rc, _, _ = _read_image(host, tmp_path / "00000004", (32, 32))
-    assert rc != 0
+@pytest.mark.parametrize("mode,subsampling,size,quality", [("L", 0, (64, 48), 90), ("L", 0, (37, 53), 60), ("RGB", 0, (61, 45), 92),
+                                                           ("RGB", 2, (70, 50), 85), ("RGB", 1, (33, 17), 75), ("RGB", 2, (129, 130), 40)])
+def test_progressive_jpeg_matches_libjpeg(host, tmp_path, mode, subsampling, size, quality):
+    """cv::imread decodes progressive files (SOF2) like any other; so does the drop-in's decoder since round 2: spectral
+    selection + successive approximation (T.81 Annex G: DC / AC first and refinement scans, EOB runs), then the same islow IDCT,
+    chroma upsampling and colour conversion as for baseline files.  PIL's libjpeg is the golden decoder, grey and colour."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(size[0] * 7 + size[1] + quality)
+    w, h = size
+    base = rng.rand(h // 4 + 2, w // 4 + 2, 3)
+    img = np.kron(base, np.ones((4, 4, 1)))[:h, :w] * 255
+    img += rng.rand(h, w, 3) * 30
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    path = tmp_path / "00000004.jpg"
+    kw = {} if mode == "L" else {"subsampling": subsampling}
+    Image.fromarray(img if mode == "RGB" else img[..., 0], mode).save(path, quality=quality, progressive=True, **kw)
+    assert b"\xff\xc2" in path.read_bytes()[:1000]  # really a progressive file
+    ref = Image.open(path)
+    ref.draft("L", ref.size)
+    ref = np.asarray(ref.convert("L") if ref.mode != "L" else ref, np.float32)
+    rc, shp, out = _read_image(host, tmp_path / "00000004", (h, w))
+    assert rc == 0 and shp == (h, w)
+    assert np.array_equal(out, ref), int((out != ref).sum())
+    ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
+    host.apdhost_read_color_image.argtypes = [C.c_char_p, ip, ip, fp, C.c_size_t]
+    refc = np.asarray(Image.open(path).convert("RGB"))[..., ::-1].astype(np.float32)
+    r, c = C.c_int(), C.c_int()
+    outc = np.zeros((h, w, 3), np.float32)
+    assert host.apdhost_read_color_image(str(tmp_path / "00000004").encode(), C.byref(r), C.byref(c), outc.ctypes.data_as(fp), outc.size) == 0
+    assert np.array_equal(outc, refc), int((outc != refc).sum())
+
+
+def test_progressive_jpeg_with_restart_markers(host, tmp_path):
+    """Progressive + restart intervals (EOB runs and DC predictions reset at every RSTn)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(12)
+    img = (np.kron(rng.rand(20, 28, 3), np.ones((4, 4, 1))) * 255).astype(np.uint8)
+    path = tmp_path / "00000006.jpg"
+    try:
+        Image.fromarray(img, "RGB").save(path, quality=80, progressive=True, subsampling=2, restart_marker_blocks=3)
+    except TypeError:
+        pytest.skip("this PIL cannot write restart markers")
+    ref = Image.open(path)
+    ref.draft("L", ref.size)
+    ref = np.asarray(ref.convert("L") if ref.mode != "L" else ref, np.float32)
+    rc, shp, out = _read_image(host, tmp_path / "00000006", img.shape[:2])
+    assert rc == 0 and np.array_equal(out, ref)
 
 
 def test_resize_linear_power_of_two_is_centre_box(host):
@@ -230,7 +271,8 @@ def test_malformed_jpegs_never_leave_their_buffers(tmp_path):
     rng = np.random.RandomState(5)
     seeds = []
     for k, (mode, sub, size, extra) in enumerate([("L", 0, (40, 30), {}), ("RGB", 2, (37, 29), {}), ("RGB", 1, (48, 16), {}),
-                                                   ("RGB", 0, (24, 24), {"optimize": True})]):
+                                                   ("RGB", 0, (24, 24), {"optimize": True}), ("RGB", 2, (40, 24), {"progressive": True}),
+                                                   ("L", 0, (33, 21), {"progressive": True})]):
         w, h = size
         img = (rng.rand(h, w, 3) * 255).astype(np.uint8)
         p = tmp_path / ("seed%d.jpg" % k)
