@@ -98,17 +98,21 @@ TOOLS_DIR = os.path.join(HERE, "..", "tools")
 
 
 def build_tools(force=False):
-    """tools/_build/valu_rates: issue-rate measurements and the exhaustive ISA checks of the arithmetic contract."""
-    src = os.path.join(TOOLS_DIR, "valu_rates.hip")
+    """tools/_build/: valu_rates (exhaustive ISA checks of the arithmetic contract), valu_issue (issue cost per VALU instruction
+    class, the basis of bench.py's roofline peak), unaligned_gather (cost of dword gathers at 2-byte alignment)."""
     out_dir = os.path.join(TOOLS_DIR, "_build")
-    out = os.path.join(out_dir, "valu_rates")
     os.makedirs(out_dir, exist_ok=True)
-    if force or _newer(out, [src]):
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", src, "-o", out],
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed on tools/valu_rates.hip:\n" + r.stdout)
-    return out
+    outs = []
+    for name, flags in (("valu_rates", ["-ffp-contract=off", "-fno-slp-vectorize"]), ("valu_issue", []), ("unaligned_gather", [])):
+        src = os.path.join(TOOLS_DIR, name + ".hip")
+        out = os.path.join(out_dir, name)
+        if force or _newer(out, [src]):
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17"] + flags + [src, "-o", out],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed on tools/%s.hip:\n%s" % (name, r.stdout))
+        outs.append(out)
+    return outs
 
 
 if __name__ == "__main__":
