@@ -240,8 +240,8 @@ int apd_create(apd_handle *out, int device, int width, int height, const apd_par
     if (!out || !params || width <= 0 || height <= 0) {
         return fail(APD_ERR_INVALID, "apd_create: bad argument");
     }
-    if (width > 16384 || height > 16384) {
-        return fail(APD_ERR_UNSUPPORTED, "apd_create: image larger than 16384 px per side");
+    if (width > 12000 || height > 16384) {  // the tiled copy divides the column by 7 with a multiply-shift that is exact below 13,000
+        return fail(APD_ERR_UNSUPPORTED, "apd_create: image larger than 12000 x 16384 px");
     }
     if (params->strong_radius != 5 || params->strong_increment != 2 || params->weak_radius != 5 || params->weak_increment != 5) {
         // the reference never changes these (main.h:84-87); the kernels are specialised for them
@@ -468,9 +468,9 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         const int tiled_mode = tm ? atoi(tm) : 1;
         c->have_tiled = tiled_mode == 2 || (tiled_mode == 1 && c->params.state == APD_FIRST_INIT);
         if (c->have_tiled) {
-            const size_t tn = apd::quad_tiled_entries(c->W, c->H);
+            const size_t tbytes = apd::quad_tiled_bytes(c->W, c->H);
             for (int i = 1; i < num_images; ++i) {
-                HIP_TRY(hipMalloc(&c->quads_tiled[i], tn * sizeof(apd::quad_t)));
+                HIP_TRY(hipMalloc(&c->quads_tiled[i], tbytes));
                 hipError_t e = apd::launch_pack_quads_tiled(c->images[i], c->W, c->H, c->quads_tiled[i], c->stream);
                 if (e != hipSuccess) {
                     return fail(APD_ERR_HIP, "k_pack_quads_tiled failed: %s", hipGetErrorString(e));

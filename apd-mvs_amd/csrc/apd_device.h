@@ -38,7 +38,7 @@ constexpr unsigned kQuadBytes = 1u << kQuadShift;
 // half the footprint (twice the pixels per 128-byte line, per L1, per L2).  Half of these gathers are not dword aligned,
 // which costs nothing on gfx950 (tools/unaligned_gather.hip: 18.67 vs 18.85 ms for 1.07e9 lines).  -DAPD_QUAD4 builds the
 // round-1 layout (4-byte entries {I(qx,qy), I(qx+1,qy), I(qx,qy+1), I(qx+1,qy+1)}, pitch W + 1) for A/B runs.
-// The tiled copy (quad_tiled_index) keeps 4-byte entries; both copies use the byte order of the row-major dword, so there
+// The tiled copy (quad_tiled_offset_tu) is laid out so that its dwords have the byte order of the row-major dword, so there
 // is one decode: kPair2: bytes {t00, t01, t10, t11}, else {t00, t10, t01, t11}.
 #ifndef APD_QUAD4
 constexpr bool kPair2 = true;
@@ -76,7 +76,7 @@ struct ViewConst {
     // scale 1): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], holds the four clamped taps
     // {I(qx,qy), I(qx+1,qy), I(qx,qy+1), I(qx+1,qy+1)} of one bilinear fetch (quad_t below).
     const quad_t *quad;  // (H+1)*(W+1) entries or nullptr
-    const quad_t *quad_tiled;  // the same entries in 8 x 4 tiles (quad_tiled_index) or nullptr
+    const quad_t *quad_tiled;  // the same texels in 128-byte tiles (quad_tiled_offset_tu) or nullptr
     // Float texel-quad image (every other input: float grey values, e.g. the resampled images of the coarse pyramid
     // levels, APD.cpp:474): entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1], holds the two texel pairs
     // {I(qx,qy), I(qx+1,qy) - I(qx,qy), I(qx,qy+1), I(qx+1,qy+1) - I(qx,qy+1)} with clamped coordinates (fquad_t below):
@@ -536,24 +536,35 @@ __device__ __forceinline__ int med3_i32(int x, int lo, int hi)
     return r;
 }
 
-// Second copy of the byte-quad image in tiles of 8 x 4 entries = one 128-byte line, for gathers that land anywhere in the
-// source image (first iteration of a FIRST_INIT pass: every lane warps its patch with another random plane).  An 11 x 11 px
-// warped patch touches ~8 tiles against ~14 lines of the row-major image (32 x 1 entries per line): L1 -> L2 requests per
-// gather 16.5 -> 9.7, first black launch of configs[1] 129 -> 94 ms (profiles/r02/tiled_vs_rowmajor.txt).  Rows are read
-// better from the row-major copy (window staging, the 3 x 3 stride-5 sub-patches of the weak sweep), which stays.
-// Entry (t, u) = (qx + 1, qy + 1) lives at ((u / 4) * tiles_x + t / 8) * 32 + (u % 4) * 8 + t % 8.  Same entries: same bits.
-__host__ __device__ __forceinline__ unsigned quad_tiles_x(int W) { return ((unsigned)(W + 1) + 7u) >> 3; }
-__host__ __device__ __forceinline__ size_t quad_tiled_entries(int W, int H)
+// Second, TILED copy of the 8-bit source images for gathers that land anywhere in the source image (K5 and the first iteration
+// of a FIRST_INIT pass: every lane warps its patch with another random plane).  One tile = one 128-byte line:
+//   kPair2 (default): 7 columns x 8 rows of 2-byte column pairs, each tile row padded with the first pair of the next tile
+//     (8 entries = 16 bytes per row), so that the dword at any entry still holds entries t and t + 1, i.e. the four taps;
+//     an 11 x 11 px warped patch touches ~5.5 tiles (row-major pairs: ~7 lines of 64 x 1 px; round 1's row-major 4-byte quads: ~14);
+//   APD_QUAD4: 8 x 4 four-byte quads (~7.9 tiles per patch; measured against the row-major quads in profiles/r02/tiled_vs_rowmajor.txt:
+//     L1 -> L2 requests per gather 16.5 -> 9.7, first black launch of configs[1] 129 -> 94 ms).
+// Rows are read better from the row-major copy (window staging, the 3 x 3 stride-5 sub-patches of the weak sweep), which stays.
+// Entry (t, u) = (qx + 1, qy + 1).  Same texels, same arithmetic: same bits.
+constexpr unsigned kTileCols = kPair2 ? 7u : 8u, kTileRows = kPair2 ? 8u : 4u;
+__host__ __device__ __forceinline__ unsigned quad_tiles_x(int W)
 {
-    return (size_t)quad_tiles_x(W) * 8u * ((((size_t)H + 1u) + 3u) & ~(size_t)3u);
+    return kPair2 ? ((unsigned)(W + 2) + kTileCols - 1u) / kTileCols : ((unsigned)(W + 1) + 7u) >> 3;
 }
-__host__ __device__ __forceinline__ unsigned quad_tiled_index(unsigned t, unsigned u, unsigned tiles_x)
+__host__ __device__ __forceinline__ unsigned quad_tiles_y(int H) { return ((unsigned)(H + 1) + kTileRows - 1u) / kTileRows; }
+__host__ __device__ __forceinline__ size_t quad_tiled_bytes(int W, int H) { return (size_t)quad_tiles_x(W) * quad_tiles_y(H) * 128u + 4u; }
+// byte offset of entry (t, u); t / 7 as a multiply-shift (exact for t < 13,000; images are at most 16,384 wide -> checked in apd_create)
+__host__ __device__ __forceinline__ unsigned quad_tiled_offset_tu(unsigned t, unsigned u, unsigned tiles_x)
 {
-    return (((u >> 2) * tiles_x + (t >> 3)) << 5) | ((u & 3u) << 3) | (t & 7u);
+    if (kPair2) {
+        const unsigned q = (t * 9363u) >> 16;  // t / 7
+        const unsigned r = t - 7u * q;
+        return (((u >> 3) * tiles_x + q) << 7) | ((u & 7u) << 4) | (r << 1);
+    }
+    return ((((u >> 2) * tiles_x + (t >> 3)) << 5) | ((u & 3u) << 3) | (t & 7u)) << 2;
 }
 __device__ __forceinline__ unsigned quad_tiled_byte_offset(int qx, int qy, unsigned tiles_x)
 {
-    return quad_tiled_index((unsigned)(qx + 1), (unsigned)(qy + 1), tiles_x) << kQuadShift;
+    return quad_tiled_offset_tu((unsigned)(qx + 1), (unsigned)(qy + 1), tiles_x);
 }
 
 // byte offset of quad entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1]: qy*pitch + (pitch + entry) + entry*qx with

@@ -721,18 +721,33 @@ __global__ __launch_bounds__(256) void k_pack_pairs(const float *__restrict__ im
     pairs[(size_t)u * (W + 2) + t] = (uint16_t)(top | (bot << 8));
 }
 
-// the byte quads again, in 8 x 4 tiles (quad_tiled_index); same entries as k_pack_quads writes
+// the tiled copy (apd_device.h: quad_tiled_offset_tu).  kPair2: one thread per (tile row, slot): slots 0..6 are the tile's own
+// columns, slot 7 repeats the first column of the next tile so that every dword of the tile holds two consecutive pairs
 __global__ __launch_bounds__(256) void k_pack_quads_tiled(const float *__restrict__ img, int W, int H, quad_t *__restrict__ quad)
 {
-    const int qx = blockIdx.x * 32 + (threadIdx.x & 31);  // 0..W  <-> image x = qx - 1
-    const int qy = blockIdx.y * 8 + (threadIdx.x >> 5);   // 0..H
-    if (qx > W || qy > H) {
+    if (kPair2) {
+        const unsigned tiles_x = quad_tiles_x(W), tiles_y = quad_tiles_y(H);
+        const unsigned gid = blockIdx.x * 256u + threadIdx.x;  // (tile, row in tile, slot)
+        const unsigned slot = gid & 7u, iy = (gid >> 3) & 7u, tile = gid >> 6;
+        if (tile >= tiles_x * tiles_y) {
+            return;
+        }
+        const unsigned ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int t = (int)(tx * 7u + slot), u = (int)(ty * 8u + iy);
+        const uint32_t top = (uint32_t)fetch_texel(img, W, H, t - 1, u - 1), bot = (uint32_t)fetch_texel(img, W, H, t - 1, u);
+        reinterpret_cast<uint16_t *>(quad)[(size_t)tile * 64u + iy * 8u + slot] = (uint16_t)(top | (bot << 8));
         return;
     }
-    const uint32_t t00 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy - 1), t10 = (uint32_t)fetch_texel(img, W, H, qx, qy - 1);
-    const uint32_t t01 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy), t11 = (uint32_t)fetch_texel(img, W, H, qx, qy);
-    quad[quad_tiled_index((unsigned)qx, (unsigned)qy, quad_tiles_x(W))] =
-        kPair2 ? (t00 | (t01 << 8) | (t10 << 16) | (t11 << 24)) : (t00 | (t10 << 8) | (t01 << 16) | (t11 << 24));  // one decode for both copies
+    const int qx = blockIdx.x * 256 + threadIdx.x;  // flat over (W + 1) x (H + 1) entries
+    const int n = (W + 1) * (H + 1);
+    if (qx >= n) {
+        return;
+    }
+    const int ex = qx % (W + 1), ey = qx / (W + 1);
+    const uint32_t t00 = (uint32_t)fetch_texel(img, W, H, ex - 1, ey - 1), t10 = (uint32_t)fetch_texel(img, W, H, ex, ey - 1);
+    const uint32_t t01 = (uint32_t)fetch_texel(img, W, H, ex - 1, ey), t11 = (uint32_t)fetch_texel(img, W, H, ex, ey);
+    *reinterpret_cast<quad_t *>(reinterpret_cast<char *>(quad) + quad_tiled_offset_tu((unsigned)ex, (unsigned)ey, quad_tiles_x(W))) =
+        t00 | (t10 << 8) | (t01 << 16) | (t11 << 24);
 }
 
 // float texel quads of a float image: entry (qx, qy), qx in [-1, W-1], qy in [-1, H-1] (clamped coordinates)
@@ -775,7 +790,8 @@ hipError_t launch_pack_quads_tiled(const float *img, int W, int H, quad_t *quad,
 #ifdef APD_QUAD_F16
     return hipErrorNotSupported;
 #else
-    hipLaunchKernelGGL(k_pack_quads_tiled, dim3((W + 1 + 31) / 32, (H + 1 + 7) / 8), dim3(256), 0, s, img, W, H, quad);
+    const size_t threads = kPair2 ? (size_t)quad_tiles_x(W) * quad_tiles_y(H) * 64u : (size_t)(W + 1) * (H + 1);
+    hipLaunchKernelGGL(k_pack_quads_tiled, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, img, W, H, quad);
     return hipGetLastError();
 #endif
 }
