@@ -394,7 +394,9 @@ hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStr
     const int tiles = ((fa.W + kTileW - 1) / kTileW) * ((fa.H + kTileH - 1) / kTileH);
     if (fa.use_quads) {
         const int mode = k67_tiled_mode();
-        const bool windows_off = fa.state == APD_FIRST_INIT && iter < APD_WIN_FROM_ITER;
+        const char *ti = getenv("APD_K67_TILED_ITERS");  // experiment knob: global gathers from the tiles in iterations < N of a FIRST_INIT pass
+        const int tiled_iters = ti ? atoi(ti) : APD_WIN_FROM_ITER;
+        const bool windows_off = fa.state == APD_FIRST_INIT && iter < tiled_iters;
         if (fa.have_tiled && (mode == 2 || (mode == 1 && windows_off))) {
             launch_k67w<true, true>(fa, tiles, colour, iter, s);
         } else {

@@ -4,7 +4,7 @@
 gfx950 issues the plain binary32 multiply / add / FMA (and v_mov, v_add_u32, v_and_b32) in ~2 cycles per wave64 instruction,
 transcendental instructions in ~8 and everything else in ~4 (tools/valu_issue.hip -> profiles/r02/valu_issue.csv).  A count of
 VALU instructions alone therefore says little about how busy the pipe is; this tool weights the static instruction mix of
-the three 36-sample bodies of k67w_update_strong<8, true, false> (LDS window, global fast reciprocal, global IEEE division)
+the three 36-sample bodies of k67w_update_strong<8, true, false, false> (LDS window, global fast reciprocal, global IEEE division)
 with the measured costs and writes profiles/r02/valu_mix_k67w.json, which bench.py uses for `roofline.valu_busy_estimate`.
 
 usage: tools/valu_mix.py [out.json]
@@ -45,7 +45,7 @@ def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02", "valu_mix_k67w.json")
     asm = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "apd-mvs_amd", "csrc", "apd_kernels_k67w.hip"),
                           "-o", "-"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
-    m = re.search(r"^_ZN3apd18k67w_update_strongILi8ELb1ELb0EEEvNS_9FrameArgsEii:(.*?)s_endpgm", asm, re.S | re.M)
+    m = re.search(r"^_ZN3apd18k67w_update_strongILi8ELb1ELb0ELb0EEEvNS_9FrameArgsEii:(.*?)s_endpgm", asm, re.S | re.M)
     assert m, "kernel not found in the ISA"
     blocks, cur = [], None
     for line in m.group(1).split("\n"):
@@ -82,7 +82,7 @@ def main():
                 "lds_reads": sum(v for k, v in b["ops"].items() if k.startswith("ds_read")),
                 "global_loads": sum(v for k, v in b["ops"].items() if k.startswith("global_load")),
                 "mix": dict(sorted(valu.items(), key=lambda kv: -kv[1]))}
-    res = {"kernel": "k67w_update_strong<8, true, false>", "class_cycles": {"fast": fast_c, "slow": slow_c, "transcendental": trans_c},
+    res = {"kernel": "k67w_update_strong<8, true, false, false>", "class_cycles": {"fast": fast_c, "slow": slow_c, "transcendental": trans_c},
            "source": "static ISA of the 36-sample bodies (first of the two copies: propagation phase), costs from profiles/r02/valu_issue.csv"}
     win = [b for b in blocks if b["ops"].get("ds_read2st64_b32", 0) >= 30]
     glob = [b for b in blocks if sum(v for k, v in b["ops"].items() if k.startswith("global_load")) >= 30]
