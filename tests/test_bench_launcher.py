@@ -41,3 +41,40 @@ def test_refuses_more_gpus_than_visible():
 def test_world_size_must_match_gpus():
     r = _run("--gpus", "1", "--selftest-cpu", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_committed_counter_profiles_give_roofline_fractions_below_one():
+    """bench.py's roofline = live launch time + the committed counter profile of the same command line.  With the launch times the
+    profiles themselves recorded, every fraction the line can print must be a fraction: VALU issue against the 2-cycle peak, the
+    mix-weighted busy estimate, memory-side bytes against 8 TB/s -- for every profile under profiles/, per launch and per dispatch."""
+    import glob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    mix = bench.load_valu_mix()
+    assert mix is not None and 2.0 <= mix["mean_cycles_per_inst"] <= 4.2
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02", "pmc_bench_*.json")))
+    assert len(paths) >= 3
+    seen_default = False
+    for path in paths:
+        rec = json.load(open(path))
+        cfg = rec["config"]
+        for name, k in rec["kernels"].items():
+            t = k["launch_ms"] * 1e-3
+            valu = k["valu_insts_per_launch"] / t / 1e9 / bench.VALU_PEAK_GINST
+            busy = k["valu_insts_per_launch"] * mix["mean_cycles_per_inst"] / (bench.NUM_SIMDS * bench.MAX_CLOCK_GHZ * 1e9 * t)
+            hbm = k["hbm_bytes_per_launch"] / t / 1e9 / bench.HBM_PEAK_GBPS
+            assert 0.05 < valu <= 1.0 and 0.0 < hbm <= 1.0, (path, name, valu, hbm)
+            if name == "k67":
+                assert busy <= 1.0, (path, busy)
+            pd = k["per_dispatch_timed"]
+            assert len(pd["SQ_INSTS_VALU"]) == 2 * cfg["steps"] == len(pd["duration_ns@trace"])
+            for insts, ns, fe in zip(pd["SQ_INSTS_VALU"], pd["duration_ns@sq"], pd["FETCH_SIZE"]):
+                assert insts / ns / bench.VALU_PEAK_GINST <= 1.0
+        if cfg["workload"] == "eth3d_office_fullres_8src" and cfg["steps"] == 6 and cfg["warmup"] == 1:
+            seen_default = True
+            got = bench.load_pmc_profile(cfg["workload"], 6, 1, "k67")
+            assert got is not None and got["source"].startswith("profiles/")
+    assert seen_default, "the default bench command line needs a committed profile"
+    assert bench.load_pmc_profile("eth3d_office_fullres_8src", 7, 1, "k67") is None  # never borrowed from another configuration
