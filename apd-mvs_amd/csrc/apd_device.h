@@ -17,19 +17,10 @@ namespace apd {
 // data model
 // ------------------------------------------------------------------------------------------------
 
-// One texel-quad entry = everything one bilinear fetch needs, gathered with one load.
-//   APD_QUAD_F16 (8 B): four binary16 values {t00, t10 - t00} {t01, t11 - t01}.  Integers up to 255 and their
-//     differences are exact in binary16 and v_fma_mix_f32 widens them inside the FMA, so the two horizontal
-//     lerps cost one instruction each (no byte -> float conversions, no subtractions).
-//   otherwise (4 B): the four taps as bytes {t00, t10, t01, t11}.
-// Both give bit-identical samples (same taps, same three fmaf as the float sampler).
-#ifdef APD_QUAD_F16
-typedef uint32_t quad_t __attribute__((ext_vector_type(2)));
-constexpr int kQuadShift = 3;
-#else
+// One fetched dword = the four byte taps of one bilinear fetch (layouts below); bit-identical to the float sampler (same taps,
+// same three fmaf).
 typedef uint32_t quad_t;
 constexpr int kQuadShift = 2;
-#endif
 constexpr unsigned kQuadBytes = 1u << kQuadShift;
 
 // Row-major copy of the 8-bit source images ("texel quads").  Default: 2-byte COLUMN PAIRS -- entry (t, u) = (qx + 1, qy + 1)
@@ -489,14 +480,6 @@ __device__ __forceinline__ float lerp_f16_pair(float a, uint32_t p)
     return r;
 }
 
-#ifdef APD_QUAD_F16
-__device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
-{
-    const float top = lerp_f16_pair(a, t.x);
-    const float bot = lerp_f16_pair(a, t.y);
-    return fmaf(b, bot - top, top);
-}
-#else
 __device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
 {
     float t00, t10, t01, t11;  // four v_cvt_f32_ubyte<k>; the differences below stay binary32 subtractions (see quad_row_lerp)
@@ -513,7 +496,6 @@ __device__ __forceinline__ float quad_lerp(quad_t t, float a, float b)
     const float bot = fmaf(a, t11 - t01, t01);
     return fmaf(b, bot - top, top);
 }
-#endif
 
 // Bilinear tap position for the texel-quad image, three VALU instructions per axis:
 //   weight  = v_fract_f32(s)        == s - floor(s) for every s >= 0; for s < 0 it can differ in the last bit
@@ -746,11 +728,7 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
         const uint32_t fake = (uint32_t)qx[j] * 2654435761u;
-#ifdef APD_QUAD_F16
-        t[j] = quad_t{fake & 0x3fff3fffu, (fake >> 1) & 0x3fff3fffu};
-#else
         t[j] = fake;
-#endif
     }
     return;
 #endif
@@ -765,13 +743,6 @@ __device__ __forceinline__ void quad_row_lerp(const quad_t (&t)[kPatchN], const 
                                               float (&v)[kPatchN])
 {
     float t00[kPatchN], t01[kPatchN];
-#ifdef APD_QUAD_F16
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        t00[j] = lerp_f16_pair(a[j], t[j].x);
-        t01[j] = lerp_f16_pair(a[j], t[j].y);
-    }
-#else
     // byte k -> float with v_cvt_f32_ubyte<k> (4 cycles), the two differences as binary32 subtractions (2 cycles): left to
     // itself the compiler subtracts the bytes as integers (SDWA) and converts the difference, two 4-cycle instructions each
     float d0[kPatchN], d1[kPatchN];
@@ -799,7 +770,6 @@ __device__ __forceinline__ void quad_row_lerp(const quad_t (&t)[kPatchN], const 
         t00[j] = fmaf(a[j], d0[j], t00[j]);
         t01[j] = fmaf(a[j], d1[j], t01[j]);
     }
-#endif
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {

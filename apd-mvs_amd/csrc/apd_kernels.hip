@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void k15_local_refine(FrameArgs fa)
     if (px >= fa.W || py >= fa.H) {
         return;
     }
-    const int W = fa.W, H = fa.H;
+    const int W = fa.W;
     const int center = px + py * W;
     const float4 origin = normal_world_to_cam(fa, fa.planes[center]);
     const float origin_depth = origin.w;
@@ -683,13 +683,7 @@ __global__ __launch_bounds__(256) void k_check_u8(const float *__restrict__ img,
     }
 }
 
-// bits of the binary16 value of an integer |v| <= 2048 (exact)
-__device__ __forceinline__ uint32_t f16_bits(float v)
-{
-    const _Float16 h = (_Float16)v;
-    return (uint32_t)__builtin_bit_cast(unsigned short, h);
-}
-
+// round 1's row-major 4-byte quads (-DAPD_QUAD4): entry (qx, qy) = {I(qx-1,qy-1), I(qx,qy-1), I(qx-1,qy), I(qx,qy)}, clamped
 __global__ __launch_bounds__(256) void k_pack_quads(const float *__restrict__ img, int W, int H, quad_t *__restrict__ quad)
 {
     const int qx = blockIdx.x * 32 + (threadIdx.x & 31);  // 0..W  <-> image x = qx - 1
@@ -697,15 +691,9 @@ __global__ __launch_bounds__(256) void k_pack_quads(const float *__restrict__ im
     if (qx > W || qy > H) {
         return;
     }
-#ifdef APD_QUAD_F16
-    const float t00 = fetch_texel(img, W, H, qx - 1, qy - 1), t10 = fetch_texel(img, W, H, qx, qy - 1);
-    const float t01 = fetch_texel(img, W, H, qx - 1, qy), t11 = fetch_texel(img, W, H, qx, qy);
-    quad[(size_t)qy * (W + 1) + qx] = quad_t{f16_bits(t00) | (f16_bits(t10 - t00) << 16), f16_bits(t01) | (f16_bits(t11 - t01) << 16)};
-#else
     const uint32_t t00 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy - 1), t10 = (uint32_t)fetch_texel(img, W, H, qx, qy - 1);
     const uint32_t t01 = (uint32_t)fetch_texel(img, W, H, qx - 1, qy), t11 = (uint32_t)fetch_texel(img, W, H, qx, qy);
     quad[(size_t)qy * (W + 1) + qx] = t00 | (t10 << 8) | (t01 << 16) | (t11 << 24);
-#endif
 }
 
 // 2-byte column pairs (the default row-major copy, apd_device.h): entry (t, u), t in [0, W + 1], u in [0, H], =
@@ -787,13 +775,9 @@ hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipSt
 
 hipError_t launch_pack_quads_tiled(const float *img, int W, int H, quad_t *quad, hipStream_t s)
 {
-#ifdef APD_QUAD_F16
-    return hipErrorNotSupported;
-#else
     const size_t threads = kPair2 ? (size_t)quad_tiles_x(W) * quad_tiles_y(H) * 64u : (size_t)(W + 1) * (H + 1);
     hipLaunchKernelGGL(k_pack_quads_tiled, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, img, W, H, quad);
     return hipGetLastError();
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -809,12 +793,8 @@ hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStr
 // window-vs-global parity test; same results).  Read at every launch: a getenv per 25 ms kernel is free.
 static bool k67_window_enabled()
 {
-#ifdef APD_QUAD_F16
-    return false;
-#else
     const char *e = getenv("APD_K67_WINDOW");
     return !(e && e[0] == '0');
-#endif
 }
 
 hipError_t launch_k14_windowed(const FrameArgs &fa, hipStream_t s);  // apd_kernels_k1415w.hip
@@ -823,12 +803,8 @@ hipError_t launch_k15_windowed(const FrameArgs &fa, hipStream_t s);
 // APD_K1415_WINDOW=0: K14/K15 without LDS source windows (same results)
 static bool k1415_window_enabled()
 {
-#ifdef APD_QUAD_F16
-    return false;
-#else
     const char *e = getenv("APD_K1415_WINDOW");
     return !(e && e[0] == '0');
-#endif
 }
 
 template <int NMAX>

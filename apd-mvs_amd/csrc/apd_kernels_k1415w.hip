@@ -12,7 +12,6 @@
 #include "apd_sweep.h"
 #include "apd_window.h"
 
-#ifndef APD_QUAD_F16
 
 namespace apd {
 
@@ -487,15 +486,7 @@ hipError_t launch_k15_windowed(const FrameArgs &fa, hipStream_t s)
 
 }  // namespace apd
 
-#else
 
-namespace apd {
-hipError_t launch_k14_windowed(const FrameArgs &, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_k15_windowed(const FrameArgs &, hipStream_t) { return hipErrorNotSupported; }
-}  // namespace apd
-
-#endif
-
-#if defined(APD_EXPERIMENT_WIN_STATS) && !defined(APD_QUAD_F16)
+#ifdef APD_EXPERIMENT_WIN_STATS
 APD_WIN_STATS_ACCESSOR(apd_debug_win_stats_k1415)
 #endif

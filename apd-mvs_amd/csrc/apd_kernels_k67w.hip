@@ -19,7 +19,6 @@
 #include "apd_sweep.h"
 #include "apd_window.h"
 
-#ifndef APD_QUAD_F16  // the window holds 4-byte entries
 
 namespace apd {
 
@@ -410,14 +409,7 @@ hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStr
 
 }  // namespace apd
 
-#else
 
-namespace apd {
-hipError_t launch_k67_windowed(const FrameArgs &, int, int, hipStream_t) { return hipErrorNotSupported; }
-}  // namespace apd
-
-#endif
-
-#if defined(APD_EXPERIMENT_WIN_STATS) && !defined(APD_QUAD_F16)
+#ifdef APD_EXPERIMENT_WIN_STATS
 APD_WIN_STATS_ACCESSOR(apd_debug_win_stats)
 #endif

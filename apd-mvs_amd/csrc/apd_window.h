@@ -4,7 +4,6 @@
 
 #include "apd_device.h"
 
-#ifndef APD_QUAD_F16  // the windows are staged from 4-byte quad entries
 
 namespace apd {
 
@@ -468,4 +467,3 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
 
 }  // namespace apd
 
-#endif  // APD_QUAD_F16

@@ -596,8 +596,8 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
                                         if (t < 0 || t > 15) {
                                             return false;
                                         }
-                                        cc.dc_pred += extend(br.get_bits(t), t);
-                                        blk[0] = (int16_t)(cc.dc_pred * (1 << Al));
+                                        cc.dc_pred = (int)((unsigned)cc.dc_pred + (unsigned)extend(br.get_bits(t), t));  // wraps instead of overflowing on hostile files
+                                        blk[0] = (int16_t)((unsigned)cc.dc_pred << Al);
                                     } else if (br.get_bit()) {  // DC refinement: one more bit
                                         blk[0] = (int16_t)(blk[0] | p1);
                                     }
@@ -734,8 +734,8 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
                             if (t < 0 || t > 11) {
                                 return false;
                             }
-                            cc.dc_pred += extend(br.get_bits(t), t);
-                            coef[0] = cc.dc_pred * qt[cc.tq][0];
+                            cc.dc_pred = (int)((unsigned)cc.dc_pred + (unsigned)extend(br.get_bits(t), t));  // wraps instead of overflowing on hostile files
+                            coef[0] = (int)((unsigned)cc.dc_pred * (unsigned)qt[cc.tq][0]);
                             for (int k = 1; k < 64;) {
                                 const int rs = decode_symbol(br, ac[cc.ta]);
                                 if (rs < 0) {
