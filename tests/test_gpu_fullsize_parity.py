@@ -53,7 +53,9 @@ def _weak_windows(weak, w=128, hh=80):
     cy, cx = np.unravel_index(int(np.argmax(run)), run.shape)
     cx = max(cx - int(run[cy, cx]) // 2, 0)
     wins = []
-    for (px, py) in ((cx, cy), (int(xs[0]), int(ys[0]))):
+    far = (xs > 400) | (ys > 300)  # not inside the fixed corner window
+    first = int(np.argmax(far)) if far.any() else 0
+    for (px, py) in ((cx, cy), (int(xs[first]), int(ys[first]))):
         x0, y0 = min(max(px - w // 2, 0), W - w), min(max(py - hh // 2, 0), H - hh)
         wins.append((x0, y0, x0 + w, y0 + hh))
     return wins
@@ -132,5 +134,57 @@ def test_configs4_synthetic_4096x3072_16src(gpu_pkg, ob, synth):
     n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(2, False), _fixed_windows(W, H, 192, 128), "configs[4]", log)
     print("\n".join(log))
     assert n == 14
+    h.close()
+    o.close()
+
+
+def test_configs2_geometric_apd_pass_fullres(gpu_pkg, ob, synth):
+    """The third pass kind at the full size of configs[2]: REFINE_ITER with the geometric-consistency term (depth maps of all
+    eleven views resident, APD.cu:760-772) and adaptive patch deformation, 10 source views, on the state a FIRST_INIT pass
+    leaves: K1..K5, one iteration of K6..K10, K11..K15."""
+    W, H, N = 6200, 4130, 10
+    sc, imgs = _scene(synth, W, H, N, textureless=0.2)
+    p0 = common.base_params(sc, N, max_iterations=2, seed=4321, weak_peak_radius=6)
+    h0 = common.make_handle(gpu_pkg, sc, imgs, N, p0)
+    h0.run()
+    planes, weak, views = h0.download()
+    h0.close()
+    prior = common.postprocess(planes, weak, views, p0["depth_min"], p0["depth_max"])
+    # depth maps "of the previous pass" for every view: the reference view's own estimate and smooth analytic maps with holes
+    deps = [np.ascontiguousarray(prior[0][..., 3])] + common.fake_depth_maps(W, H, N)
+    p = common.base_params(sc, N, max_iterations=1, seed=4322, state=2, use_APD=1, geom_consistency=1, weak_peak_radius=4,
+                           rotate_time=4, ransac_threshold=0.01 - 0.00125 * 3)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p, depths=deps, prior=prior)
+    o = common.make_oracle(ob, sc, imgs, N, p, depths=deps, prior=prior)
+    assert h.weak_count == o.weak_count > 0
+    windows = _fixed_windows(W, H, 128, 80)[:5] + _weak_windows(prior[2], 128, 96)
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(1, True), windows, "configs[2] geometric")
+    assert n == 15
+    h.close()
+    o.close()
+
+
+def test_float_images_at_a_pyramid_level_of_configs1(gpu_pkg, ob, synth):
+    """Level 1 of the configs[1] pyramid: 3100 x 2065, non-integer grey values (what cv::resize leaves, APD.cpp:474), i.e. the
+    float texel-quad path with binary32 LDS windows, through a REFINE_INIT + APD pass on a FIRST_INIT prior."""
+    W, H, N = 3100, 2065, 8
+    sc, imgs = _scene(synth, W, H, N, textureless=0.2)
+    imgs = [(im * np.float32(0.75) + np.float32(13.37)).astype(np.float32) for im in imgs]
+    p0 = common.base_params(sc, N, max_iterations=2, seed=99, weak_peak_radius=6)
+    h0 = common.make_handle(gpu_pkg, sc, imgs, N, p0)
+    o0 = common.make_oracle(ob, sc, imgs, N, p0)
+    wins = _fixed_windows(W, H, 160, 96)
+    n0 = common.fullsize_lockstep(gpu_pkg, h0, o0, _schedule(2, False), wins, "float level FIRST_INIT")
+    assert n0 == 14
+    planes, weak, views = h0.download()
+    h0.close()
+    o0.close()
+    prior = common.postprocess(planes, weak, views, p0["depth_min"], p0["depth_max"])
+    p = common.base_params(sc, N, max_iterations=1, seed=100, state=1, use_APD=1, weak_peak_radius=6, rotate_time=2, ransac_threshold=0.00875)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p, prior=prior)
+    o = common.make_oracle(ob, sc, imgs, N, p, prior=prior)
+    assert h.weak_count == o.weak_count > 0
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(1, True), wins[:5] + _weak_windows(prior[2], 128, 96), "float level APD")
+    assert n == 15
     h.close()
     o.close()
