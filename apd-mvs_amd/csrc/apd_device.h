@@ -622,7 +622,11 @@ __device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float 
 // ~5 (tools/valu_rates.hip), and only 2-3 waves fit a SIMD here, so the six samples of a patch row are
 // computed in lock step: every stage below is six independent instructions, and the scheduler is not
 // allowed to re-serialise the chains to save registers.
+#ifdef APD_NO_STAGE  // A/B: let the scheduler interleave the stages (measured slower: it re-serialises the chains to save registers)
+#define APD_STAGE() ((void)0)
+#else
 #define APD_STAGE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // byte offset of a 16-byte float quad entry (qx, qy): qy*pitch + (pitch + 16) + 16*qx with pitch = (W+1)*16 bytes
 __device__ __forceinline__ unsigned fquad_byte_offset(int qx, int qy, int pitch, int origin)
