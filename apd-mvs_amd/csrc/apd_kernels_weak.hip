@@ -636,6 +636,14 @@ __global__ __launch_bounds__(64) void k_compact_weak(FrameArgs fa, int colour, i
     }
 }
 
+// Plane of reliable neighbour h of a WEAK pixel (slot h + 1 of its neighbour table): re-read where it is needed -- the planes
+// of STRONG pixels do not change during a weak launch -- instead of eight float4 held in registers through the whole kernel.
+__device__ __forceinline__ float4 candidate_plane(const FrameArgs &fa, const short2 *nb, int h)
+{
+    const short2 q = nb[h + 1];
+    return fa.planes[q.x + q.y * fa.W];
+}
+
 // Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
 // plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
 #ifndef APD_K910_WAVES
@@ -689,7 +697,6 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
     }
     cost_array[0][0] = 2.0f;  // APD.cu:1345
     unsigned flags = 0;
-    float4 cand[8];
     ViewWeights<NMAX> vw;
     vw.clear();
     float weight_norm = 0.0f;
@@ -708,7 +715,6 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             continue;
         }
         flags |= 1u << h;
-        cand[h] = fa.planes[q.x + q.y * W];
     }
     // Costs of hypotheses 0..8.  View-major order: every hypothesis of a pixel projects a neighbour's sub-patch
     // to nearly the same place in one source image, so the nine evaluations per view reuse the lines the
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             if (h < 8 && !(flags & (1u << h))) {
                 continue;
             }
-            const float4 pl = (h < 8) ? cand[h] : plane_now;
+            const float4 pl = (h < 8) ? candidate_plane(fa, nb, h) : plane_now;
             cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
         }
     }
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                     if (vw.get(j) > 0) {
                         if (fa.geom_consistency) {
                             if (flags & (1u << i)) {
-                                f += (float)vw.get(j) * (cost_array[i][j] + fa.geom_factor * geom_cost(fa, fa.views[j], px, py, cand[i]));
+                                f += (float)vw.get(j) * (cost_array[i][j] + fa.geom_factor * geom_cost(fa, fa.views[j], px, py, candidate_plane(fa, nb, i)));
                             } else {
                                 f += (float)vw.get(j) * (cost_array[i][j] + fa.geom_factor * 3.0f);
                             }
@@ -785,10 +791,11 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             cost_committed = cost_now;
             depth_now = depth_from_plane(fa, plane_now, px, py);
             if (flags & (1u << best)) {
-                const float d = depth_from_plane(fa, cand[best], px, py);
+                const float4 cand_best = candidate_plane(fa, nb, best);
+                const float d = depth_from_plane(fa, cand_best, px, py);
                 if (d >= fa.depth_min && d <= fa.depth_max && final_costs[best] < cost_now) {
                     depth_now = d;
-                    plane_now = cand[best];
+                    plane_now = cand_best;
                     cost_now = final_costs[best];
                     fa.selected_views[center] = sel;
                 }
