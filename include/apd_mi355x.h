@@ -118,7 +118,9 @@ enum {
 void apd_default_params(apd_params *p);
 
 /* APD::APD(const Problem&) (APD.cpp:356-359) + the allocations of CudaSpaceInitialization
- * (APD.cpp:636-666).  `device` < 0 keeps the current device (reference: cudaSetDevice, main.cpp:153). */
+ * (APD.cpp:636-666).  `device` < 0 keeps the current device (reference: cudaSetDevice, main.cpp:153).
+ * Limits (APD_ERR_UNSUPPORTED otherwise): width <= 12000, height <= 16384 (16-bit neighbour coordinates, 24-bit index
+ * arithmetic, the tiled copy's column / 7 multiply-shift); patch geometry strong 5/2, weak 5/5. */
 int apd_create(apd_handle *out, int device, int width, int height, const apd_params *params);
 
 /* ~APD (APD.cpp:361-397). */
