@@ -167,3 +167,40 @@ def test_identical_images_identity_pose_cost_zero(ob, synth):
     o = ob.Oracle(W, H, p, cams, [imgs[0], imgs[0]])
     for (x, y) in [(10, 10), (32, 24), (50, 40)]:
         assert o.ncc_old(x, y, 1, [0.1, -0.2, -0.97, 2.0]) < 1e-6
+
+
+def test_median_filter_is_the_median_of_the_21_tap_stencil(ob, synth):
+    """K12/K13 (CheckerboardFilterStrong, APD.cu:1604-1714): away from the border and with every tap STRONG, the depth of a pixel
+    becomes the median of itself and twenty taps -- (0, +-1), (0, +-3), (0, +-5), (+-1, 0), (+-3, 0), (+-5, 0), (+-2, +-1), (+-1, +-2) --
+    all of the other colour, so black pixels read the pre-filter state and red pixels the black result; pixels whose cost is
+    below 0.001 are left alone (:1638)."""
+    W, H, N = 40, 32, 2
+    sc, imgs = common.scene_inputs(synth, W, H, N)
+    o = common.make_oracle(ob, sc, imgs, N, common.base_params(sc, N))
+    rng = np.random.RandomState(4)
+    o.planes[..., 3] = rng.uniform(1.0, 3.0, (H, W)).astype(np.float32)
+    o.costs[...] = 1.0
+    o.costs[10, 10] = 0.0005
+    o.costs[11, 10] = 0.0005
+    o.weak_info[...] = ob.STRONG
+    taps = [(0, -1), (0, -3), (0, -5), (0, 1), (0, 3), (0, 5), (-1, 0), (-3, 0), (-5, 0), (1, 0), (3, 0), (5, 0),
+            (2, -1), (2, 1), (-2, -1), (-2, 1), (-1, -2), (1, -2), (-1, 2), (1, 2)]
+    for kid, colour in ((12, 0), (13, 1)):
+        before = o.planes[..., 3].copy()
+        o.run_kernel(kid)
+        after = o.planes[..., 3]
+        checked = 0
+        for y in range(6, H - 6):
+            for x in range(6, W - 6):
+                # colour of a pixel as the checkerboard launches see it: black = (x + y) even
+                if (x + y) % 2 != colour:
+                    assert after[y, x] == before[y, x]
+                    continue
+                if o.costs[y, x] < 0.001:
+                    assert after[y, x] == before[y, x]
+                    continue
+                vals = np.array([before[y, x]] + [before[y + dy, x + dx] for dx, dy in taps], np.float32)
+                assert after[y, x] == np.sort(vals)[10], (kid, x, y)
+                checked += 1
+        assert checked > 100
+    o.close()
