@@ -1042,9 +1042,12 @@ constexpr int kSubStep = 5;
 // Nine warped samples in lock step (same stages as quad_row_issue), reduced in the reference's order.
 // ref_rows[i] packs the three reference texels of x offset i (y offset j in byte j).
 // kRecip: kRecipExact (every denominator in the fast range) or kRecipIeee (any denominator; same bits where both are valid).
+// Two halves, so that a caller can have the nine gathers of the next sub-patch in flight while it reduces this one
+// (K9/K10, two waves per SIMD: latency is what is left once the traffic is halved).
 template <int kRecip = kRecipExact>
-__device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_quad_ptr srcq, unsigned qpitch, int wm1, int hm1,
-                                                    int cx, int cy, const uint32_t (&ref_rows)[kSubN], float mean_r, float var_r)
+__device__ __forceinline__ void subpatch_issue_quad(const Homography &H, global_quad_ptr srcq, unsigned qpitch, int wm1, int hm1, int cx,
+                                                    int cy, float (&a)[kSubN * kSubN], float (&b)[kSubN * kSubN],
+                                                    quad_t (&t)[kSubN * kSubN])
 {
     constexpr int N = kSubN * kSubN;
     float z[N], X[N], Y[N], r[N];
@@ -1091,7 +1094,6 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
         Y[k] *= r[k];
     }
     APD_STAGE();
-    float a[N], b[N];
     int qx[N], qy[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -1119,12 +1121,17 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
     }
     APD_STAGE();
 #endif
-    quad_t t[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         t[k] = quad_fetch(srcq, (unsigned)qx[k]);
     }
-    APD_STAGE();
+}
+
+__device__ __forceinline__ float subpatch_finish_quad(const quad_t (&t)[kSubN * kSubN], const float (&a)[kSubN * kSubN],
+                                                      const float (&b)[kSubN * kSubN], const uint32_t (&ref_rows)[kSubN], float mean_r,
+                                                      float var_r)
+{
+    constexpr int N = kSubN * kSubN;
     float v[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -1158,6 +1165,17 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
     const float covar = fmaf(-mean_r, sum_s, sum_rs);
     const float denom = sqrtf(var_r * var_s);
     return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+}
+
+template <int kRecip = kRecipExact>
+__device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_quad_ptr srcq, unsigned qpitch, int wm1, int hm1,
+                                                    int cx, int cy, const uint32_t (&ref_rows)[kSubN], float mean_r, float var_r)
+{
+    float a[kSubN * kSubN], b[kSubN * kSubN];
+    quad_t t[kSubN * kSubN];
+    subpatch_issue_quad<kRecip>(H, srcq, qpitch, wm1, hm1, cx, cy, a, b, t);
+    APD_STAGE();
+    return subpatch_finish_quad(t, a, b, ref_rows, mean_r, var_r);
 }
 
 // The same sub-patch on a float texel-quad image (float grey values); ref[i * 3 + j] is read with stride `ref_stride` floats.

@@ -561,6 +561,67 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
 #else
     constexpr int kNbEnd = 8;
 #endif
+#ifndef APD_K910_PIPELINE
+#define APD_K910_PIPELINE 0  // measured on configs[2]: 73.0 ms per launch with the pipeline, 71.8 ms without (profiles/r02/ab_pipe.txt)
+#endif
+#if APD_K910_PIPELINE && !defined(APD_EXPERIMENT_WEAK_NB)
+    if constexpr (kQuad) {
+        // Experiment (off): software pipeline over the eight neighbours; the nine gathers of sub-patch k + 1 are in flight
+        // while sub-patch k is interpolated and reduced (201 registers, still two waves per SIMD).  Bit-identical, not faster.
+        // The costs are still added in neighbour order (`retire` runs for k = 0, 1, ..., 7), including the 2.0 of a
+        // neighbour that projects outside the image, so nothing changes bitwise.
+        float aA[kSubN * kSubN], bA[kSubN * kSubN], aB[kSubN * kSubN], bB[kSubN * kSubN];
+        quad_t tA[kSubN * kSubN], tB[kSubN * kSubN];
+        // kind of a prepared neighbour: 0 contributes nothing, 1 adds 2.0 (outside the image, view selected there), 2 sub-patch in flight
+        auto prepare = [&](int k, float (&a)[kSubN * kSubN], float (&b)[kSubN * kSubN], quad_t (&t)[kSubN * kSubN]) -> int {
+            const int packed = lds.nb[k][lane];
+            if (packed == -1) {
+                return 0;
+            }
+            const int nbx = (int)(short)(packed & 0xFFFF), nby = packed >> 16;
+            float nx, ny;
+            correspond(H, (float)nbx, (float)nby, nx, ny);
+            if (nx < 0 || ny < 0 || nx >= (float)fa.W || ny >= (float)fa.H) {
+                const uint32_t vi = fa.selected_views[nbx + nby * fa.W];
+                return bit_test(vi, (unsigned)v) ? 1 : 0;
+            }
+            const bool fast = denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep));
+            if (__builtin_amdgcn_ballot_w64(!fast) == 0) {  // one body per wave and sub-patch (see below)
+                subpatch_issue_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, a, b, t);
+            } else {
+                subpatch_issue_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, a, b, t);
+            }
+            return 2;
+        };
+        auto retire = [&](int kind, int k, const float (&a)[kSubN * kSubN], const float (&b)[kSubN * kSubN], const quad_t (&t)[kSubN * kSubN]) {
+            if (kind == 1) {
+                strong_cost += 2.0f;
+                strong_count++;
+            } else if (kind == 2) {
+                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
+                strong_cost += subpatch_finish_quad(t, a, b, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+                strong_count++;
+            }
+        };
+        int kindA = 0, kindB = 0;
+#pragma unroll 1
+        for (int k = 0; k < 8; k += 2) {
+            kindA = prepare(k, aA, bA, tA);
+            if (k > 0) {
+                retire(kindB, k - 1, aB, bB, tB);
+            }
+            kindB = prepare(k + 1, aB, bB, tB);
+            retire(kindA, k, aA, bA, tA);
+        }
+        retire(kindB, 7, aB, bB, tB);
+        if (strong_count == 0) {
+            return center_cost;
+        }
+        strong_cost /= (float)strong_count;
+        strong_cost = (strong_cost > 2.0f) ? 2.0f : strong_cost;
+        return (float)(0.25 * (double)center_cost + 0.75 * (double)strong_cost);
+    }
+#endif
 #pragma unroll 1
     for (int k = 0; k < kNbEnd; ++k) {
         const int packed = lds.nb[k][lane];
