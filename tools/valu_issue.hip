@@ -28,14 +28,16 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum Kind {
     FMA, FMA_DEP, PK_FMA, PK_FMA_DEP, MUL, PK_MUL, ADD, PK_ADD, FRACT, CVT_FLR, MED3_I32, MAD_I24, LSHL_ADD, FMA_MIX, RCP, CVT_UBYTE,
-    FMA_AND_PK_FMA, LDS_READ2, SUB, MAX_F32, MOV, ADD_U32, AND_B32, CNDMASK, CMP_LT, FLOOR, FMAC, LDS_READ_B32, MUL_LIT, KIND_COUNT
+    FMA_AND_PK_FMA, LDS_READ2, SUB, MAX_F32, MOV, ADD_U32, AND_B32, CNDMASK, CMP_LT, FLOOR, FMAC, LDS_READ_B32, MUL_LIT, MUL_LO_U32, MUL_U32_U24, MAD_U32_U24, MUL_HI_U32, LSHRREV, LSHLREV, OR_B32, OR3, AND_OR, BFE_U32,
+    ADD_LSHL, CVT_U32_F32, CVT_F32_U32, PERM, ADD3, SUB_U32, XAD, KIND_COUNT
 };
 static const char *kNames[KIND_COUNT] = {
     "v_fma_f32 (16 independent)", "v_fma_f32 (one dependent chain)", "v_pk_fma_f32 (16 independent)", "v_pk_fma_f32 (dependent chain)",
     "v_mul_f32", "v_pk_mul_f32", "v_add_f32", "v_pk_add_f32", "v_fract_f32", "v_cvt_flr_i32_f32", "v_med3_i32", "v_mad_i32_i24",
     "v_lshl_add_u32", "v_fma_mix_f32", "v_rcp_f32", "v_cvt_f32_ubyte1", "v_fma_f32 + v_pk_fma_f32 alternating (per instruction)",
     "ds_read2st64_b32 (8 B per lane, conflict-free)", "v_sub_f32", "v_max_f32", "v_mov_b32", "v_add_u32", "v_and_b32", "v_cndmask_b32",
-    "v_cmp_lt_f32 (to vcc)", "v_floor_f32", "v_fmac_f32", "ds_read_b32 (4 B per lane, conflict-free)", "v_mul_f32 by a literal"};
+    "v_cmp_lt_f32 (to vcc)", "v_floor_f32", "v_fmac_f32", "ds_read_b32 (4 B per lane, conflict-free)", "v_mul_f32 by a literal", "v_mul_lo_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_mul_hi_u32", "v_lshrrev_b32", "v_lshlrev_b32",
+    "v_or_b32", "v_or3_b32", "v_and_or_b32", "v_bfe_u32", "v_add_lshl_u32", "v_cvt_u32_f32", "v_cvt_f32_u32", "v_perm_b32", "v_add3_u32", "v_sub_u32", "v_xad_u32"};
 
 constexpr int kBody = 256;   // instructions per loop iteration
 constexpr int kLoops = 512;  // iterations
@@ -126,6 +128,40 @@ __global__ __launch_bounds__(256) void issue_kernel(float *out, float seed, long
                 asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
             } else if (KIND == MUL_LIT) {
                 asm volatile("v_mul_f32 %0, 0x3f7fbe77, %0" : "+v"(a[i]));
+            } else if (KIND == MUL_LO_U32) {
+                asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(n[i]) : "v"(pitch));
+            } else if (KIND == MUL_U32_U24) {
+                asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(n[i]) : "v"(pitch));
+            } else if (KIND == MAD_U32_U24) {
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(n[i]) : "v"(pitch), "v"(hi));
+            } else if (KIND == MUL_HI_U32) {
+                asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(n[i]) : "v"(pitch));
+            } else if (KIND == LSHRREV) {
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(n[i]) : "v"(n[(i + 1) & 15]));
+            } else if (KIND == LSHLREV) {
+                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(n[i]) : "v"(n[(i + 1) & 15]));
+            } else if (KIND == OR_B32) {
+                asm volatile("v_or_b32 %0, %0, %1" : "+v"(n[i]) : "v"(hi));
+            } else if (KIND == OR3) {
+                asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(n[i]) : "v"(hi), "v"(lo));
+            } else if (KIND == AND_OR) {
+                asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(n[i]) : "v"(hi), "v"(lo));
+            } else if (KIND == BFE_U32) {
+                asm volatile("v_bfe_u32 %0, %1, 3, 8" : "=v"(n[i]) : "v"(n[(i + 1) & 15]));
+            } else if (KIND == ADD_LSHL) {
+                asm volatile("v_add_lshl_u32 %0, %0, %1, 2" : "+v"(n[i]) : "v"(hi));
+            } else if (KIND == CVT_U32_F32) {
+                asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(n[i]) : "v"(a[i]));
+            } else if (KIND == CVT_F32_U32) {
+                asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(a[i]) : "v"(n[i]));
+            } else if (KIND == PERM) {
+                asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(n[i]) : "v"(hi), "v"(lo));
+            } else if (KIND == ADD3) {
+                asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(n[i]) : "v"(hi), "v"(lo));
+            } else if (KIND == SUB_U32) {
+                asm volatile("v_sub_u32 %0, %0, %1" : "+v"(n[i]) : "v"(hi));
+            } else if (KIND == XAD) {
+                asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(n[i]) : "v"(hi), "v"(lo));
             } else if (KIND == LDS_READ_B32) {
                 asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(8)" : "=v"(n[i]) : "v"(lds_addr) : "memory");
             } else if (KIND == LDS_READ2) {
@@ -224,6 +260,23 @@ int main(int argc, char **argv)
     rc |= run<FLOOR>(dout, dclk, csv);
     rc |= run<FMAC>(dout, dclk, csv);
     rc |= run<MUL_LIT>(dout, dclk, csv);
+    rc |= run<MUL_LO_U32>(dout, dclk, csv);
+    rc |= run<MUL_U32_U24>(dout, dclk, csv);
+    rc |= run<MAD_U32_U24>(dout, dclk, csv);
+    rc |= run<MUL_HI_U32>(dout, dclk, csv);
+    rc |= run<LSHRREV>(dout, dclk, csv);
+    rc |= run<LSHLREV>(dout, dclk, csv);
+    rc |= run<OR_B32>(dout, dclk, csv);
+    rc |= run<OR3>(dout, dclk, csv);
+    rc |= run<AND_OR>(dout, dclk, csv);
+    rc |= run<BFE_U32>(dout, dclk, csv);
+    rc |= run<ADD_LSHL>(dout, dclk, csv);
+    rc |= run<CVT_U32_F32>(dout, dclk, csv);
+    rc |= run<CVT_F32_U32>(dout, dclk, csv);
+    rc |= run<PERM>(dout, dclk, csv);
+    rc |= run<ADD3>(dout, dclk, csv);
+    rc |= run<SUB_U32>(dout, dclk, csv);
+    rc |= run<XAD>(dout, dclk, csv);
     if (csv) {
         fclose(csv);
     }

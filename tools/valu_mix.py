@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-mllvm", "-amdgpu-promote-alloca-to-vector-limit=2048"]
 FAST = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_add_u32", "v_and_b32",
-        "v_fmaak_f32", "v_fmamk_f32"}
+        "v_fmaak_f32", "v_fmamk_f32", "v_lshrrev_b32", "v_or_b32", "v_sub_u32", "v_subrev_u32"}
 TRANS = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32"}
 
 
