@@ -119,6 +119,22 @@ struct FrameArgs {
                              // evaluates every NCC the reference evaluates (A/B runs and the parity test; same results)
 };
 
+// The per-view constants are read-only for every kernel and the view index is wave-uniform wherever it is used: reading the
+// table through the constant address space lets the compiler use scalar loads (s_load_dword*) into SGPRs.  Through the
+// generic pointer of FrameArgs it cannot prove that the kernel's own stores leave the table alone, and every NCC re-read its
+// 20-odd fields with vector loads (one per lane) and waited for them (round 2: 2.6e6 scalar against 3.8e8 vector loads
+// per K6/K7 launch).
+typedef const __attribute__((address_space(4))) ViewConst *const_view_ptr;
+__device__ __forceinline__ const ViewConst &view_const(const FrameArgs &fa, int v)
+{
+#ifdef APD_VIEWS_GENERIC
+    return fa.views[v];
+#else
+    return *(const ViewConst *)((const_view_ptr)(uintptr_t)fa.views + v);
+#endif
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // polynomial kernels (contract C5) -- same coefficients and operation order as the oracle
 // ------------------------------------------------------------------------------------------------

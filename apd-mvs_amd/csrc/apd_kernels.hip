@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
         int valid = 0;
 #pragma unroll 1
         for (int v = 0; v < fa.num_src; ++v) {
-            const float c = ncc_fixed<kQuad, RefPatchLds<kFullPitch>, kTiled>(fa, fa.views[v], rp, px, py, qx, qy, qz);
+            const float c = ncc_fixed<kQuad, RefPatchLds<kFullPitch>, kTiled>(fa, view_const(fa, v), rp, px, py, qx, qy, qz);
             sorted[v] = c;
             orig[v] = c;
             if (c < 2.0f) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k5_random_initialization(FrameArgs fa)
 #pragma unroll 1
         for (int v = 0; v < fa.num_src; ++v) {
             if (bit_test(sel, (unsigned)v)) {
-                const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
+                const float c = ncc_fixed<kQuad>(fa, view_const(fa, v), rp, px, py, qx, qy, qz);
                 if (c < 2.0f) {
                     count++;
                     cost += c;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
             if (h >= 9 && wv == 0) {
                 continue;  // a refinement hypothesis only ever uses the costs of the selected views (:876-880)
             }
-            const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
+            const float c = ncc_fixed<kQuad>(fa, view_const(fa, v), rp, px, py, qx, qy, qz);
             if (h < 9) {
                 cost_array[h][v] = c;
             } else {
@@ -491,18 +491,18 @@ __device__ __forceinline__ float disparity_sample_cost(const FrameArgs &fa, cons
 #pragma unroll 1
     for (int v = 0; v < fa.num_src; ++v) {
         if (bit_test(sel, (unsigned)v)) {
-            const float c = ncc_fixed<kQuad>(fa, fa.views[v], rp, px, py, qx, qy, qz);
+            const float c = ncc_fixed<kQuad>(fa, view_const(fa, v), rp, px, py, qx, qy, qz);
             if (kLocalRefine) {
                 const float wv = (float)vw.get(v);
                 acc += c * wv;
                 if (fa.geom_consistency) {
-                    acc += fa.geom_factor * geom_cost(fa, fa.views[v], px, py, pl) * wv;
+                    acc += fa.geom_factor * geom_cost(fa, view_const(fa, v), px, py, pl) * wv;
                 }
             } else {
                 float tc = 0.0f;
                 tc += c;
                 if (fa.geom_consistency) {
-                    tc += fa.geom_factor * geom_cost(fa, fa.views[v], px, py, pl);
+                    tc += fa.geom_factor * geom_cost(fa, view_const(fa, v), px, py, pl);
                 }
                 acc += tc * (float)vw.get(v);
             }
@@ -518,7 +518,7 @@ __device__ __forceinline__ int baseline_and_weight(const FrameArgs &fa, uint32_t
     int valid = 0;
     for (int v = 0; v < fa.num_src; ++v) {
         if (bit_test(sel, (unsigned)v)) {
-            const ViewConst &vc = fa.views[v];
+            const ViewConst &vc = view_const(fa, v);
             wn += (float)vw.get(v);
             const float d0 = fa.c[0] - vc.c[0];
             const float d1 = fa.c[1] - vc.c[1];

@@ -77,7 +77,7 @@ __device__ __forceinline__ int fw_baseline_and_weight(const FrameArgs &fa, uint3
     int valid = 0;
     for (int v = 0; v < fa.num_src; ++v) {
         if (bit_test(sel, (unsigned)v)) {
-            const ViewConst &vc = fa.views[v];
+            const ViewConst &vc = view_const(fa, v);
             wn += (float)vw.get(v);
             const float d0 = fa.c[0] - vc.c[0];
             const float d1 = fa.c[1] - vc.c[1];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
             if (__builtin_amdgcn_ballot_w64(use) == 0) {
                 continue;
             }
-            const ViewConst &vc = fa.views[v];
+            const ViewConst &vc = view_const(fa, v);
             const float wv = (float)vw.get(v);
 #pragma unroll 1
             for (int c0 = 0; c0 < NP; c0 += APD_K14_CHUNK) {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
         if (__builtin_amdgcn_ballot_w64(use) == 0) {
             continue;
         }
-        const ViewConst &vc = fa.views[v];
+        const ViewConst &vc = view_const(fa, v);
         const float wv = (float)vw.get(v);
         const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use, px, py, origin, w_now);
         if (use) {
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
         if (__builtin_amdgcn_ballot_w64(open != 0) == 0) {
             continue;
         }
-        const ViewConst &vc = fa.views[v];
+        const ViewConst &vc = view_const(fa, v);
         const float wv = (float)vw.get(v);
         const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use, px, py, origin, w_now);
 #pragma unroll 1

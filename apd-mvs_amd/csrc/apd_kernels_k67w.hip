@@ -208,9 +208,21 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
     // ---- costs of the eight propagation candidates and of the current plane, view by view (:1203-1209) ----
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
-        const ViewConst &vc = fa.views[v];
+        const ViewConst &vc = view_const(fa, v);
+#ifdef APD_EXPERIMENT_SKIP_GLOBAL
+        SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
+        w.valid |= (iter >= APD_EXPERIMENT_SKIP_GLOBAL) ? 2 : 0;
+#elif defined(APD_EXPERIMENT_STAGE_TWICE)  // timing experiment (same results): what staging a window costs
+        stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
         const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
+#else
+        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
+#endif
         if (alive) {
+            // The candidate planes are re-read per view: eight float4 do not fit the register budget.  Hiding that read was
+            // tried twice in round 2 and is not worth it: loading candidate h + 1 into registers before candidate h is scored
+            // costs more in spills than the wait it hides (59.6 -> 61.8 ms per iteration on configs[1]), and sending it to a
+            // per-wave LDS slot with global_load_lds_dwordx4 changes nothing (59.5 against 60.0).
 #pragma unroll 1
             for (int h = 0; h < 9; ++h) {
                 if (h < 8 && !(flags & (1u << h))) {
@@ -310,8 +322,16 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
         if (__builtin_amdgcn_ballot_w64(open != 0) == 0) {
             continue;  // nobody in the wave has anything left to score in this view
         }
-        const ViewConst &vc = fa.views[v];
+        const ViewConst &vc = view_const(fa, v);
+#ifdef APD_EXPERIMENT_SKIP_GLOBAL
+        SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
+        w.valid |= (iter >= APD_EXPERIMENT_SKIP_GLOBAL) ? 2 : 0;
+#elif defined(APD_EXPERIMENT_STAGE_TWICE)  // timing experiment (same results): what staging a window costs
+        stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
         const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
+#else
+        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
+#endif
         if (open != 0) {
 #pragma unroll 1
             for (int k = 0; k < 5; ++k) {

@@ -782,7 +782,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
     // first one brought in (the reference's hypothesis-major order cycles through all N images in between).
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
-        const ViewConst &vc = fa.views[v];
+        const ViewConst &vc = view_const(fa, v);
 #pragma unroll 1
         for (int h = 0; h < 9; ++h) {
             if (h < 8 && !(flags & (1u << h))) {
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                     if (vw.get(j) > 0) {
                         if (fa.geom_consistency) {
                             if (flags & (1u << i)) {
-                                f += (float)vw.get(j) * (cost_array[i][j] + fa.geom_factor * geom_cost(fa, fa.views[j], px, py, candidate_plane(fa, nb, i)));
+                                f += (float)vw.get(j) * (cost_array[i][j] + fa.geom_factor * geom_cost(fa, view_const(fa, j), px, py, candidate_plane(fa, nb, i)));
                             } else {
                                 f += (float)vw.get(j) * (cost_array[i][j] + fa.geom_factor * 3.0f);
                             }
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             cost_now = 0.0f;
             for (int i = 0; i < nsrc; ++i) {
                 if (fa.geom_consistency) {
-                    cost_now += (float)vw.get(i) * (cost_array[8][i] + fa.geom_factor * geom_cost(fa, fa.views[i], px, py, plane_now));
+                    cost_now += (float)vw.get(i) * (cost_array[8][i] + fa.geom_factor * geom_cost(fa, view_const(fa, i), px, py, plane_now));
                 } else {
                     cost_now += (float)vw.get(i) * cost_array[8][i];
                 }
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
         const float lost = (h <= 14 && !(fa.geom_factor < 0.0f)) ? refinement_lost_bound(fa, cost_now, weight_norm) : __builtin_inff();
 #pragma unroll 1
         for (int v = 0; v < nsrc; ++v) {
-            const ViewConst &vc = fa.views[v];
+            const ViewConst &vc = view_const(fa, v);
             if (vw.get(v) == 0) {
                 // the cost of an unselected view is never used (:966-972); in the re-score it is multiplied by a zero
                 // weight (:1503) and, being a finite value in [0, 2], adds exactly +0

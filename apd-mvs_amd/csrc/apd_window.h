@@ -263,8 +263,15 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
     // so the two floor conversions + v_mad_i32_i24 + v_lshl_add_u32 (16 cycles) become two subtractions, two FMAs and one
     // conversion (13 cycles).  Exact: samples of the window path have X, Y >= 0 (SrcWindow::lo_x / lo_y), where
     // v_fract_f32(X) == X - floor(X) exactly, so X - fract(X) is floor(X); the address is an integer below 2^24 at every step.
+    // The last step is not a conversion either: with 2^23 added to the constant term the sum lies in [2^23, 2^24), where
+    // the low 23 bits of the binary32 encoding are the integer itself -- one v_and_b32 (2 cycles) instead of v_cvt_i32_f32
+    // (4).  addr0 is above -2^23 - 2^20 for every image apd_create accepts (height <= 16384, window rows of at most 576
+    // bytes), so every step stays an integer of magnitude below 2^24.  (ds_read does not ignore the high address bits: tools/lds_addr_bits.hip.)
+#ifndef APD_WIN_ADDR_MAGIC
+#define APD_WIN_ADDR_MAGIC 1
+#endif
     constexpr float kEntryBytes = (float)(1 << WinEntry<kQuad>::kShift), kPitchBytes = (float)(kPitch << WinEntry<kQuad>::kShift);
-    const float addr0f = (float)addr0;
+    const float addr0f = (float)addr0 + (APD_WIN_ADDR_MAGIC ? 8388608.0f : 0.0f);
     float fx[kPatchN], fy[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
@@ -291,7 +298,7 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
     int addr[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        addr[j] = (int)fx[j];
+        addr[j] = APD_WIN_ADDR_MAGIC ? (int)(__float_as_uint(fx[j]) & 0x007FFFFFu) : (int)fx[j];
     }
     APD_STAGE();
 #pragma unroll
@@ -452,6 +459,11 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
     const bool fast_body = fast_recip;
 #endif
     float sum_s, sum_ss, sum_rs;
+#ifdef APD_EXPERIMENT_SKIP_GLOBAL  // timing experiment only (wrong results): what the NCCs outside the window cost
+    if (!in_window && (w.valid & 2)) {  // bit 1 is set by K6/K7 from iteration APD_EXPERIMENT_SKIP_GLOBAL on
+        return 2.0f;
+    }
+#endif
     if (in_window) {
         ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
     } else if constexpr (kApprox) {

@@ -36,6 +36,18 @@ PASSES = [
     ("fetch", ["--kernel-trace", "--pmc", "FETCH_SIZE"]),
     ("write", ["--kernel-trace", "--pmc", "WRITE_SIZE"]),
 ]
+# optional diagnostic groups, selected with APD_PROFILE_PASSES=icache,lds,sq2 (then only these run and the summary is written
+# as pmc_extra_<tag>.json with the mean of every counter over the timed launches)
+EXTRA_PASSES = {
+    "icache": ["--kernel-trace", "--pmc", "SQC_ICACHE_REQ", "SQC_ICACHE_HITS", "SQC_ICACHE_MISSES", "SQC_ICACHE_MISSES_DUPLICATE", "SQ_IFETCH",
+               "SQ_IFETCH_LEVEL", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
+    "lds": ["--kernel-trace", "--pmc", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS",
+            "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL"],
+    "sq2": ["--kernel-trace", "--pmc", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC",
+            "SQ_ACTIVE_INST_ANY", "SQ_INSTS_BRANCH", "SQ_INST_CYCLES_SALU"],
+    "sq3": ["--kernel-trace", "--pmc", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32",
+            "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_INT32", "SQ_INST_LEVEL_LDS", "SQ_INST_LEVEL_VMEM"],
+}
 SWEEP_KERNELS = {"k67": "k67", "k910": "k910_update_weak"}
 
 
@@ -53,7 +65,9 @@ def main():
     per_dispatch = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel key -> counter -> [values in launch order]
     meta = {}
     rows_csv = []
-    for name, prof_flags in PASSES:
+    extra = [e for e in os.environ.get("APD_PROFILE_PASSES", "").split(",") if e]
+    passes = [(e, EXTRA_PASSES[e]) for e in extra] if extra else PASSES
+    for name, prof_flags in passes:
         raw = os.path.join("/tmp", "apd_prof_%s_%s" % (tag, name))
         subprocess.call(["rm", "-rf", raw])
         cmd = ["rocprofv3"] + prof_flags + ["--output-format", "csv", "-d", raw, "-o", name, "--", sys.executable,
@@ -121,7 +135,14 @@ def main():
         k["fetch_bytes_per_launch"] = None if fe is None else fe * 1024 * 2
         k["write_bytes_per_launch"] = None if wr is None else wr * 1024
         k["hbm_bytes_per_launch"] = None if fe is None or wr is None else fe * 1024 * 2 + wr * 1024
+        k["mean_over_timed_launches"] = {c: mean(c) for c in sorted(k["per_dispatch_timed"])}
         out["kernels"][key] = k
+    if extra:
+        with open(os.path.join(out_dir, "pmc_extra_%s_%s.json" % ("_".join(extra), tag)), "w") as f:
+            json.dump(out, f, indent=1)
+        for key, k in out["kernels"].items():
+            print(key, json.dumps(k["mean_over_timed_launches"]))
+        return 0
     with open(os.path.join(out_dir, "pmc_bench_%s.json" % tag), "w") as f:
         json.dump(out, f, indent=1)
     with open(os.path.join(out_dir, "pmc_bench_%s.csv" % tag), "w", newline="") as f:
