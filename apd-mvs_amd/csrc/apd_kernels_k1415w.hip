@@ -226,11 +226,22 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                 }
                 const int mid = (c0 + c1) >> 1;
                 const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use && ((in_range >> mid) & 1ull) != 0, px, py, origin, pw[mid]);
+                // pw[] and pc[] are indexed dynamically and live in scratch memory: the two reads of sample i + 1 are issued
+                // before sample i is scored instead of stalling its start and its end
+#ifndef APD_K14_PREFETCH
+#define APD_K14_PREFETCH 1
+#endif
+                float pw_next = pw[c0], pc_next = pc[c0];
 #pragma unroll 1
                 for (int i = c0; i < c1; ++i) {
+                    const float pw_i = APD_K14_PREFETCH ? pw_next : pw[i], pc_i = APD_K14_PREFETCH ? pc_next : 0.0f;
+                    if (APD_K14_PREFETCH && i + 1 < c1) {
+                        pw_next = pw[i + 1];
+                        pc_next = pc[i + 1];
+                    }
                     if (use && ((in_range >> i) & 1ull)) {
                         float4 pl = origin;
-                        pl.w = pw[i];
+                        pl.w = pw_i;
                         float qx, qy, qz;
                         plane_q(pl, qx, qy, qz);
                         float tc = 0.0f;
@@ -238,7 +249,11 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                         if (fa.geom_consistency) {
                             tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
                         }
-                        pc[i] += tc * wv;
+                        if (APD_K14_PREFETCH) {
+                            pc[i] = pc_i + tc * wv;
+                        } else {
+                            pc[i] += tc * wv;
+                        }
                     }
                 }
             }
