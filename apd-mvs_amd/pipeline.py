@@ -284,9 +284,9 @@ def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=
                     depth_store[v] = gathered[v, ..., 0].contiguous()
 
     def to_view_state(planes, weak, views):
-        pl = planes.cpu().numpy()
-        return ViewState(np.ascontiguousarray(pl[..., 3]), np.ascontiguousarray(pl[..., :3]), weak.cpu().numpy().astype(np.uint8),
-                         np.ascontiguousarray(views.cpu().numpy()).view(np.uint32))
+        # split depth / normal on the device: the host then receives two contiguous arrays instead of re-packing 16 bytes per pixel
+        return ViewState(planes[..., 3].contiguous().cpu().numpy(), planes[..., :3].contiguous().cpu().numpy(),
+                         weak.cpu().numpy().astype(np.uint8, copy=False), views.contiguous().cpu().numpy().view(np.uint32))
 
     # before fusion: everybody gets every view's depth + normal + weak (+ selected views)
     if distributed:
