@@ -318,6 +318,22 @@ def main():
         weak_path = {"kernel": "k910_update_weak (Black/RedPixelUpdateWeak)", "weak_fraction": round(weak_fraction, 4),
                      "avg_launch_ms": round(wms, 3), "launches": wl, "algorithmic_bytes_per_launch_nominal_max": wbytes,
                      "achieved_GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0}
+        # what bounds K9/K10: its scattered sub-patch gathers -- L1 tag look-ups per gather and the bytes the
+        # misses pull through the fabric; counters from the profile of this same command line, time measured live
+        wp = load_pmc_profile(args.workload, args.steps, args.warmup, "k910")
+        if wp and wms > 0 and wp.get("fetch_bytes_per_launch") and wp.get("vmem_rd_insts_per_launch"):
+            fabric = wp["fetch_bytes_per_launch"] / (wms * 1e-3) / 1e9
+            gathers = wp["vmem_rd_insts_per_launch"]
+            cyc = wms * 1e-3 * 2.4e9 * 256 / gathers
+            weak_path["bound"] = {"kind": "l1-tag pipeline + fabric", "fabric_GBps": round(fabric, 1), "fabric_peak_GBps": 8000.0,
+                                  "fabric_frac": round(fabric / 8000.0, 4), "fabric_frac_of_achievable_6290": round(fabric / 6290.0, 4),
+                                  "wave_gathers_per_launch": gathers,
+                                  "tag_lookups_per_gather": round(wp["tcp_tag_accesses_per_launch"] / gathers, 1) if wp.get("tcp_tag_accesses_per_launch") else None,
+                                  "cu_cycles_per_gather": round(cyc, 1),
+                                  "cu_cycles_per_gather_all_hits": 32.0,
+                                  "note": "an all-hit wave-level dword gather occupies a CU's L1 for 32 cycles (tools/unaligned_gather.hip); "
+                                          "FETCH_SIZE x 2 = bytes requested from the fabric (Infinity Cache + HBM)",
+                                  "pmc_source": wp["source"]}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
@@ -416,7 +432,9 @@ def load_pmc_profile(workload, steps, warmup, kernel):
         if not k or not k.get("valu_insts_per_launch") or k.get("hbm_bytes_per_launch") is None:
             continue
         best = {"valu_insts_per_launch": k["valu_insts_per_launch"], "hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
-                "launch_ms": k.get("launch_ms"), "source": os.path.relpath(path, ROOT)}
+                "launch_ms": k.get("launch_ms"), "source": os.path.relpath(path, ROOT),
+                "fetch_bytes_per_launch": k.get("fetch_bytes_per_launch"), "vmem_rd_insts_per_launch": k.get("vmem_rd_insts_per_launch"),
+                "tcp_tag_accesses_per_launch": k.get("tcp_tag_accesses_per_launch")}
     return best
 
 
