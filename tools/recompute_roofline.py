@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Recomputes every `roofline` field of the committed bench lines from the committed counter files, nothing else.
+
+    python tools/recompute_roofline.py [profiles/r02]
+
+For each bench line under the directory (bench_default.json, bench_driver_s20_w5.json, bench_apd_s3_w1.json, ...) it finds the
+counter profile of the same workload / --steps / --warmup (pmc_bench_<workload>_s<steps>_w<warmup>.json, written by
+tools/profile_bench.py from separate rocprofv3 --pmc passes), re-derives
+
+    per-launch means   = mean of the per-dispatch values over the timed launches (the .csv holds the same numbers)
+    achieved           = SQ_INSTS_VALU per launch / live launch time
+    frac               = achieved / (1024 SIMDs x 2.4 GHz / 2 cycles)
+    traffic            = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB per launch
+    hbm.frac           = traffic / live launch time / 8 TB/s
+    valu_busy_estimate = SQ_INSTS_VALU x mean issue cycles of the window body (valu_mix_k67w.json) / (1024 x 2.4 GHz x time)
+    profile vs live    = launch duration in the rocprofv3 kernel trace against the HIP-event duration of the bench line
+
+and compares them with what the line says.  Exits non-zero on any mismatch; tests/test_profiles_consistent.py runs it."""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PEAK = 1024 * 2.4 / 2.0  # G wave-instructions / s
+HBM = 8000.0             # GB/s
+
+
+def close(a, b, rel):
+    return abs(a - b) <= rel * max(abs(a), abs(b), 1e-30)
+
+
+def check(directory):
+    problems, lines = [], 0
+    mix = json.load(open(os.path.join(directory, "valu_mix_k67w.json")))["window_body"]["mean_cycles_per_inst"]
+    for path in sorted(glob.glob(os.path.join(directory, "bench_*.json"))):
+        with open(path) as f:
+            first = f.readline()
+        try:
+            line = json.loads(first)
+        except ValueError:
+            continue
+        roof = line.get("roofline")
+        if not roof or roof.get("achieved") is None:
+            continue
+        cfg = line["config"]
+        name = "pmc_bench_%s_s%d_w%d.json" % (cfg["workload"], line["steps"], line["warmup"])
+        prof_path = os.path.join(directory, name)
+        if not os.path.exists(prof_path):
+            problems.append("%s: cites counters but %s is not committed" % (os.path.basename(path), name))
+            continue
+        k = json.load(open(prof_path))["kernels"]["k67"]
+        pd = k["per_dispatch_timed"]
+        n = k["launches_timed"]
+        mean = lambda c: sum(pd[c][-n:]) / n
+        insts = mean("SQ_INSTS_VALU")
+        traffic = mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024
+        t = roof["avg_launch_ms"] * 1e-3
+        achieved = insts / t / 1e9
+        tag = os.path.basename(path)
+        lines += 1
+        for what, got, want, rel in (
+                ("launches", roof["launches"], n, 0),
+                ("valu_insts_per_launch", roof["valu_insts_per_launch"], insts, 1e-9),
+                ("achieved", roof["achieved"], achieved, 1e-3),
+                ("frac", roof["frac"], achieved / PEAK, 1e-3),
+                ("peak", roof["peak"], PEAK, 1e-6),
+                ("traffic", roof["traffic"], traffic, 1e-9),
+                ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
+                ("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),
+                ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03)):
+            ok = got == want if rel == 0 else close(got, want, rel)
+            if not ok:
+                problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
+        if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or roof["valu_busy_estimate"]["frac"] > 1:
+            problems.append("%s: a fraction above 1" % tag)
+        print("%-28s %s  frac %.4f  hbm %.4f  busy %.4f  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
+            tag, cfg["workload"], achieved / PEAK, traffic / t / 1e9 / HBM, insts * mix / (1024 * 2.4e9 * t), n, t * 1e3,
+            mean("duration_ns@trace") * 1e-6))
+    return problems, lines
+
+
+def main():
+    directory = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02")
+    problems, lines = check(directory)
+    for p in problems:
+        print("MISMATCH " + p)
+    if lines == 0:
+        print("no bench line with counter fields under " + directory)
+        return 1
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
