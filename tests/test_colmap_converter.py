@@ -216,3 +216,30 @@ def test_nearest_resize_picks_floor_of_scaled_index():
 def test_quaternion_convention():
     R = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])   # 90 degrees about z
     assert np.allclose(conv.rotation_of([np.sqrt(0.5), 0, 0, np.sqrt(0.5)]), R)
+
+
+# ---- pinned against the reference's own converter ------------------------------------------------------------------------
+# tests/golden/colmap/<case>/ holds a synthetic COLMAP model (input/) and the cams/ + pair.txt that the REFERENCE script wrote
+# for it in the build container (expected/; tests/golden/make_colmap_golden.py explains how it was run there without cv2).
+# The image conversion at the end of the reference script needs cv2 and is not part of the vectors.
+_GOLDEN = os.path.join(ROOT, "tests", "golden", "colmap")
+_CASES = {
+    "text_default": dict(model_ext=".txt", max_d=192, interval_scale=1, scale_factor=1),
+    "binary_inverse_depth_scale2": dict(model_ext=".bin", max_d=0, interval_scale=0.8, scale_factor=2),
+}
+
+
+@pytest.mark.parametrize("case", sorted(_CASES))
+def test_cams_and_pairs_equal_the_reference_converter_byte_for_byte(case, tmp_path):
+    src = os.path.join(_GOLDEN, case)
+    assert open(os.path.join(src, "args.txt")).read().split() == [t for k, v in sorted(_CASES[case].items()) for t in ("--" + k, str(v))]
+    out = str(tmp_path / "out")
+    conv.convert(os.path.join(src, "input"), out, write_images=False, verbose=False, **_CASES[case])
+    expected = os.path.join(src, "expected")
+    names = sorted(os.listdir(os.path.join(expected, "cams")))
+    assert names == sorted(os.listdir(os.path.join(out, "cams"))) and len(names) == 5
+    for n in names:
+        want = open(os.path.join(expected, "cams", n)).read()
+        got = open(os.path.join(out, "cams", n)).read()
+        assert got == want, "%s differs from the reference's file:\n%s\n--- reference ---\n%s" % (n, got, want)
+    assert open(os.path.join(out, "pair.txt")).read() == open(os.path.join(expected, "pair.txt")).read()

@@ -3,8 +3,10 @@
 
 Host-side data preparation of SURVEY.md section 8 (f4); same command line and same outputs as the reference's
 converter (`colmap2mvsnet.py:304-473`, arguments `:476-494`), written against numpy 2 / PIL (no OpenCV in
-this image; the reference's script needs cv2 and the removed `np.asscalar`, so it cannot run here and this
-tool is "parity unpinned" like the rest -- what is tested is the documented behaviour, tests/test_colmap_converter.py).
+this image).  cams/ and pair.txt are pinned byte for byte against files the reference's own script wrote in the build
+container (tests/golden/colmap, made by tests/golden/make_colmap_golden.py: text and binary model, --max_d 0,
+--scale_factor 2); the image conversion at its end needs cv2 and is tested as documented behaviour only
+(tests/test_colmap_converter.py).
 
 What is kept, because the C++ side depends on it:
   * images are re-indexed 0..n-1 in ascending COLMAP image id (`:354-357`); file names `%08d_cam.txt`, `%08d.jpg`
