@@ -554,9 +554,25 @@ __host__ __device__ __forceinline__ size_t quad_tiled_bytes(int W, int H) { retu
 __host__ __device__ __forceinline__ unsigned quad_tiled_offset_tu(unsigned t, unsigned u, unsigned tiles_x)
 {
     if (kPair2) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(APD_TILE_OFFSET_PLAIN)
+        // the same value in nine instructions, five of the 4-cycle class (24-bit multiply-adds, shift-adds; every factor is
+        // below 2^24), where the compiler's choice for the plain expression is twelve with seven of that class
+        unsigned q, t2, r2, uq, ur, tile, off;
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(q) : "v"(t), "v"(9363u));
+        asm("v_lshrrev_b32 %0, 16, %1" : "=v"(q) : "v"(q));                            // t / 7
+        asm("v_add_u32 %0, %1, %1" : "=v"(t2) : "v"(t));
+        asm("v_mad_i32_i24 %0, %1, -14, %2" : "=v"(r2) : "v"(q), "v"(t2));              // 2 * (t - 7 q)
+        asm("v_lshrrev_b32 %0, 3, %1" : "=v"(uq) : "v"(u));
+        asm("v_and_b32 %0, 7, %1" : "=v"(ur) : "v"(u));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(tile) : "v"(uq), "v"(tiles_x), "v"(q));
+        asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(off) : "v"(tile), "v"(r2));
+        asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(off) : "v"(ur), "v"(off));
+        return off;
+#else
         const unsigned q = (t * 9363u) >> 16;  // t / 7
         const unsigned r = t - 7u * q;
         return (((u >> 3) * tiles_x + q) << 7) | ((u & 7u) << 4) | (r << 1);
+#endif
     }
     return ((((u >> 2) * tiles_x + (t >> 3)) << 5) | ((u & 3u) << 3) | (t & 7u)) << 2;
 }
