@@ -16,7 +16,9 @@
 
 namespace apd {
 hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
-hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
+hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s, const int *const weak_list[2], const int weak_count[2]);
+size_t weak_list_scratch_ints(int W, int H);
+hipError_t build_weak_lists(const FrameArgs &fa, int *const list[2], int *scratch, int counts[2], hipStream_t s);
 hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s);
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s);
 hipError_t launch_weak_index_map(const uint8_t *weak, size_t n, int *map, int *scratch, hipStream_t s);
@@ -75,8 +77,12 @@ struct apd_context {
     uint8_t *view_weight = nullptr, *weak_info = nullptr, *weak_reliable = nullptr;
     short2 *nearest_strong = nullptr, *neighbours = nullptr;
     int8_t *column_nearest = nullptr;
-    int *weak_list = nullptr;
-    size_t weak_list_cap = 0;
+    // K9/K10: compacted WEAK pixels per checkerboard colour, rebuilt when weak_info changes (upload, K4, K14)
+    int *weak_list[2] = {nullptr, nullptr};
+    size_t weak_list_cap = 0;  // entries per list
+    int *weak_list_scratch = nullptr;
+    int weak_list_count[2] = {0, 0};
+    bool weak_lists_valid = false;
     int *neighbours_map = nullptr;
     size_t neighbours_cap = 0;
     FrameArgs fa{};
@@ -165,8 +171,6 @@ static void refresh_frame_args(apd_context *c)
     fa.weak_reliable = c->weak_reliable;
     fa.nearest_strong = c->nearest_strong;
     fa.column_nearest = c->column_nearest;
-    fa.weak_list = c->weak_list;
-    fa.weak_list_cap = (int)c->weak_list_cap;
     fa.neighbours_map = c->neighbours_map;
     fa.neighbours = c->neighbours;
     const char *eo = getenv("APD_EARLY_OUT");
@@ -307,6 +311,7 @@ int apd_reset(apd_handle c, const apd_params *params)
     c->views_uploaded = false;
     c->prior_uploaded = false;
     c->weak_count = 0;
+    c->weak_lists_valid = false;
     const int st = initial_state(c);
     if (st != APD_OK) {
         return st;
@@ -349,7 +354,9 @@ int apd_destroy(apd_handle c)
     hipFree(c->weak_reliable);
     hipFree(c->nearest_strong);
     hipFree(c->column_nearest);
-    hipFree(c->weak_list);
+    hipFree(c->weak_list[0]);
+    hipFree(c->weak_list[1]);
+    hipFree(c->weak_list_scratch);
     hipFree(c->neighbours_map);
     hipFree(c->neighbours);
     for (auto &pe : c->pending) {
@@ -565,12 +572,19 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
         c->neighbours_cap = need;
     }
     HIP_TRY(hipMemsetAsync(c->neighbours, 0, c->neighbours_cap * APD_NEIGHBOUR_NUM * sizeof(short2), c->stream));
-    if (need > c->weak_list_cap) {  // one colour holds at most every WEAK pixel; +1 int for the list length
-        hipFree(c->weak_list);
-        c->weak_list = nullptr;
+    c->weak_lists_valid = false;
+    if (need > c->weak_list_cap) {  // one colour holds at most every WEAK pixel
+        for (int k = 0; k < 2; ++k) {
+            hipFree(c->weak_list[k]);
+            c->weak_list[k] = nullptr;
+        }
         c->weak_list_cap = 0;
-        HIP_TRY(hipMalloc(&c->weak_list, (need + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc(&c->weak_list[0], need * sizeof(int)));
+        HIP_TRY(hipMalloc(&c->weak_list[1], need * sizeof(int)));
         c->weak_list_cap = need;
+    }
+    if (!c->weak_list_scratch) {
+        HIP_TRY(hipMalloc(&c->weak_list_scratch, apd::weak_list_scratch_ints(c->W, c->H) * sizeof(int)));
     }
     HIP_TRY(hipMemsetAsync(c->fit_planes, 0, n * sizeof(float4), c->stream));
     HIP_TRY(hipMemsetAsync(c->view_weight, 0, n * APD_MAX_IMAGES, c->stream));
@@ -617,13 +631,29 @@ static int launch_one(apd_context *c, int kernel_id, int iter)
     }
     hipError_t e;
     switch (kernel_id) {
-    case APD_K2_FIND_NEAREST_STRONG:
-    case APD_K3_GEN_NEIGHBOURS:
-    case APD_K4_NEIGHBOUR_UPDATE:
-    case APD_K8_RANSAC_FIT_PLANE:
     case APD_K9_BLACK_UPDATE_WEAK:
     case APD_K10_RED_UPDATE_WEAK:
-        e = apd::launch_weak_kernel(c->fa, kernel_id, iter, c->stream);
+        if (c->weak_list[0] && !c->weak_lists_valid) {
+            e = apd::build_weak_lists(c->fa, c->weak_list, c->weak_list_scratch, c->weak_list_count, c->stream);
+            if (e != hipSuccess) {
+                return fail(APD_ERR_HIP, "building the WEAK pixel lists failed: %s", hipGetErrorString(e));
+            }
+            c->weak_lists_valid = true;
+        }
+        e = apd::launch_weak_kernel(c->fa, kernel_id, iter, c->stream, c->weak_list, c->weak_list_count);
+        break;
+    case APD_K4_NEIGHBOUR_UPDATE:  // WEAK -> UNKNOWN: the lists are stale
+        c->weak_lists_valid = false;
+        e = apd::launch_weak_kernel(c->fa, kernel_id, iter, c->stream, nullptr, nullptr);
+        break;
+    case APD_K2_FIND_NEAREST_STRONG:
+    case APD_K3_GEN_NEIGHBOURS:
+    case APD_K8_RANSAC_FIT_PLANE:
+        e = apd::launch_weak_kernel(c->fa, kernel_id, iter, c->stream, nullptr, nullptr);
+        break;
+    case APD_K14_DEPTH_TO_WEAK:  // rewrites weak_info
+        c->weak_lists_valid = false;
+        e = apd::launch_kernel(c->fa, kernel_id, iter, c->stream);
         break;
     default:
         e = apd::launch_kernel(c->fa, kernel_id, iter, c->stream);
@@ -800,6 +830,9 @@ int apd_upload_state(apd_handle c, int which, const void *src, size_t bytes)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (which == APD_STATE_WEAK_INFO) {
+        c->weak_lists_valid = false;
+    }
     return APD_OK;
 }
 

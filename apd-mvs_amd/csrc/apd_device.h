@@ -113,8 +113,6 @@ struct FrameArgs {
     int8_t *column_nearest;  // K2 scratch: dy of the nearest STRONG pixel in the same column, 127 = none within 100
     const int *neighbours_map;
     short2 *neighbours;      // 9 per weak pixel
-    int *weak_list;          // K9/K10 scratch: compacted WEAK pixels of one colour, then one int: the count
-    int weak_list_cap;
     int early_out;           // 1 (default): the exact early-outs of the refinement loops, K14 and K15; APD_EARLY_OUT=0 in the environment
                              // evaluates every NCC the reference evaluates (A/B runs and the parity test; same results)
 };

@@ -844,6 +844,8 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
         }
         if (fa.num_src <= 8) {
             launch_k67<8>(fa, colour, iter, s);
+        } else if (fa.num_src <= 12) {
+            launch_k67<12>(fa, colour, iter, s);
         } else if (fa.num_src <= 16) {
             launch_k67<16>(fa, colour, iter, s);
         } else {

@@ -381,6 +381,8 @@ static void launch_k67w_n(const FrameArgs &fa, int tiles, int colour, int iter, 
 {
     if (fa.num_src <= 8) {
         hipLaunchKernelGGL((k67w_update_strong<8, kQuad, kTiled, kApprox>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
+    } else if (fa.num_src <= 12) {  // ten sources is the common MVS count: do not pay scratch for sixteen columns
+        hipLaunchKernelGGL((k67w_update_strong<12, kQuad, kTiled, kApprox>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
     } else if (fa.num_src <= 16) {
         hipLaunchKernelGGL((k67w_update_strong<16, kQuad, kTiled, kApprox>), dim3(tiles), dim3(256), 0, s, fa, colour, iter);
     } else {

@@ -671,30 +671,113 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
     return (float)(0.25 * (double)center_cost + 0.75 * (double)strong_cost);
 }
 
-// WEAK pixels are sparse and clustered: compact the ones of this colour into a list (tile by tile, so
-// list neighbours are image neighbours) and let the update kernel run on full waves.
-__global__ __launch_bounds__(64) void k_compact_weak(FrameArgs fa, int colour, int *__restrict__ list, int *__restrict__ count)
+// WEAK pixels are sparse and clustered: the ones of each colour are compacted into a list and the update kernels run on
+// full waves.  The list order decides what the caches see, so it is built deterministically (counts -> scan -> scatter,
+// no atomics) in an order chosen for locality: 16 x 8 px tiles (one wave's worth of one colour), tiles raster-ordered
+// inside supertiles of 16 x 16 tiles (256 x 128 px), supertiles in raster order.  Consecutive list chunks are therefore
+// image neighbours in both directions, and an XCD that walks one contiguous eighth of the list (weak_chunk_of_block)
+// keeps a compact 2-D region of every source image in its private L2 instead of a full-width strip shared with the
+// seven other XCDs.  WEAK pixels only change in K4 and K14, so the two lists are built once per pass (apd_capi.hip).
+#ifndef APD_WEAK_SUPER_SHIFT
+#define APD_WEAK_SUPER_SHIFT 4
+#endif
+constexpr int kSuperShift = APD_WEAK_SUPER_SHIFT, kSuperTiles = 1 << kSuperShift;  // supertile edge in tiles
+constexpr int kListTileW = 16, kListTileH = 8;                  // 64 pixels of one colour
+constexpr int kCountTilesPerBlock = 64;
+
+struct TileOrder {
+    int tiles_x, tiles_y, supers_x, total;  // total = number of ordered tile slots (supertiles are padded to 256 tiles)
+};
+
+static TileOrder tile_order(int W, int H)
 {
-    const int tiles_x = (fa.W + 15) / 16;
-    const int tile = blockIdx.x;
-    const int ty0 = (tile / tiles_x) * 8, tx0 = (tile - (tile / tiles_x) * tiles_x) * 16;
-    const int lane = threadIdx.x;
-    const int py = ty0 + (lane >> 3);
-    const int px = tx0 + 2 * (lane & 7) + ((py + colour) & 1);
-    // rows beyond half_rows are never visited by the reference's HALF launch (APD.cu:2402)
-    const bool weak = px < fa.W && py < fa.H && py < fa.half_rows && fa.weak_info[py * fa.W + px] == APD_WEAK;
-    const unsigned long long mask = __ballot(weak);
-    if (mask == 0) {
-        return;
+    TileOrder o;
+    o.tiles_x = (W + kListTileW - 1) / kListTileW;
+    o.tiles_y = (H + kListTileH - 1) / kListTileH;
+    o.supers_x = (o.tiles_x + kSuperTiles - 1) >> kSuperShift;
+    const int supers_y = (o.tiles_y + kSuperTiles - 1) >> kSuperShift;
+    o.total = o.supers_x * supers_y * kSuperTiles * kSuperTiles;
+    return o;
+}
+
+// lane -> pixel of ordered tile slot s; false for padding slots, pixels outside the image and rows the reference's HALF
+// launch never visits (APD.cu:2402)
+__device__ __forceinline__ bool weak_pixel_of_lane(const FrameArgs &fa, const TileOrder o, int colour, int s, int lane, int &center)
+{
+    const int super = s >> (2 * kSuperShift), within = s & (kSuperTiles * kSuperTiles - 1);
+    const int sy = super / o.supers_x, sx = super - sy * o.supers_x;
+    const int tx = (sx << kSuperShift) + (within & (kSuperTiles - 1)), ty = (sy << kSuperShift) + (within >> kSuperShift);
+    const int py = ty * kListTileH + (lane >> 3);
+    const int px = tx * kListTileW + 2 * (lane & 7) + ((py + colour) & 1);
+    center = py * fa.W + px;
+    return tx < o.tiles_x && ty < o.tiles_y && px < fa.W && py < fa.H && py < fa.half_rows && fa.weak_info[center] == APD_WEAK;
+}
+
+// pass 1: WEAK pixels of `colour` per ordered tile -> exclusive offsets inside a block of 64 tiles + the block's total
+__global__ __launch_bounds__(256) void k_weak_tile_counts(FrameArgs fa, TileOrder o, int colour, int *__restrict__ local_off,
+                                                          int *__restrict__ block_total)
+{
+    __shared__ int cnt[kCountTilesPerBlock];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s0 = blockIdx.x * kCountTilesPerBlock;
+    for (int t = 0; t < kCountTilesPerBlock / 4; ++t) {
+        const int s = s0 + wave * (kCountTilesPerBlock / 4) + t;
+        int center;
+        const bool weak = s < o.total && weak_pixel_of_lane(fa, o, colour, s, lane, center);
+        const unsigned long long mask = __ballot(weak);
+        if (lane == 0) {
+            cnt[wave * (kCountTilesPerBlock / 4) + t] = __popcll(mask);
+        }
     }
-    int base = 0;
-    if (lane == 0) {
-        base = atomicAdd(count, __popcll(mask));
+    __syncthreads();
+    if (wave == 0) {
+        const int v = cnt[lane];
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) {
+                incl += up;
+            }
+        }
+        if (s0 + lane < o.total) {
+            local_off[s0 + lane] = incl - v;
+        }
+        if (lane == 63) {
+            block_total[blockIdx.x] = incl;
+        }
     }
-    base = __shfl(base, 0);
-    if (weak) {
-        list[base + __popcll(mask & ((1ull << lane) - 1ull))] = py * fa.W + px;
+}
+
+// pass 3 (pass 2 = k_weak_block_offsets over the block totals): write the pixel indices
+__global__ __launch_bounds__(256) void k_weak_tile_scatter(FrameArgs fa, TileOrder o, int colour, const int *__restrict__ local_off,
+                                                           const int *__restrict__ block_off, int *__restrict__ list)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s0 = blockIdx.x * kCountTilesPerBlock;
+    const int base0 = block_off[blockIdx.x];
+    for (int t = 0; t < kCountTilesPerBlock / 4; ++t) {
+        const int s = s0 + wave * (kCountTilesPerBlock / 4) + t;
+        if (s >= o.total) {
+            break;
+        }
+        int center;
+        const bool weak = weak_pixel_of_lane(fa, o, colour, s, lane, center);
+        const unsigned long long mask = __ballot(weak);
+        if (weak) {
+            list[base0 + local_off[s] + __popcll(mask & ((1ull << lane) - 1ull))] = center;
+        }
     }
+}
+
+// Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md): XCD x walks list chunks [x * per_xcd, (x + 1) * per_xcd).
+__device__ __forceinline__ int weak_chunk_of_block(int b, int per_xcd)
+{
+#ifdef APD_LAB_K910_INTERLEAVED  // A/B: consecutive chunks on consecutive XCDs (every L2 sees the whole live region)
+    return b;
+#else
+    return (b & 7) * per_xcd + (b >> 3);
+#endif
 }
 
 // Plane of reliable neighbour h of a WEAK pixel (slot h + 1 of its neighbour table): re-read where it is needed -- the planes
@@ -711,7 +794,7 @@ __device__ __forceinline__ float4 candidate_plane(const FrameArgs &fa, const sho
 #define APD_K910_WAVES 2
 #endif
 template <int NMAX, bool kQuad>
-__global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, const int *__restrict__ count)
+__global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, int count, int per_xcd)
 {
     __shared__ WeakLdsT<kQuad> lds;
     // Round 1 (4-byte quads): bound by the L1/L2 traffic of the scattered sub-patch gathers, and six waves per CU evicted each
@@ -729,8 +812,8 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
         }
     }
     const int lane = threadIdx.x;
-    const int gid = blockIdx.x * 64 + lane;
-    if (gid >= *count) {
+    const int gid = weak_chunk_of_block(blockIdx.x, per_xcd) * 64 + lane;
+    if (gid >= count) {
         return;
     }
     const int W = fa.W;
@@ -1071,26 +1154,52 @@ hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *
     return hipGetLastError();
 }
 
-template <int NMAX>
-static void launch_k910(const FrameArgs &fa, int colour, int iter, hipStream_t s)
+// scratch ints build_weak_lists needs for a W x H frame
+size_t weak_list_scratch_ints(int W, int H)
 {
-    // The list length is only known on the device: launch one wave per 16x8 tile (an upper bound of
-    // ceil(count / 64)); surplus waves retire on their first instruction.
-    const int tiles = ((fa.W + 15) / 16) * ((fa.H + 7) / 8);
-    if (!fa.weak_list) {
-        return;  // no prior state was uploaded: every pixel is STRONG (APD.cpp:541-547)
+    const TileOrder o = tile_order(W, H);
+    return (size_t)o.total + (size_t)(o.total / kCountTilesPerBlock) + 1;
+}
+
+// The compacted WEAK pixels of both colours (list[0] black, list[1] red; each with room for every WEAK pixel) and their
+// lengths, which come back to the host: the update kernels are launched with exact grids.  Synchronises the stream.
+hipError_t build_weak_lists(const FrameArgs &fa, int *const list[2], int *scratch, int counts[2], hipStream_t s)
+{
+    const TileOrder o = tile_order(fa.W, fa.H);
+    const int nblocks = o.total / kCountTilesPerBlock;  // o.total is a multiple of 256
+    int *local_off = scratch, *block_off = scratch + o.total;
+    for (int colour = 0; colour < 2; ++colour) {
+        hipLaunchKernelGGL(k_weak_tile_counts, dim3(nblocks), dim3(256), 0, s, fa, o, colour, local_off, block_off);
+        hipLaunchKernelGGL(k_weak_block_offsets, dim3(1), dim3(kMapBlock), 0, s, block_off, nblocks);
+        hipLaunchKernelGGL(k_weak_tile_scatter, dim3(nblocks), dim3(256), 0, s, fa, o, colour, (const int *)local_off,
+                           (const int *)block_off, list[colour]);
+        hipError_t e = hipMemcpyAsync(&counts[colour], block_off + nblocks, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) {
+            return e;
+        }
+        e = hipStreamSynchronize(s);  // the scratch is reused by the other colour
+        if (e != hipSuccess) {
+            return e;
+        }
     }
-    int *count = fa.weak_list + fa.weak_list_cap;
-    (void)hipMemsetAsync(count, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_compact_weak, dim3(tiles), dim3(64), 0, s, fa, colour, fa.weak_list, count);
+    return hipGetLastError();
+}
+
+template <int NMAX>
+static void launch_k910(const FrameArgs &fa, const int *list, int count, int iter, hipStream_t s)
+{
+    if (count <= 0) {
+        return;
+    }
+    const int chunks = (count + 63) / 64, per_xcd = (chunks + 7) / 8;
     if (fa.use_quads) {
-        hipLaunchKernelGGL((k910_update_weak<NMAX, true>), dim3(tiles), dim3(64), 0, s, fa, iter, fa.weak_list, count);
+        hipLaunchKernelGGL((k910_update_weak<NMAX, true>), dim3(8 * per_xcd), dim3(64), 0, s, fa, iter, list, count, per_xcd);
     } else {
-        hipLaunchKernelGGL((k910_update_weak<NMAX, false>), dim3(tiles), dim3(64), 0, s, fa, iter, fa.weak_list, count);
+        hipLaunchKernelGGL((k910_update_weak<NMAX, false>), dim3(8 * per_xcd), dim3(64), 0, s, fa, iter, list, count, per_xcd);
     }
 }
 
-hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s)
+hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s, const int *const weak_list[2], const int weak_count[2])
 {
     const int n = fa.W * fa.H;
     switch (kernel_id) {
@@ -1112,12 +1221,17 @@ hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipS
     case APD_K9_BLACK_UPDATE_WEAK:
     case APD_K10_RED_UPDATE_WEAK: {
         const int colour = (kernel_id == APD_K9_BLACK_UPDATE_WEAK) ? 0 : 1;
+        if (!weak_list || !weak_list[colour]) {
+            break;  // no prior state was uploaded: every pixel is STRONG (APD.cpp:541-547)
+        }
         if (fa.num_src <= 8) {
-            launch_k910<8>(fa, colour, iter, s);
+            launch_k910<8>(fa, weak_list[colour], weak_count[colour], iter, s);
+        } else if (fa.num_src <= 12) {
+            launch_k910<12>(fa, weak_list[colour], weak_count[colour], iter, s);
         } else if (fa.num_src <= 16) {
-            launch_k910<16>(fa, colour, iter, s);
+            launch_k910<16>(fa, weak_list[colour], weak_count[colour], iter, s);
         } else {
-            launch_k910<32>(fa, colour, iter, s);
+            launch_k910<32>(fa, weak_list[colour], weak_count[colour], iter, s);
         }
         break;
     }

@@ -74,7 +74,7 @@ __device__ __forceinline__ bool checkerboard_active(const FrameArgs &fa, const T
 
 template <int NMAX>
 struct ViewWeights {
-    static constexpr int kWords = NMAX / 8;
+    static constexpr int kWords = (NMAX + 7) / 8;
     uint32_t w[kWords];
 
     __device__ __forceinline__ void clear()

@@ -54,6 +54,17 @@ APD_WORKLOADS = {"eth3d_pipes_fullres_10src_apd": "eth3d_pipes_fullres_10src", "
 WORKLOADS.update({k: WORKLOADS[v] for k, v in APD_WORKLOADS.items()})
 
 
+def resolve_workload(name):
+    """Named workloads above, or an ad-hoc shape for tuning runs: custom_<W>x<H>_<N>src[_apd]."""
+    import re
+    if name in WORKLOADS:
+        return WORKLOADS[name], name in APD_WORKLOADS
+    m = re.match(r"^custom_(\d+)x(\d+)_(\d+)src(_apd)?$", name)
+    if not m:
+        raise SystemExit("bench.py: unknown workload %r (named: %s; or custom_<W>x<H>_<N>src[_apd])" % (name, ", ".join(sorted(WORKLOADS))))
+    return (int(m.group(1)), int(m.group(2)), int(m.group(3))), m.group(4) is not None
+
+
 def algorithmic_bytes_per_weak_pixel(num_src):
     """SURVEY.md 8(d), nominal: 15*N NCCNew of 108 samples + N NCCOld of 36 samples, 20 B per sample, + 176 B of state."""
     return 33120 * num_src + 176
@@ -69,7 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="eth3d_office_fullres_8src", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="eth3d_office_fullres_8src",
+                    help="one of %s, or custom_<W>x<H>_<N>src[_apd]" % ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1024x768", help="WxH of the CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=12345)
@@ -141,8 +153,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if distributed else 0)
 
-    W, H, N = WORKLOADS[args.workload]
-    apd_mode = args.workload in APD_WORKLOADS
+    (W, H, N), apd_mode = resolve_workload(args.workload)
     # every rank owns a different reference view of the same camera ring
     sc = synth.make_scene(W, H, N, seed=0, ref_view=rank, device=dev, textureless=0.2 if apd_mode else 0.0)
     cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
