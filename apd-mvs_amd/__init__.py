@@ -28,6 +28,11 @@ KERNEL_NAMES = {
     14: "DepthToWeak", 15: "LocalRefine",
 }
 
+# apd_set_option / apd_get_option (include/apd_mi355x.h): the library reads nothing from the environment
+(OPT_FAST_RCP, OPT_EARLY_OUT, OPT_SOURCE_QUADS, OPT_TILED_COPY, OPT_K67_WINDOWS, OPT_K1415_WINDOWS) = range(6)
+OPTION_NAMES = {"fast_rcp": OPT_FAST_RCP, "early_out": OPT_EARLY_OUT, "source_quads": OPT_SOURCE_QUADS, "tiled_copy": OPT_TILED_COPY,
+                "k67_windows": OPT_K67_WINDOWS, "k1415_windows": OPT_K1415_WINDOWS}
+
 (STATE_PLANES, STATE_FIT_PLANES, STATE_COSTS, STATE_RNG, STATE_SELECTED_VIEWS, STATE_VIEW_WEIGHT,
  STATE_WEAK_INFO, STATE_WEAK_RELIABLE, STATE_NEAREST_STRONG, STATE_NEIGHBOURS_MAP, STATE_NEIGHBOURS) = range(11)
 
@@ -105,6 +110,8 @@ def lib():
     L.apd_profile_reset.argtypes = [H]
     L.apd_profile_get.argtypes = [H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.apd_set_stream.argtypes = [H, C.c_void_p]
+    L.apd_set_option.argtypes = [H, C.c_int, C.c_int]
+    L.apd_get_option.argtypes = [H, C.c_int, C.POINTER(C.c_int)]
     L.apd_last_error.restype = C.c_char_p
     L.apd_device_count.restype = C.c_int
     _lib = L
@@ -187,6 +194,18 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, option, value):
+        """apd_set_option; `option` is an OPT_* constant or one of OPTION_NAMES.  Upload-time options (source_quads,
+        tiled_copy) must be set before upload_views."""
+        opt = OPTION_NAMES[option] if isinstance(option, str) else int(option)
+        _check(lib().apd_set_option(self._h, opt, int(value)))
+
+    def get_option(self, option):
+        opt = OPTION_NAMES[option] if isinstance(option, str) else int(option)
+        v = C.c_int()
+        _check(lib().apd_get_option(self._h, opt, C.byref(v)))
+        return v.value
 
     def upload_views(self, cameras, images, depths=None):
         """images/depths: lists of float32 [H, W] numpy arrays or torch tensors (host or device)."""

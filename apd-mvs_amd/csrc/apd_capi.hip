@@ -83,6 +83,7 @@ struct apd_context {
     int *weak_list_scratch = nullptr;
     int weak_list_count[2] = {0, 0};
     bool weak_lists_valid = false;
+    int options[APD_OPT_COUNT] = {0, 1, 1, 1, 1, 1};  // defaults of include/apd_mi355x.h
     int *neighbours_map = nullptr;
     size_t neighbours_cap = 0;
     FrameArgs fa{};
@@ -138,10 +139,10 @@ static void refresh_frame_args(apd_context *c)
     fa.half_rows = 2 * (((c->H / 2) + 15) / 16) * 16;
     fa.use_quads = c->use_quads ? 1 : 0;
     fa.have_tiled = c->have_tiled ? 1 : 0;
-    {   // optional tolerance mode (default off: the parity target is the exact mode); read when the handle is (re)armed
-        const char *e = getenv("APD_FAST_RCP");
-        fa.approx_rcp = (e && e[0] == '1') ? 1 : 0;
-    }
+    fa.approx_rcp = c->options[APD_OPT_FAST_RCP];  // tolerance mode, default off: the parity target is the exact mode
+    fa.tiled_mode = c->options[APD_OPT_TILED_COPY];
+    fa.k67_windows = c->options[APD_OPT_K67_WINDOWS];
+    fa.k1415_windows = c->options[APD_OPT_K1415_WINDOWS];
     fa.top_k = p.top_k;
     fa.depth_min = p.depth_min;
     fa.depth_max = p.depth_max;
@@ -173,8 +174,7 @@ static void refresh_frame_args(apd_context *c)
     fa.column_nearest = c->column_nearest;
     fa.neighbours_map = c->neighbours_map;
     fa.neighbours = c->neighbours;
-    const char *eo = getenv("APD_EARLY_OUT");
-    fa.early_out = (eo && eo[0] == '0') ? 0 : 1;
+    fa.early_out = c->options[APD_OPT_EARLY_OUT];
 }
 
 extern "C" {
@@ -244,8 +244,8 @@ int apd_create(apd_handle *out, int device, int width, int height, const apd_par
     if (!out || !params || width <= 0 || height <= 0) {
         return fail(APD_ERR_INVALID, "apd_create: bad argument");
     }
-    if (width > 12000 || height > 16384) {  // the tiled copy divides the column by 7 with a multiply-shift that is exact below 13,000
-        return fail(APD_ERR_UNSUPPORTED, "apd_create: image larger than 12000 x 16384 px");
+    if (width > 16384 || height > 16384) {  // pixel coordinates travel as short2 and through 24-bit multiply-adds
+        return fail(APD_ERR_UNSUPPORTED, "apd_create: image larger than 16384 x 16384 px");
     }
     if (params->strong_radius != 5 || params->strong_increment != 2 || params->weak_radius != 5 || params->weak_increment != 5) {
         // the reference never changes these (main.h:84-87); the kernels are specialised for them
@@ -449,7 +449,7 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     int all_u8 = 0;
     HIP_TRY(hipMemcpyAsync(&all_u8, c->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->use_quads = all_u8 != 0 && getenv("APD_NO_QUADS") == nullptr;
+    c->use_quads = all_u8 != 0 && c->options[APD_OPT_SOURCE_QUADS] != 0;
     if (!c->use_quads) {  // float grey values (e.g. a resampled pyramid level): float texel quads of the source views
         const size_t fn = (size_t)(c->W + 1) * (c->H + 1);
         for (int i = 1; i < num_images; ++i) {
@@ -470,9 +470,8 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
             }
         }
         // the tiled copy serves the gathers of planes that are still random: the first iteration of a FIRST_INIT pass
-        // (APD_K67_TILED=2 uses it in every pass; =0 never builds it)
-        const char *tm = getenv("APD_K67_TILED");
-        const int tiled_mode = tm ? atoi(tm) : 1;
+        // (APD_OPT_TILED_COPY = 2 uses it in every pass; 0 never builds it)
+        const int tiled_mode = c->options[APD_OPT_TILED_COPY];
         c->have_tiled = tiled_mode == 2 || (tiled_mode == 1 && c->params.state == APD_FIRST_INIT);
         if (c->have_tiled) {
             const size_t tbytes = apd::quad_tiled_bytes(c->W, c->H);
@@ -847,6 +846,29 @@ int apd_export_depth_normal_device(apd_handle c, float *depth_dev, float *normal
         return fail(APD_ERR_HIP, "export kernel failed: %s", hipGetErrorString(e));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return APD_OK;
+}
+
+int apd_set_option(apd_handle c, int option, int value)
+{
+    if (!c || option < 0 || option >= APD_OPT_COUNT) {
+        return fail(APD_ERR_INVALID, "apd_set_option: bad handle or option %d", option);
+    }
+    const int hi = option == APD_OPT_TILED_COPY ? 2 : 1;
+    if (value < 0 || value > hi) {
+        return fail(APD_ERR_INVALID, "apd_set_option: option %d takes 0..%d, got %d", option, hi, value);
+    }
+    c->options[option] = value;
+    refresh_frame_args(c);
+    return APD_OK;
+}
+
+int apd_get_option(apd_handle c, int option, int *value)
+{
+    if (!c || !value || option < 0 || option >= APD_OPT_COUNT) {
+        return fail(APD_ERR_INVALID, "apd_get_option: bad argument");
+    }
+    *value = c->options[option];
     return APD_OK;
 }
 

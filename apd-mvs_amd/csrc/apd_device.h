@@ -81,7 +81,10 @@ struct FrameArgs {
     int half_rows;     // rows reachable by the reference HALF launch: 2*ceil((H/2)/16)*16 (APD.cu:2402)
     int use_quads;     // 1: source images are also available as texel quads (ViewConst::quad)
     int have_tiled;    // 1: ... and as the tiled copy (ViewConst::quad_tiled)
-    int approx_rcp;    // 1: tolerance mode APD_FAST_RCP=1 (K6/K7 sample loops stop at v_rcp_f32; results are NOT the oracle's bits)
+    int approx_rcp;    // 1: tolerance mode APD_OPT_FAST_RCP (K6/K7 sample loops stop at v_rcp_f32; results are NOT the oracle's bits)
+    // host-side dispatch switches (apd_set_option): which kernels launch_kernel picks; same results
+    int tiled_mode;    // APD_OPT_TILED_COPY
+    int k67_windows, k1415_windows;
     // params (main.h:75-94)
     int top_k;
     float depth_min, depth_max;
@@ -113,7 +116,7 @@ struct FrameArgs {
     int8_t *column_nearest;  // K2 scratch: dy of the nearest STRONG pixel in the same column, 127 = none within 100
     const int *neighbours_map;
     short2 *neighbours;      // 9 per weak pixel
-    int early_out;           // 1 (default): the exact early-outs of the refinement loops, K14 and K15; APD_EARLY_OUT=0 in the environment
+    int early_out;           // 1 (default): the exact early-outs of the refinement loops, K14 and K15; APD_OPT_EARLY_OUT = 0
                              // evaluates every NCC the reference evaluates (A/B runs and the parity test; same results)
 };
 
@@ -548,7 +551,8 @@ __host__ __device__ __forceinline__ unsigned quad_tiles_x(int W)
 }
 __host__ __device__ __forceinline__ unsigned quad_tiles_y(int H) { return ((unsigned)(H + 1) + kTileRows - 1u) / kTileRows; }
 __host__ __device__ __forceinline__ size_t quad_tiled_bytes(int W, int H) { return (size_t)quad_tiles_x(W) * quad_tiles_y(H) * 128u + 4u; }
-// byte offset of entry (t, u); t / 7 as a multiply-shift (exact for t < 13,000; images are at most 16,384 wide -> checked in apd_create)
+// byte offset of entry (t, u); t / 7 as a multiply-shift: (t * 37450) >> 18 is exact for t < 43,690 and both factors fit the
+// 24-bit multiplier for the 16,384-px widest image apd_create accepts
 __host__ __device__ __forceinline__ unsigned quad_tiled_offset_tu(unsigned t, unsigned u, unsigned tiles_x)
 {
     if (kPair2) {
@@ -556,8 +560,8 @@ __host__ __device__ __forceinline__ unsigned quad_tiled_offset_tu(unsigned t, un
         // the same value in nine instructions, five of the 4-cycle class (24-bit multiply-adds, shift-adds; every factor is
         // below 2^24), where the compiler's choice for the plain expression is twelve with seven of that class
         unsigned q, t2, r2, uq, ur, tile, off;
-        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(q) : "v"(t), "v"(9363u));
-        asm("v_lshrrev_b32 %0, 16, %1" : "=v"(q) : "v"(q));                            // t / 7
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(q) : "v"(t), "v"(37450u));
+        asm("v_lshrrev_b32 %0, 18, %1" : "=v"(q) : "v"(q));                            // t / 7
         asm("v_add_u32 %0, %1, %1" : "=v"(t2) : "v"(t));
         asm("v_mad_i32_i24 %0, %1, -14, %2" : "=v"(r2) : "v"(q), "v"(t2));              // 2 * (t - 7 q)
         asm("v_lshrrev_b32 %0, 3, %1" : "=v"(uq) : "v"(u));
@@ -567,7 +571,7 @@ __host__ __device__ __forceinline__ unsigned quad_tiled_offset_tu(unsigned t, un
         asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(off) : "v"(ur), "v"(off));
         return off;
 #else
-        const unsigned q = (t * 9363u) >> 16;  // t / 7
+        const unsigned q = (t * 37450u) >> 18;  // t / 7
         const unsigned r = t - 7u * q;
         return (((u >> 3) * tiles_x + q) << 7) | ((u & 7u) << 4) | (r << 1);
 #endif
@@ -671,7 +675,7 @@ __device__ __forceinline__ unsigned fquad_byte_offset(int qx, int qy, int pitch,
 // Reciprocal of the sample loops: kRecipIeee -- IEEE division (any denominator); kRecipExact -- v_rcp_f32 + one Newton step,
 // the correctly rounded reciprocal on the range denominators_fast() checks (the default path); kRecipApprox -- the bare
 // v_rcp_f32 (<= 1 ulp), what the reference's own --use_fast_math build does (CMakeLists.txt:20): the optional tolerance
-// mode APD_FAST_RCP=1, NOT bit-identical to the oracle (tests/test_gpu_fast_rcp.py states what it keeps).
+// mode APD_OPT_FAST_RCP, NOT bit-identical to the oracle (tests/test_gpu_fast_rcp.py states what it keeps).
 enum { kRecipIeee = 0, kRecipExact = 1, kRecipApprox = 2 };
 
 template <int kRecip, bool kTiled = false>

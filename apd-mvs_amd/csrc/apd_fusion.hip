@@ -414,7 +414,6 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
     FUS_TRY(dev_alloc(max_px * 12, &xyz_out));
     FUS_TRY(dev_alloc(max_px * 3, &grey_out));
 
-    const bool verbose = getenv("APD_FUSION_VERBOSE") != nullptr;
     std::vector<uint8_t> body;  // PLY records: x y z float + diffuse_blue/green/red uchar (APD.cpp:214-254)
     std::vector<float> hxyz;
     std::vector<uint8_t> hgrey;
@@ -466,9 +465,7 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
         FUS_TRY(hipGetLastError());
         int npts = 0;
         FUS_TRY(hipMemcpy(&npts, total, sizeof(int), hipMemcpyDeviceToHost));
-        if (verbose) {
-            fprintf(stderr, "apd_fuse_views: view %d: %d points after %d consumption round(s)\n", i, npts, rounds);
-        }
+        (void)rounds;
         if (npts > 0) {
             hxyz.resize((size_t)npts * 3);
             hgrey.resize((size_t)npts * 3);

@@ -789,23 +789,13 @@ static inline int checkerboard_tiles(const FrameArgs &fa) { return ((fa.W + kTil
 
 hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStream_t s);  // apd_kernels_k67w.hip
 
-// APD_K67_WINDOW=0 in the environment selects the kernel without the LDS source windows (A/B timing and the
-// window-vs-global parity test; same results).  Read at every launch: a getenv per 25 ms kernel is free.
-static bool k67_window_enabled()
-{
-    const char *e = getenv("APD_K67_WINDOW");
-    return !(e && e[0] == '0');
-}
+// APD_OPT_K67_WINDOWS = 0 selects the kernel without the LDS source windows (A/B timing and the window-vs-global parity
+// test; same results)
 
 hipError_t launch_k14_windowed(const FrameArgs &fa, hipStream_t s);  // apd_kernels_k1415w.hip
 hipError_t launch_k15_windowed(const FrameArgs &fa, hipStream_t s);
 
-// APD_K1415_WINDOW=0: K14/K15 without LDS source windows (same results)
-static bool k1415_window_enabled()
-{
-    const char *e = getenv("APD_K1415_WINDOW");
-    return !(e && e[0] == '0');
-}
+// APD_OPT_K1415_WINDOWS = 0: K14/K15 without LDS source windows (same results)
 
 template <int NMAX>
 static void launch_k67(const FrameArgs &fa, int colour, int iter, hipStream_t s)
@@ -839,7 +829,7 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
     case APD_K6_BLACK_UPDATE_STRONG:
     case APD_K7_RED_UPDATE_STRONG: {
         const int colour = (kernel_id == APD_K6_BLACK_UPDATE_STRONG) ? 0 : 1;
-        if (k67_window_enabled()) {
+        if (fa.k67_windows) {
             return launch_k67_windowed(fa, colour, iter, s);
         }
         if (fa.num_src <= 8) {
@@ -862,7 +852,7 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
                            (kernel_id == APD_K12_BLACK_FILTER) ? 0 : 1);
         break;
     case APD_K14_DEPTH_TO_WEAK:
-        if (k1415_window_enabled()) {
+        if (fa.k1415_windows) {
             return launch_k14_windowed(fa, s);
         }
         if (fa.use_quads) {
@@ -872,7 +862,7 @@ hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream
         }
         break;
     case APD_K15_LOCAL_REFINE:
-        if (k1415_window_enabled()) {
+        if (fa.k1415_windows) {
             return launch_k15_windowed(fa, s);
         }
         if (fa.use_quads) {

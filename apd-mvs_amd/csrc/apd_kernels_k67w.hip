@@ -129,7 +129,7 @@ constexpr float kTrustedCost = APD_WIN_TRUST;
 #define APD_K67W_WAVES_F32 3  // float windows are twice the size: three workgroups per CU
 #endif
 // kTiled: NCCs that miss the window (all of them while the windows are off) gather from the tiled copy of the quad image
-// kApprox: tolerance mode APD_FAST_RCP=1 (bare v_rcp_f32 in the sample loops; not bit-identical to the oracle)
+// kApprox: tolerance mode APD_OPT_FAST_RCP (bare v_rcp_f32 in the sample loops; not bit-identical to the oracle)
 template <int NMAX, bool kQuad, bool kTiled, bool kApprox>
 __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) void k67w_update_strong(FrameArgs fa, int colour, int iter)
 {
@@ -400,24 +400,16 @@ static void launch_k67w(const FrameArgs &fa, int tiles, int colour, int iter, hi
     }
 }
 
-// Which launches gather from the tiled copy (APD_K67_TILED in the environment; same results either way):
+// Which launches gather from the tiled copy (APD_OPT_TILED_COPY; same results either way):
 //   0 never, 1 (default) while the windows are off, i.e. the random first iteration of a FIRST_INIT pass, 2 always.
 // Measured on configs[1] (profiles/r02/tiled_vs_rowmajor.txt): the first black launch 129 -> 94 ms; from the second
 // iteration on the row-major copy is faster (three extra address instructions per sample on a VALU-bound kernel).
-static int k67_tiled_mode()
-{
-    const char *e = getenv("APD_K67_TILED");
-    return e ? atoi(e) : 1;
-}
-
 hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStream_t s)
 {
     const int tiles = ((fa.W + kTileW - 1) / kTileW) * ((fa.H + kTileH - 1) / kTileH);
     if (fa.use_quads) {
-        const int mode = k67_tiled_mode();
-        const char *ti = getenv("APD_K67_TILED_ITERS");  // experiment knob: global gathers from the tiles in iterations < N of a FIRST_INIT pass
-        const int tiled_iters = ti ? atoi(ti) : APD_WIN_FROM_ITER;
-        const bool windows_off = fa.state == APD_FIRST_INIT && iter < tiled_iters;
+        const int mode = fa.tiled_mode;
+        const bool windows_off = fa.state == APD_FIRST_INIT && iter < APD_WIN_FROM_ITER;
         if (fa.have_tiled && (mode == 2 || (mode == 1 && windows_off))) {
             launch_k67w<true, true>(fa, tiles, colour, iter, s);
         } else {

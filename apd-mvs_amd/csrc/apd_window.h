@@ -240,7 +240,7 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
         r[j] = __builtin_amdgcn_rcpf(z[j]);
     }
     APD_STAGE();
-    if constexpr (!kApprox) {  // Newton step: the correctly rounded reciprocal (tolerance mode APD_FAST_RCP=1 stops at v_rcp_f32)
+    if constexpr (!kApprox) {  // Newton step: the correctly rounded reciprocal (tolerance mode APD_OPT_FAST_RCP stops at v_rcp_f32)
 #pragma unroll
         for (int j = 0; j < kPatchN; ++j) {
             z[j] = fmaf(-z[j], r[j], 1.0f);

@@ -10,7 +10,9 @@
 // fixed-point YCbCr -> RGB conversion.  For grey output the chroma blocks of a sequential file are entropy-decoded (to keep
 // the bit stream in step) and dropped.
 // Supported: SOF0/SOF1/SOF2 8-bit, 1 or 3 components, sampling factors 1..4, restart intervals.
-// Not supported (returns false): arithmetic coding, lossless / hierarchical frames, 12-bit samples.
+// Not supported (returns false): arithmetic coding, lossless / hierarchical frames, 12-bit samples, a second SOF marker,
+// and INCOMPLETE progressive files (no EOI, or low-frequency coefficients not refined to full precision): libjpeg
+// would show those with inter-block smoothing, i.e. other pixels than a plain IDCT of what was read.
 // Every table index that comes from the file is bounds-checked; tests/test_host_io.py fuzzes the decoder under ASan + UBSan.
 #include <cstdint>
 #include <cstdio>
@@ -344,6 +346,8 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
     bool have_sof = false;
     bool progressive = false;  // SOF2: coefficients are collected over several scans, the IDCT runs after the last one
     std::vector<int16_t> coefs[4];          // progressive only: [block][64] in natural order, blocks_w x blocks_h per component
+    int8_t coef_al[4][64];                  // progressive only: successive-approximation bit each zig-zag position was last coded at (-1 = never)
+    bool saw_eoi = false;
     int blocks_w[4] = {0, 0, 0, 0}, blocks_h[4] = {0, 0, 0, 0};
     uint16_t latched_qt[4][64];             // quantisation table of a component as of its first scan (jdinput.c latch_quant_tables)
     bool qt_latched[4] = {false, false, false, false};
@@ -409,6 +413,7 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
             continue;
         }
         if (marker == 0xD9) {
+            saw_eoi = true;
             break;
         }
         if (pos + 2 > size) {
@@ -451,6 +456,9 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
                 i += 17 + n;
             }
         } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {  // SOF0 / SOF1 (sequential), SOF2 (progressive)
+            if (have_sof) {
+                return false;  // a second frame header would resize planes and coefficient arrays under the scans (libjpeg: JERR_SOF_DUPLICATE)
+            }
             progressive = marker == 0xC2;
             if (seglen < 6 || seg[0] != 8) {
                 return false;
@@ -534,6 +542,15 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
                     blocks_h[c] = mcus_y * comp[c].v;
                     if (coefs[c].empty()) {
                         coefs[c].assign((size_t)blocks_w[c] * blocks_h[c] * 64, 0);
+                        memset(coef_al[c], 0xFF, sizeof(coef_al[c]));
+                    }
+                    if (coefs[c].size() != (size_t)blocks_w[c] * blocks_h[c] * 64) {
+                        return false;  // cannot happen with a single SOF; guards every blk pointer below
+                    }
+                }
+                for (int s2 = 0; s2 < ns; ++s2) {  // successive-approximation bookkeeping: which precision each coefficient has reached
+                    for (int k = Ss; k <= Se; ++k) {
+                        coef_al[scan_comp[s2]][k] = (int8_t)Al;
                     }
                 }
                 for (int s2 = 0; s2 < ns; ++s2) {
@@ -798,13 +815,29 @@ bool decode_jpeg(const uint8_t *data, size_t size, bool want_colour, std::vector
         pos += len;
     }
     if (progressive && have_sof && scanned[yc]) {
-        // all scans read (EOI, or the end of a truncated file: libjpeg shows what it has as well): dequantise + IDCT
+        // All scans read: dequantise + IDCT.  Only files libjpeg decodes WITHOUT inter-block smoothing are accepted: EOI
+        // reached, and the DC and the first five AC coefficients in zig-zag order (natural 1, 8, 16, 9, 2 -- the ones jdcoefct.c's
+        // smoothing_ok() inspects) of every needed component refined down to bit 0.  For anything else libjpeg
+        // interpolates the missing AC precision from the neighbouring blocks' DC values, which is not built here: such a
+        // file is refused instead of being decoded to different pixels.
+        for (size_t q = pos; !saw_eoi && q + 2 <= size; ++q) {  // the marker loop stops four bytes before the end: EOI is usually in them
+            saw_eoi = data[q] == 0xFF && data[q + 1] == 0xD9;
+        }
+        if (!saw_eoi) {
+            return false;
+        }
         for (int c = 0; c < ncomp; ++c) {
             if (!(c == yc || want_colour)) {
                 continue;
             }
-            if (!scanned[c] || !qt_latched[c] || coefs[c].empty()) {
+            if (!scanned[c] || !qt_latched[c] || coefs[c].size() != (size_t)blocks_w[c] * blocks_h[c] * 64 ||
+                planes[c].size() != (size_t)plane_w[c] * plane_h[c]) {
                 return false;
+            }
+            for (int k = 0; k < 6; ++k) {  // coef_al is indexed by zig-zag position, like Ss / Se
+                if (coef_al[c][k] != 0) {
+                    return false;
+                }
             }
             int block[64];
             for (int by = 0; by < blocks_h[c]; ++by) {

@@ -85,6 +85,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1024x768", help="WxH of the CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="apd_set_option on the handle (A/B runs), e.g. --opt k67_windows=0; names: fast_rcp early_out source_quads "
+                         "tiled_copy k67_windows k1415_windows.  Reported in config.options")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher / collective plumbing only, on CPU with gloo: no PatchMatch work is done or reported "
                          "(value is null); used by tests/test_bench_launcher.py to cover the --gpus N spawn path without GPUs")
@@ -164,6 +167,7 @@ def main():
         params = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0,
                                     state=pkg.FIRST_INIT, max_iterations=total_iters, seed=args.seed)
         h = pkg.Handle(W, H, params, device=dev.index)
+        apply_options(h, args.opt)
         h.upload_views(cams, sc.images)  # device->device copies: inputs are resident in HBM before timing
     else:
         # untimed: the photometric FIRST_INIT pass of main.cpp:169-190 (3 iterations, weak_peak_radius 6) that
@@ -182,6 +186,7 @@ def main():
                                     max_iterations=total_iters, weak_peak_radius=6, rotate_time=4,
                                     ransac_threshold=0.01 - 0.00125 * 3, seed=args.seed + 1)
         h = pkg.Handle(W, H, params, device=dev.index)
+        apply_options(h, args.opt)
         h.upload_views(cams, sc.images)
         prior = (planes, views, weak)
     del sc.images[:]
@@ -367,7 +372,7 @@ def main():
             "config": {"workload": args.workload, "width": W, "height": H, "num_src": N,
                        "state": "REFINE_INIT+APD" if apd_mode else "FIRST_INIT",
                        "views_per_gpu": 1, "parallelism": "views sharded, %d rank(s)" % world,
-                       "backend": "nccl" if distributed else "single process"},
+                       "backend": "nccl" if distributed else "single process", "options": args.opt},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "weak_path": weak_path,
@@ -386,6 +391,12 @@ def main():
     if distributed:
         dist.destroy_process_group()
     return 0
+
+
+def apply_options(h, opts):
+    for o in opts:
+        name, _, value = o.partition("=")
+        h.set_option(name, int(value))
 
 
 def selftest_cpu(args, world, rank):

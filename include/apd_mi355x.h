@@ -119,8 +119,8 @@ void apd_default_params(apd_params *p);
 
 /* APD::APD(const Problem&) (APD.cpp:356-359) + the allocations of CudaSpaceInitialization
  * (APD.cpp:636-666).  `device` < 0 keeps the current device (reference: cudaSetDevice, main.cpp:153).
- * Limits (APD_ERR_UNSUPPORTED otherwise): width <= 12000, height <= 16384 (16-bit neighbour coordinates, 24-bit index
- * arithmetic, the tiled copy's column / 7 multiply-shift); patch geometry strong 5/2, weak 5/5. */
+ * Limits (APD_ERR_UNSUPPORTED otherwise): width, height <= 16384 (16-bit neighbour coordinates, 24-bit index
+ * arithmetic); patch geometry strong 5/2, weak 5/5. */
 int apd_create(apd_handle *out, int device, int width, int height, const apd_params *params);
 
 /* ~APD (APD.cpp:361-397). */
@@ -180,6 +180,25 @@ int apd_weak_count(apd_handle h);
 int apd_profile_enable(apd_handle h, int on);
 int apd_profile_reset(apd_handle h);
 int apd_profile_get(apd_handle h, int kernel_id, double *total_ms, int *launches);
+
+/* Options of one handle.  The library reads NOTHING from the process environment: every switch is set here, explicitly,
+ * and can be read back.  All options but APD_OPT_FAST_RCP leave every result bit unchanged (they select between
+ * implementations that the test-suite compares bit for bit); APD_OPT_FAST_RCP is a tolerance mode and is off by default.
+ * Options marked (upload) are latched by the next apd_upload_views. */
+enum {
+    APD_OPT_FAST_RCP = 0,       /* 0 (default) exact reciprocals: results are the arithmetic contract's bits.  1: the K6/K7 sample
+                                 * loops stop at v_rcp_f32 (<= 1 ulp), what the reference's --use_fast_math build does
+                                 * (CMakeLists.txt:20); NOT bit-identical, see tests/test_gpu_fast_rcp.py */
+    APD_OPT_EARLY_OUT = 1,      /* 1 (default) exact early-outs of the refinement loops, K14 and K15; 0: every NCC the reference evaluates */
+    APD_OPT_SOURCE_QUADS = 2,   /* (upload) 1 (default) 8-bit inputs are also kept as packed texel pairs; 0: float texel quads for every input */
+    APD_OPT_TILED_COPY = 3,     /* (upload) second, tiled copy of 8-bit sources for random gathers: 0 never, 1 (default) built for FIRST_INIT
+                                 * passes and used while the planes are random (first iteration), 2 built always, used by every global gather */
+    APD_OPT_K67_WINDOWS = 4,    /* 1 (default) K6/K7 with LDS source windows; 0: every sample from HBM */
+    APD_OPT_K1415_WINDOWS = 5,  /* 1 (default) K14/K15 with LDS source windows */
+    APD_OPT_COUNT = 6
+};
+int apd_set_option(apd_handle h, int option, int value);
+int apd_get_option(apd_handle h, int option, int *value);
 
 /* Use an existing HIP stream (hipStream_t) instead of the handle's own. */
 int apd_set_stream(apd_handle h, void *hip_stream);

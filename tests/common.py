@@ -22,10 +22,12 @@ def make_oracle(ob, sc, imgs, N, params, depths=None, prior=None):
                      prior_weak=pr[2])
 
 
-def make_handle(pkg, sc, imgs, N, params, depths=None, prior=None, device=0):
+def make_handle(pkg, sc, imgs, N, params, depths=None, prior=None, device=0, options=None):
     W, H = sc.width, sc.height
     cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
     h = pkg.Handle(W, H, pkg.default_params(**params), device=device)
+    for name, value in (options or {}).items():  # apd_set_option, before the upload latches the upload-time ones
+        h.set_option(name, value)
     h.upload_views(cams, imgs, depths)
     if prior is not None:
         h.upload_prior(*prior)

@@ -1,4 +1,4 @@
-"""APD_FAST_RCP=1: the optional tolerance mode of the strong sweep (K6/K7 sample loops stop at the bare v_rcp_f32, <= 1 ulp, like
+"""apd_set_option(APD_OPT_FAST_RCP, 1): the optional tolerance mode of the strong sweep (K6/K7 sample loops stop at the bare v_rcp_f32, <= 1 ulp, like
 the reference's own --use_fast_math build, CMakeLists.txt:20; no IEEE-division body).  It is NOT the parity target -- exact
 mode stays the default and the only mode compared with the oracle -- so what is checked here is north_star's tolerance
 between the two modes after the reference's three pass kinds at 1024x768: the fraction of pixels whose depth agrees to 1e-3
@@ -13,14 +13,14 @@ import common
 pytestmark = pytest.mark.gpu
 
 
-def _three_passes(pkg, sc, imgs, N, deps):
+def _three_passes(pkg, sc, imgs, N, deps, options=None):
     passes = [dict(state=0, use_APD=0, weak_peak_radius=6),
               dict(state=1, use_APD=1, weak_peak_radius=6, rotate_time=2, ransac_threshold=0.00875),
               dict(state=2, use_APD=1, weak_peak_radius=4, rotate_time=4, ransac_threshold=0.0075, geom_consistency=1)]
     prior = None
     for extra in passes:
         p = common.base_params(sc, N, seed=99, max_iterations=3, **extra)
-        h = common.make_handle(pkg, sc, imgs, N, p, depths=deps if p.get("geom_consistency") else None, prior=prior)
+        h = common.make_handle(pkg, sc, imgs, N, p, depths=deps if p.get("geom_consistency") else None, prior=prior, options=options)
         h.run()
         planes, weak, views = h.download()
         prior = common.postprocess(planes, weak, views, p["depth_min"], p["depth_max"])
@@ -33,15 +33,14 @@ def test_fast_rcp_mode_stays_within_the_stated_tolerance(gpu_pkg, synth, record_
     sc, imgs = common.scene_inputs(synth, W, H, N, seed=8, textureless=0.15)
     gt = sc.gt_depth.numpy()
     deps = [gt.copy() for _ in range(N + 1)]  # any fixed maps do for the geometric term; both modes get the same
-    assert os.environ.get("APD_FAST_RCP") is None
     exact, weak_e = _three_passes(gpu_pkg, sc, imgs, N, deps)
-    os.environ["APD_FAST_RCP"] = "1"
+    fast, weak_f = _three_passes(gpu_pkg, sc, imgs, N, deps, options={"fast_rcp": 1})
+    os.environ["APD_FAST_RCP"] = "1"  # the library reads nothing from the environment any more: this must change no bit
     try:
-        fast, weak_f = _three_passes(gpu_pkg, sc, imgs, N, deps)
+        again, _ = _three_passes(gpu_pkg, sc, imgs, N, deps)
     finally:
         del os.environ["APD_FAST_RCP"]
-    again, _ = _three_passes(gpu_pkg, sc, imgs, N, deps)
-    assert np.array_equal(again.view(np.uint32), exact.view(np.uint32)), "the switch must not leak into later handles"
+    assert np.array_equal(again.view(np.uint32), exact.view(np.uint32)), "the option is per handle and off by default; the environment is ignored"
     assert not np.array_equal(fast.view(np.uint32), exact.view(np.uint32)), "the mode must actually change the arithmetic"
     de, df = exact[..., 3].astype(np.float64), fast[..., 3].astype(np.float64)
     both = (de > 0) & (df > 0)

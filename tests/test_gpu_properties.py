@@ -92,17 +92,18 @@ def test_red_black_independence(gpu_pkg, ob, synth):
 
 def test_window_and_global_kernels_agree(gpu_pkg, synth, monkeypatch):
     """K6/K7 with per-wave LDS source windows (apd_kernels_k67w.hip, default) against the kernel that gathers every
-    sample from HBM (APD_K67_WINDOW=0): all state bit-identical after every iteration at a size where, from the second
+    sample from HBM (APD_OPT_K67_WINDOWS = 0): all state bit-identical after every iteration at a size where, from the second
     iteration on, most NCCs read the windows (the oracle is too slow for this size)."""
     W, H, N, iters = 1536, 1152, 5, 4
     runs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("APD_K67_WINDOW", mode)
         sc = synth.make_scene(W, H, N, seed=2, device="cuda", textureless=0.1)
         cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
         p = gpu_pkg.default_params(num_images=N + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0,
                                    state=gpu_pkg.FIRST_INIT, max_iterations=iters, seed=31)
         h = gpu_pkg.Handle(W, H, p, device=0)
+        h.set_option("k67_windows", int(mode))
+        assert h.get_option("k67_windows") == int(mode)
         h.upload_views(cams, sc.images)
         for k in (1, 2, 5):
             h.run_kernel(k)
@@ -118,13 +119,12 @@ def test_window_and_global_kernels_agree(gpu_pkg, synth, monkeypatch):
 
 def test_window_and_global_post_loop_kernels_agree(gpu_pkg, synth, monkeypatch):
     """K14 DepthToWeak / K15 LocalRefine with LDS source windows (apd_kernels_k1415w.hip, default) against the
-    window-less kernels (APD_K1415_WINDOW=0): identical weak map and depths after a complete pass, photometric and with
+    window-less kernels (APD_OPT_K1415_WINDOWS = 0): identical weak map and depths after a complete pass, photometric and with
     the geometric term, at a size the oracle cannot reach."""
     import torch
     W, H, N = 1280, 960, 5
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("APD_K1415_WINDOW", mode)
         sc = synth.make_scene(W, H, N, seed=4, device="cuda", textureless=0.15)
         cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
         dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
@@ -134,6 +134,7 @@ def test_window_and_global_post_loop_kernels_agree(gpu_pkg, synth, monkeypatch):
             p = gpu_pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0, state=state, max_iterations=2,
                                        weak_peak_radius=6, geom_consistency=geom, seed=77)
             h = gpu_pkg.Handle(W, H, p, device=0)
+            h.set_option("k1415_windows", int(mode))
             deps = [sc.gt_depth] * (N + 1) if geom else None   # stand-in depth maps of the sources
             h.upload_views(cams, sc.images, deps)
             if prior is not None:
@@ -151,14 +152,13 @@ def test_window_and_global_post_loop_kernels_agree(gpu_pkg, synth, monkeypatch):
 
 def test_early_outs_change_no_bit(gpu_pkg, synth, monkeypatch):
     """The exact early-outs (refinement hypotheses of K6/K7 and K9/K10 that can no longer beat the running cost, K15's depth
-    samples that cannot be adopted, K14's centre-first classification) against APD_EARLY_OUT=0, which
+    samples that cannot be adopted, K14's centre-first classification) against APD_OPT_EARLY_OUT = 0, which
     evaluates every NCC the reference evaluates: every state array identical after each of the three pass kinds, weak
     pixels and the geometric term included, at a size the oracle cannot reach."""
     import torch
     W, H, N = 1024, 768, 6
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("APD_EARLY_OUT", mode)
         sc = synth.make_scene(W, H, N, seed=9, device="cuda", textureless=0.25)
         cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
         dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
@@ -171,6 +171,7 @@ def test_early_outs_change_no_bit(gpu_pkg, synth, monkeypatch):
         for pi, extra in enumerate(passes):
             p = gpu_pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, max_iterations=3, seed=41 + pi, **extra)
             h = gpu_pkg.Handle(W, H, p, device=0)
+            h.set_option("early_out", int(mode))
             deps = [sc.gt_depth] * (N + 1) if extra.get("geom_consistency") else None
             h.upload_views(cams, sc.images, deps)
             if prior is not None:

@@ -282,6 +282,7 @@ def test_malformed_jpegs_never_leave_their_buffers(tmp_path):
         Image.fromarray(img if mode == "RGB" else img[..., 0], mode).save(p, quality=85, **kw)
         seeds.append(p.read_bytes())
     files = []
+    must_refuse = []
 
     def emit(data):
         p = tmp_path / ("m%04d.jpg" % len(files))
@@ -304,6 +305,24 @@ def test_malformed_jpegs_never_leave_their_buffers(tmp_path):
         emit(d)
         for cut in (2, 10, sos, sos + 5, sos + 12, len(data) // 2, len(data) - 2):  # truncations
             emit(data[:cut])
+        # a second frame header (it used to replace width / height / sampling under coefficient arrays and planes
+        # sized for the first one -> heap overflow in the next scan, out-of-bounds read in the final copy): larger frame,
+        # placed before the second scan, before the last scan and right before EOI
+        sof = max(data.find(b"\xff\xc0"), data.find(b"\xff\xc2"))
+        assert 0 < sof < sos
+        seg = bytearray(data[sof:sof + 2 + int.from_bytes(data[sof + 2:sof + 4], "big")])
+        seg[5:7] = (512).to_bytes(2, "big")
+        seg[7:9] = (512).to_bytes(2, "big")
+        scans = [i for i in range(sos, len(data) - 1) if data[i] == 0xFF and data[i + 1] == 0xDA]
+        eoi = data.rfind(b"\xff\xd9")
+        progressive = data[sof + 1] == 0xC2
+        for at in sorted({scans[min(1, len(scans) - 1)], scans[-1], eoi}):
+            if at <= scans[-1] or progressive:  # a sequential file is complete after its last scan: trailing markers are not read
+                must_refuse.append(len(files))
+            emit(data[:at] + bytes(seg) + data[at:])
+        if len(scans) > 1:  # progressive: a file that stops after its first scans (EOI appended) is incomplete -> refused, not
+            must_refuse.append(len(files))  # decoded without libjpeg's block smoothing
+            emit(data[:scans[1]] + b"\xff\xd9")
         for _ in range(60):  # random flips in the headers (before the scan data) and in the entropy-coded segment
             d = bytearray(data)
             for _ in range(rng.randint(1, 4)):
@@ -318,6 +337,9 @@ def test_malformed_jpegs_never_leave_their_buffers(tmp_path):
     assert intact and "grey=1 colour=1" in intact[0]
     refused = sum("grey=0" in ln for ln in lines)
     assert refused > 20, "the crafted selector / truncated files must be refused"
+    assert len(must_refuse) >= 10
+    for i in must_refuse:
+        assert "grey=0 colour=0" in lines[i], "duplicate SOF / incomplete progressive file was decoded: " + lines[i]
 
 
 @pytest.mark.parametrize("rows,cols,scale", [(4130, 6200, 8), (4130, 6200, 4), (4130, 6200, 2), (1080, 1920, 2), (517, 775, 2), (33, 47, 4)])

@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of run-time switches on the GPU box (no rebuild): tools/ab.sh "<ENV=.. ENV=..>" "<...>" ; workload via TUNE_WORKLOAD
+# A/B of library options on the GPU box (no rebuild): tools/ab.sh "<--opt name=value ...>" "<...>" ; workload via TUNE_WORKLOAD
 WL=${TUNE_WORKLOAD:-synthetic_4096x3072_8src}
 ARGS="--workload $WL --steps ${TUNE_STEPS:-3} --warmup 1 --no-cpu-baseline"
 for e in "$@"; do
-  echo "== env: [$e] workload $WL"
-  env $e timeout 600 python bench.py $ARGS 2>/dev/null | python -c "
+  echo "== options: [$e] workload $WL"
+  timeout 600 python bench.py $ARGS $e 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.readline())
 w=d.get('weak_path') or {}
 it=d.get('iterations') or {}
