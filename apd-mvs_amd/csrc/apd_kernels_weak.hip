@@ -528,24 +528,24 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
     }
 }
 
+// Every lane of the wave calls this (wave-uniform control flow: the sub-patch gathers are cooperative, see
+// subpatch_cost_quad_coop); `want` = this lane really scores (plane, view).  The value of a lane that does not is unspecified.
 template <bool kQuad, typename Ref>
 __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLdsT<kQuad> &lds,
-                                              int lane, int px, int py, const float4 pl)
+                                              uint32_t *xchg, int lane, int px, int py, const float4 pl, bool want)
 {
     float qx, qy, qz;
     plane_q(pl, qx, qy, qz);
     const Homography H = make_homography(fa, vc, qx, qy, qz);
     float cx, cy;
     correspond(H, (float)px, (float)py, cx, cy);
-    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
-        return 2.0f;
-    }
+    // a centre that projects outside the source image costs 2.0 (:546); such a lane scores no sub-patch either
+    const bool inside_src = want && !(cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f);
     // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above)
-#ifdef APD_EXPERIMENT_WEAK_NO_CENTRE  // timing experiment only: sub-patches alone
-    const float center_cost = 0.5f;
-#else
-    const float center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
-#endif
+    float center_cost = 2.0f;
+    if (inside_src) {
+        center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+    }
     const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
     const unsigned qpitch = quad_row_pitch_bytes(fa.W);
     const unsigned fpitch = 16u * (unsigned)(fa.W + 1);
@@ -553,115 +553,70 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
     const int wm1 = fa.W - 1, hm1 = fa.H - 1;
     float strong_cost = 0.0f;
     int strong_count = 0;
-#ifdef APD_EXPERIMENT_WEAK_NO_SUB  // timing experiment only: centre patch alone
-    return center_cost;
-#endif
-#ifdef APD_EXPERIMENT_WEAK_NB  // timing experiment only: sub-patches of the first APD_EXPERIMENT_WEAK_NB neighbours
-    constexpr int kNbEnd = APD_EXPERIMENT_WEAK_NB;
-#else
-    constexpr int kNbEnd = 8;
-#endif
-#ifndef APD_K910_PIPELINE
-#define APD_K910_PIPELINE 0  // measured on configs[2]: 73.0 ms per launch with the pipeline, 71.8 ms without (profiles/r02/ab_pipe.txt)
-#endif
-#if APD_K910_PIPELINE && !defined(APD_EXPERIMENT_WEAK_NB)
-    if constexpr (kQuad) {
-        // Experiment (off): software pipeline over the eight neighbours; the nine gathers of sub-patch k + 1 are in flight
-        // while sub-patch k is interpolated and reduced (201 registers, still two waves per SIMD).  Bit-identical, not faster.
-        // The costs are still added in neighbour order (`retire` runs for k = 0, 1, ..., 7), including the 2.0 of a
-        // neighbour that projects outside the image, so nothing changes bitwise.
-        float aA[kSubN * kSubN], bA[kSubN * kSubN], aB[kSubN * kSubN], bB[kSubN * kSubN];
-        quad_t tA[kSubN * kSubN], tB[kSubN * kSubN];
-        // kind of a prepared neighbour: 0 contributes nothing, 1 adds 2.0 (outside the image, view selected there), 2 sub-patch in flight
-        auto prepare = [&](int k, float (&a)[kSubN * kSubN], float (&b)[kSubN * kSubN], quad_t (&t)[kSubN * kSubN]) -> int {
-            const int packed = lds.nb[k][lane];
-            if (packed == -1) {
-                return 0;
-            }
-            const int nbx = (int)(short)(packed & 0xFFFF), nby = packed >> 16;
-            float nx, ny;
-            correspond(H, (float)nbx, (float)nby, nx, ny);
-            if (nx < 0 || ny < 0 || nx >= (float)fa.W || ny >= (float)fa.H) {
-                const uint32_t vi = fa.selected_views[nbx + nby * fa.W];
-                return bit_test(vi, (unsigned)v) ? 1 : 0;
-            }
-            const bool fast = denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep));
-            if (__builtin_amdgcn_ballot_w64(!fast) == 0) {  // one body per wave and sub-patch (see below)
-                subpatch_issue_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, a, b, t);
-            } else {
-                subpatch_issue_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, a, b, t);
-            }
-            return 2;
-        };
-        auto retire = [&](int kind, int k, const float (&a)[kSubN * kSubN], const float (&b)[kSubN * kSubN], const quad_t (&t)[kSubN * kSubN]) {
-            if (kind == 1) {
-                strong_cost += 2.0f;
-                strong_count++;
-            } else if (kind == 2) {
-                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-                strong_cost += subpatch_finish_quad(t, a, b, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
-                strong_count++;
-            }
-        };
-        int kindA = 0, kindB = 0;
 #pragma unroll 1
-        for (int k = 0; k < 8; k += 2) {
-            kindA = prepare(k, aA, bA, tA);
-            if (k > 0) {
-                retire(kindB, k - 1, aB, bB, tB);
-            }
-            kindB = prepare(k + 1, aB, bB, tB);
-            retire(kindA, k, aA, bA, tA);
-        }
-        retire(kindB, 7, aB, bB, tB);
-        if (strong_count == 0) {
-            return center_cost;
-        }
-        strong_cost /= (float)strong_count;
-        strong_cost = (strong_cost > 2.0f) ? 2.0f : strong_cost;
-        return (float)(0.25 * (double)center_cost + 0.75 * (double)strong_cost);
-    }
-#endif
-#pragma unroll 1
-    for (int k = 0; k < kNbEnd; ++k) {
+    for (int k = 0; k < 8; ++k) {
         const int packed = lds.nb[k][lane];
-        if (packed == -1) {
-            continue;
-        }
+        bool active = inside_src && packed != -1;
         const int nbx = (int)(short)(packed & 0xFFFF), nby = packed >> 16;
         float nx, ny;
         correspond(H, (float)nbx, (float)nby, nx, ny);
-        if (nx < 0 || ny < 0 || nx >= (float)fa.W || ny >= (float)fa.H) {
-            const uint32_t vi = fa.selected_views[nbx + nby * fa.W];
+        if (active && (nx < 0 || ny < 0 || nx >= (float)fa.W || ny >= (float)fa.H)) {
+            const uint32_t vi = fa.selected_views[nbx + nby * fa.W];  // counts 2.0 only if that neighbour selected this view (:439-449)
             if (bit_test(vi, (unsigned)v)) {
                 strong_cost += 2.0f;
                 strong_count++;
             }
-            continue;
+            active = false;
         }
-        float c;
         // one nine-sample body per wave and sub-patch: the IEEE division gives the bits of the fast reciprocal wherever that
         // one is valid, so if one lane needs it (a sign change or an extreme denominator under a random normal) all take it
         const bool fast = denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep));
-        if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
-            if constexpr (kQuad) {
-                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-                c = subpatch_cost_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+        if constexpr (kQuad) {
+            if (__builtin_amdgcn_ballot_w64(active) == 0) {
+                continue;  // wave-uniform
+            }
+            const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
+            float c;
+#ifdef APD_LAB_K910_NO_COOP  // A/B: every lane gathers its own nine taps
+            c = 0.0f;
+            if (active) {
+                if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
+                    c = subpatch_cost_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+                } else {
+                    c = subpatch_cost_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+                }
+            }
+#else
+            if (__builtin_amdgcn_ballot_w64(active && !fast) == 0) {
+                c = subpatch_cost_quad_coop<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, active, ref_rows, lds.mean[k][lane],
+                                                         lds.var[k][lane], xchg, lane);
             } else {
-                c = subpatch_cost_fquad<kRecipExact>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
-                                                     lds.var[k][lane]);
+                c = subpatch_cost_quad_coop<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, active, ref_rows, lds.mean[k][lane],
+                                                        lds.var[k][lane], xchg, lane);
+            }
+#endif
+            if (active) {
+                strong_cost += c;
+                strong_count++;
             }
         } else {
-            if constexpr (kQuad) {
-                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-                c = subpatch_cost_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+            if (!active) {
+                continue;
+            }
+            float c;
+            if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
+                c = subpatch_cost_fquad<kRecipExact>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
+                                                     lds.var[k][lane]);
             } else {
                 c = subpatch_cost_fquad<kRecipIeee>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
                                                     lds.var[k][lane]);
             }
+            strong_cost += c;
+            strong_count++;
         }
-        strong_cost += c;
-        strong_count++;
+    }
+    if (!inside_src) {
+        return 2.0f;
     }
     if (strong_count == 0) {
         return center_cost;
@@ -790,6 +745,11 @@ __device__ __forceinline__ float4 candidate_plane(const FrameArgs &fa, const sho
 
 // Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
 // plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
+//
+// One wave per workgroup, one lane per list entry.  The sub-patch gathers of ncc_deformed are cooperative, so every call of
+// it sits in wave-uniform control flow: a lane that has nothing to score for a (hypothesis, view) -- an invalid candidate, an
+// unselected view, a refinement hypothesis that can no longer win, the padding lanes of the last wave -- stays in the wave
+// with want = false while any other lane scores, and is skipped with the whole wave otherwise (ballots).
 #ifndef APD_K910_WAVES
 #define APD_K910_WAVES 2
 #endif
@@ -797,27 +757,16 @@ template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, int count, int per_xcd)
 {
     __shared__ WeakLdsT<kQuad> lds;
-    // Round 1 (4-byte quads): bound by the L1/L2 traffic of the scattered sub-patch gathers, and six waves per CU evicted each
-    // other's lines less than the eight the registers allow, so an LDS pad capped the count (ms per launch at 4096x3072,
-    // 18 % WEAK: 8 waves 38.9, 7: 37.4, 6: 36.8, 5: 38.0, 4: 39.9, 3: 48.8).  With the 2-byte column-pair copy (half the
-    // footprint, L2 hit rate 56 -> 70 %) the kernel is latency-bound instead and the pad is gone (configs[2]: 76.9 -> 71.6 ms).
-#ifndef APD_K910_LDS_PAD_KB
-#define APD_K910_LDS_PAD_KB 0  // round 2: with the 2-byte column-pair source copy eight waves per CU no longer thrash (76.9 -> 71.6 ms)
-#endif
-    constexpr int kPadBytes = kQuad ? APD_K910_LDS_PAD_KB * 1024 : 0;
-    if constexpr (kPadBytes > 0) {
-        __shared__ char lds_pad[kPadBytes > 0 ? kPadBytes : 1];
-        if (blockIdx.x == 0x7fffffff) {
-            lds_pad[threadIdx.x] = 1;
-        }
-    }
+    __shared__ uint32_t xchg[kQuad ? kXchgDwords : 1];
     const int lane = threadIdx.x;
-    const int gid = weak_chunk_of_block(blockIdx.x, per_xcd) * 64 + lane;
-    if (gid >= count) {
-        return;
+    const int first = weak_chunk_of_block(blockIdx.x, per_xcd) * 64;
+    if (first >= count) {
+        return;  // the whole wave lies beyond the list
     }
+    // padding lanes of the last wave repeat the last entry (they lend their gathers) and never store anything
+    const bool lane_valid = first + lane < count;
     const int W = fa.W;
-    const int center = list[gid];
+    const int center = list[min(first + lane, count - 1)];
     const int py = center / W, px = center - py * W;
     const int nsrc = fa.num_src;
     const short2 *nb = &fa.neighbours[(size_t)fa.neighbours_map[center] * APD_NEIGHBOUR_NUM];
@@ -848,8 +797,11 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
     float4 plane_now = fa.planes[center];
     float4 plane_final = plane_now;
     float depth_now = 0.0f, cost_now = 0.0f, cost_committed = 0.0f;
-    float ref_depths[5];
+    float ref_depths[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     float4 ref_normals[5];
+    for (int k = 0; k < 5; ++k) {
+        ref_normals[k] = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
+    }
     bool skip_refine = false;
 
     // ---- candidates: the eight reliable neighbours' planes (must still be STRONG, :1354) + the current plane ----
@@ -868,11 +820,15 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
         const ViewConst &vc = view_const(fa, v);
 #pragma unroll 1
         for (int h = 0; h < 9; ++h) {
-            if (h < 8 && !(flags & (1u << h))) {
+            const bool want = h == 8 || (flags & (1u << h)) != 0;
+            if (__builtin_amdgcn_ballot_w64(want) == 0) {
                 continue;
             }
-            const float4 pl = (h < 8) ? candidate_plane(fa, nb, h) : plane_now;
-            cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
+            const float4 pl = (h < 8 && want) ? candidate_plane(fa, nb, h) : plane_now;
+            const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, xchg, lane, px, py, pl, want);
+            if (want) {
+                cost_array[h][v] = c;
+            }
         }
     }
 
@@ -896,7 +852,9 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                 }
             }
             select_views<NMAX>(fa, iter, cost_array, priors, rng, vw, sel, weight_norm);
-            vw.store(fa, center);
+            if (lane_valid) {
+                vw.store(fa, center);
+            }
             float final_costs[8];
             for (int i = 0; i < 8; ++i) {
                 float f = 0.0f;
@@ -941,7 +899,9 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                     depth_now = d;
                     plane_now = cand_best;
                     cost_now = final_costs[best];
-                    fa.selected_views[center] = sel;
+                    if (lane_valid) {
+                        fa.selected_views[center] = sel;
+                    }
                 }
             }
             // PlaneHypothesisRefinementWeak: fit plane first (:910-936)
@@ -966,9 +926,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             pl = ref_normals[h - 10];
             pl.w = distance_to_origin(fa, px, py, ref_depths[h - 10], pl.x, pl.y, pl.z);
         }
-        if (h <= 14 && skip_refine) {
-            continue;
-        }
+        const bool scores = !(h <= 14 && skip_refine);  // this lane evaluates hypothesis h at all
         float tc = 0.0f;
         // hypotheses 9..14 are only compared with the running cost (:932, :974): a partial sum that has reached `lost`
         // cannot win any more and the remaining views are skipped (refinement_lost_bound, apd_sweep.h; the geometric term
@@ -976,22 +934,23 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
         const float lost = (h <= 14 && !(fa.geom_factor < 0.0f)) ? refinement_lost_bound(fa, cost_now, weight_norm) : __builtin_inff();
 #pragma unroll 1
         for (int v = 0; v < nsrc; ++v) {
-            const ViewConst &vc = view_const(fa, v);
-            if (vw.get(v) == 0) {
-                // the cost of an unselected view is never used (:966-972); in the re-score it is multiplied by a zero
-                // weight (:1503) and, being a finite value in [0, 2], adds exactly +0
+            // the cost of an unselected view is never used (:966-972); in the re-score it is multiplied by a zero weight
+            // (:1503) and, being a finite value in [0, 2], adds exactly +0.  tc only grows while it is below `lost`, so
+            // "tc >= lost" stays true once reached: the lane sits out the remaining views.
+            const bool want = scores && vw.get(v) != 0 && !(tc >= lost);
+            if (__builtin_amdgcn_ballot_w64(want) == 0) {
                 continue;
             }
-            if (tc >= lost) {
-                break;
-            }
+            const ViewConst &vc = view_const(fa, v);
             if (h == 15) {
-                float qx, qy, qz;
-                plane_q(pl, qx, qy, qz);
-                tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
+                if (want) {
+                    float qx, qy, qz;
+                    plane_q(pl, qx, qy, qz);
+                    tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
+                }
             } else {
-                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
-                {
+                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, xchg, lane, px, py, pl, want);
+                if (want) {
                     if (fa.geom_consistency) {
                         tc += (float)vw.get(v) * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
                     } else {
@@ -999,6 +958,9 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                     }
                 }
             }
+        }
+        if (!scores) {
+            continue;
         }
         if (h <= 14) {
             tc /= weight_norm;
@@ -1008,12 +970,14 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                 plane_now = pl;
                 cost_now = tc;
             }
-        } else {
+        } else if (lane_valid) {
             fa.costs[center] = tc / weight_norm;
             fa.planes[center] = plane_final;
         }
     }
-    rng_store(fa.rng, center, rng);
+    if (lane_valid) {
+        rng_store(fa.rng, center, rng);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
