@@ -534,7 +534,15 @@ void APD::InuputInitialization()
         depths.push_back(ref_depth);
         for (int src_idx : problem.src_image_ids) {
             Mat src_depth;
-            ReadBinMat(problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx)) / path("depths.dmb"), src_depth);
+            const path src_folder = problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx));
+            if (!std::filesystem::exists(src_folder)) {
+                // A source that is not reconstructed itself (no pair.txt entry, hence no result folder): the reference reads a
+                // file that is not there and goes on with an unspecified matrix (APD.cpp:497-506); here the view has no
+                // estimate anywhere (depth 0), which the geometric term prices like any pixel without a depth.
+                src_depth.create(height, width, MAT_32FC1);  // zero-filled
+            } else {
+                ReadBinMat(src_folder / path("depths.dmb"), src_depth);
+            }
             depths.push_back(src_depth);
         }
         for (auto &depth : depths) {

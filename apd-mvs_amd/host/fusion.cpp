@@ -147,7 +147,12 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
     for (size_t i = 0; i < problems.size(); ++i) {
         std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
         for (int id : problems[i].src_image_ids) {
-            sources[i].push_back(index_of_id[id]);  // operator[]: an id without a problem maps to view 0, as in the reference
+            // A source without a problem of its own has no maps to check against and is skipped.  (The reference's
+            // imageIdToindexMap[id] default-inserts 0 for it, APD.cpp:919, i.e. silently checks against view 0 instead.)
+            const auto it = index_of_id.find(id);
+            if (it != index_of_id.end()) {
+                sources[i].push_back(it->second);
+            }
         }
     }
     const path ply_path = dense_folder / path("APD") / path("APD.ply");

@@ -286,24 +286,15 @@ int main(int argc, char **argv)
     }
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-    {   // A source needs an entry of its own: geometric passes read its depths.dmb (APD.cpp:492-509) and RunFusion looks
-        // its view up by id (APD.cpp:899; an unknown id silently becomes view 0 there).  The reference fails on such a
-        // folder in its first geometric pass; here it is refused before any work (apd-mvs_amd/pipeline.py does the same).
-        std::vector<int> refs;
-        for (const Problem &p : problems) {
-            refs.push_back(p.ref_image_id);
-        }
-        std::sort(refs.begin(), refs.end());
-        for (const Problem &p : problems) {
-            for (int s : p.src_image_ids) {
-                if (s == p.ref_image_id) {
-                    fprintf(stderr, "pair.txt: view %d lists itself as a source\n", s);
-                    return EXIT_FAILURE;
-                }
-                if (!std::binary_search(refs.begin(), refs.end(), s)) {
-                    fprintf(stderr, "pair.txt: view %d lists source %d, which has no entry of its own\n", p.ref_image_id, s);
-                    return EXIT_FAILURE;
-                }
+    // Sources without an entry of their own (a subset of the views is reconstructed) are loaded like any other image
+    // (APD.cpp:419-452): they contribute no depth map to the geometric term and take no part in the fusion (host/APD.cpp,
+    // host/fusion.cpp; apd-mvs_amd/pipeline.py does the same).  A view that lists itself is refused: the fusion would count it
+    // as its own witness.
+    for (const Problem &p : problems) {
+        for (int s : p.src_image_ids) {
+            if (s == p.ref_image_id) {
+                fprintf(stderr, "pair.txt: view %d lists itself as a source\n", s);
+                return EXIT_FAILURE;
             }
         }
     }

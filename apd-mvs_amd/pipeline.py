@@ -28,14 +28,18 @@ from . import sharding
 
 @dataclass
 class MvsScene:
-    """cameras[i] (full resolution, `apd_camera`), images[i] (float32 [H, W]), pairs[i] = source view ids of view i."""
+    """cameras[i] (full resolution, `apd_camera`), images[i] (float32 [H, W]), pairs[i] = source view ids of view i.
+    Views 0 .. num_views-1 are reference views (one pair.txt entry each).  Further cameras / images, if any, are SOURCE-ONLY
+    views: images that pair.txt lists as sources but that have no entry of their own (a subset run).  The reference simply
+    loads them (APD.cpp:419-452); they are never processed, contribute no depth map to the geometric term (the reference
+    reads a file that does not exist there, APD.cpp:497-500) and take no part in the fusion."""
     cameras: list
     images: list
     pairs: list
 
     @property
     def num_views(self):
-        return len(self.images)
+        return len(self.pairs)
 
 
 @dataclass
@@ -262,6 +266,9 @@ def run_pipeline(scene, backend, iters=3, seed=12345, single_level=False, group=
             p["seed"] = seed + spec.iteration_index * 7919 + idx
             depths = None
             if p["geom_consistency"]:
+                for j in order:
+                    if j >= V and j not in depth_store:  # source-only view: no estimate anywhere
+                        depth_store[j] = torch.zeros((H, W), dtype=torch.float32, device=device)
                 depths = [rescale_nearest(depth_store[j], W, H).contiguous() for j in order]
             prior = None
             if p["state"] != 0:
@@ -365,15 +372,16 @@ def load_dense_folder(folder, camera_type):
                 srcs.append(sid)
         src_ids.append(srcs)
     index_of = {v: i for i, v in enumerate(ids)}
-    # A source needs an entry of its own: geometric passes read its depth map (APD.cpp:492-509) and the fusion looks its view
-    # up by id (APD.cpp:899; an unknown id silently becomes view 0 there).  The drop-in binary refuses such folders with the
-    # same message (host/main.cpp), so the two schedulers cannot diverge on them.
+    # Sources without an entry of their own (a subset of the views is reconstructed): loaded as source-only views after the
+    # reference views, like the reference loads any id it is given (APD.cpp:419-452).
+    extra = []
     for v, srcs in zip(ids, src_ids):
         for s_id in srcs:
-            if s_id not in index_of:
-                raise ValueError("pair.txt: view %d lists source %d, which has no entry of its own" % (v, s_id))
             if s_id == v:
                 raise ValueError("pair.txt: view %d lists itself as a source" % v)
+            if s_id not in index_of:
+                index_of[s_id] = len(ids) + len(extra)
+                extra.append(s_id)
     def load_view(v):
         cam = camera_type()
         if L.apdhost_read_camera(os.path.join(folder, "cams", "%08d_cam.txt" % v).encode(), C.byref(cam)) != 0:
@@ -390,11 +398,11 @@ def load_dense_folder(folder, camera_type):
     # the decoder runs outside the GIL (ctypes) and the host library's image cache is locked: one thread per image
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(16, max(1, len(ids)))) as pool:
-        loaded = list(pool.map(load_view, ids))
+        loaded = list(pool.map(load_view, ids + extra))
     cams = [c for c, _ in loaded]
     imgs = [im for _, im in loaded]
     scene = MvsScene(cams, imgs, [[index_of[s] for s in srcs] for srcs in src_ids])
-    scene.ids = ids
+    scene.ids = ids + extra   # image id of every loaded view; the first scene.num_views are the reference views
     return scene
 
 
@@ -481,7 +489,7 @@ def fuse(scene, results, ply_path, device=0, colour_images=None, block_masks=Non
     flat = []
     for v in range(V):
         offs[v] = len(flat)
-        flat += list(scene.pairs[v])
+        flat += [s for s in scene.pairs[v] if s < V]  # source-only views have no maps to check against
     offs[V] = len(flat)
     idx = (C.c_int * max(len(flat), 1))(*flat)
 

@@ -175,6 +175,37 @@ def test_pipeline_cli_writes_the_binarys_files(gpu_pkg, synth, tmp_path):
             assert fa.read_bytes() == fb.read_bytes(), (idx, name)
 
 
+def test_subset_of_views_with_source_only_images(gpu_pkg, synth, tmp_path):
+    """pair.txt reconstructs views 0..2 only, but their sources include image 3, which has no entry of its own: the
+    reference just loads it (APD.cpp:419-452).  Both schedulers accept the folder, write identical maps and the identical
+    cloud; the source-only view gets no result folder."""
+    import shutil
+    import sys
+    W, H, nviews, seed = 72, 56, 4, 5
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    _write_dense_folder(a, synth, W, H, nviews, jpeg=False)
+    pair = "3\n"
+    for i in range(3):
+        srcs = [j for j in range(nviews) if j != i]
+        pair += "%d\n%d %s\n" % (i, len(srcs), " ".join("%d %.1f" % (j, 10.0 - k) for k, j in enumerate(srcs)))
+    (a / "pair.txt").write_text(pair)
+    shutil.copytree(a, b)
+    r = subprocess.run([APD_BIN, str(a), "0", "--seed", str(seed), "--iters", "1", "--keep-maps"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mvs_pipeline.py"), str(b), "--seed", str(seed), "--iters", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    for idx in range(3):
+        for name in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
+            fa, fb = a / "APD" / ("%08d" % idx) / name, b / "APD" / ("%08d" % idx) / name
+            assert fa.read_bytes() == fb.read_bytes(), (idx, name)
+    assert not (a / "APD" / "00000003").exists() and not (b / "APD" / "00000003").exists()
+    pa, pb = (a / "APD" / "APD.ply").read_bytes(), (b / "APD" / "APD.ply").read_bytes()
+    assert pa == pb and len(_read_ply(a / "APD" / "APD.ply")[0]) > 0
+
+
 def _read_ply(path):
     raw = open(path, "rb").read()
     head, body = raw.split(b"end_header\n", 1)

@@ -103,6 +103,43 @@ def test_two_ranks_jacobi_vs_one_rank_gauss_seidel(pkg, synth, ob, tmp_path):
         assert (np.abs(d1[ok] - d2[ok]) <= 0.05 * d2[ok]).mean() > 0.8
 
 
+def test_source_only_views_are_loaded_not_processed(pkg, synth, ob, tmp_path):
+    """A subset run: pair.txt has entries for views 0..2, whose sources include image 3 (no entry of its own).  The reference
+    loads such an image like any other (APD.cpp:419-452).  The scheduler processes three views, gives the geometric term an
+    empty (all-zero) depth map for the fourth, and view 0 -- whose sources are full views -- ends exactly as in the run that
+    reconstructs all four."""
+    from apd_mvs_amd import pipeline
+    full = pipeline.synthetic_ring(synth, 40, 32, 4, 2, ob.make_camera, seed=3)
+    assert 3 in full.pairs[2] and 3 not in full.pairs[0]
+    subset = pipeline.MvsScene(full.cameras, full.images, full.pairs[:3])
+    assert subset.num_views == 3 and len(subset.images) == 4
+    out_full = pipeline.run_pipeline(full, OracleBackend(), iters=1, seed=5, max_passes=2)
+    out = pipeline.run_pipeline(subset, OracleBackend(), iters=1, seed=5, max_passes=2)
+    assert sorted(out) == [0, 1, 2]
+    for k in ("depth", "normal", "weak", "views"):
+        assert np.array_equal(getattr(out[0], k), getattr(out_full[0], k)), k
+    assert (out[2].depth > 0).mean() > 0.5
+    # the loader builds such a scene from a folder: reference views first, source-only images after them
+    (tmp_path / "images").mkdir()
+    (tmp_path / "cams").mkdir()
+    for i in range(4):
+        img = np.clip(full.images[i], 0, 255).astype(np.uint8)
+        (tmp_path / "images" / ("%08d.pgm" % (10 + i))).write_bytes(b"P5\n%d %d\n255\n" % (40, 32) + img.tobytes())
+        cam = full.cameras[i]
+        R, t, K = list(cam.R), list(cam.t), list(cam.K)
+        txt = "extrinsic\n" + "".join("%.9g %.9g %.9g %.9g\n" % (R[3 * r], R[3 * r + 1], R[3 * r + 2], t[r]) for r in range(3))
+        txt += "0 0 0 1\n\nintrinsic\n" + "".join("%.9g %.9g %.9g\n" % tuple(K[3 * r:3 * r + 3]) for r in range(3))
+        txt += "\n%.9g 0.01 192 %.9g\n" % (cam.depth_min, cam.depth_max)
+        (tmp_path / "cams" / ("%08d_cam.txt" % (10 + i))).write_text(txt)
+    (tmp_path / "pair.txt").write_text("2\n10\n2 11 5.0 13 4.0\n11\n3 10 5.0 13 4.0 12 0.0\n")
+    scene = pipeline.load_dense_folder(str(tmp_path), type(full.cameras[0]))
+    assert scene.num_views == 2 and scene.ids == [10, 11, 13] and scene.pairs == [[1, 2], [0, 2]]   # score 0 dropped (main.cpp:41)
+    assert len(scene.images) == 3 and np.array_equal(scene.images[2], np.clip(full.images[3], 0, 255).astype(np.uint8).astype(np.float32))
+    (tmp_path / "pair.txt").write_text("1\n10\n1 10 5.0\n")
+    with pytest.raises(ValueError):
+        pipeline.load_dense_folder(str(tmp_path), type(full.cameras[0]))
+
+
 def test_rescale_nearest_tensor_path_matches_numpy(pkg):
     """The device-resident pipeline resamples prior state with torch (RescaleMatToTargetSize, APD.cpp:752-774, swapped
     factors included); it must pick exactly the pixels the numpy / C++ host version picks, for every dtype it carries."""

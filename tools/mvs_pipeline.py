@@ -49,7 +49,7 @@ def main():
         pipeline.save_results(args.dense_folder, scene, results)
         if not args.no_fusion:
             tf = time.time()
-            colour = pipeline.load_colour_images(args.dense_folder, getattr(scene, "ids", list(range(scene.num_views))))
+            colour = pipeline.load_colour_images(args.dense_folder, getattr(scene, "ids", list(range(scene.num_views)))[:scene.num_views])
             n = pipeline.fuse(scene, results, os.path.join(args.dense_folder, "APD", "APD.ply"), device=local_rank, colour_images=colour)
             print("fused %d points into APD/APD.ply in %.2f s" % (n, time.time() - tf), flush=True)
         print("PatchMatch passes done in %.1f s; maps written under %s" % (time.time() - t0, os.path.join(args.dense_folder, "APD")), flush=True)
