@@ -18,7 +18,7 @@ namespace apd {
 hipError_t launch_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s);
 hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipStream_t s, const int *const weak_list[2], const int weak_count[2]);
 size_t weak_list_scratch_ints(int W, int H);
-hipError_t build_weak_lists(const FrameArgs &fa, int *const list[2], int *scratch, int counts[2], hipStream_t s);
+hipError_t build_weak_lists(const FrameArgs &fa, bool all_rows, int *const list[2], int *scratch, int counts[2], hipStream_t s);
 hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s);
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s);
 hipError_t launch_weak_index_map(const uint8_t *weak, size_t n, int *map, int *scratch, hipStream_t s);
@@ -83,6 +83,7 @@ struct apd_context {
     int *weak_list_scratch = nullptr;
     int weak_list_count[2] = {0, 0};
     bool weak_lists_valid = false;
+    bool weak_lists_all_rows = false;  // the valid lists were built for K3 (every row) / for K9, K10 (rows of the HALF launches)
     int options[APD_OPT_COUNT] = {0, 1, 1, 1, 1, 1};  // defaults of include/apd_mi355x.h
     int *neighbours_map = nullptr;
     size_t neighbours_cap = 0;
@@ -630,10 +631,12 @@ static int launch_one(apd_context *c, int kernel_id, int iter)
     }
     hipError_t e;
     switch (kernel_id) {
+    case APD_K3_GEN_NEIGHBOURS:
     case APD_K9_BLACK_UPDATE_WEAK:
     case APD_K10_RED_UPDATE_WEAK:
-        if (c->weak_list[0] && !c->weak_lists_valid) {
-            e = apd::build_weak_lists(c->fa, c->weak_list, c->weak_list_scratch, c->weak_list_count, c->stream);
+        if (c->weak_list[0] && (!c->weak_lists_valid || c->weak_lists_all_rows != (kernel_id == APD_K3_GEN_NEIGHBOURS))) {
+            c->weak_lists_all_rows = kernel_id == APD_K3_GEN_NEIGHBOURS;
+            e = apd::build_weak_lists(c->fa, c->weak_lists_all_rows, c->weak_list, c->weak_list_scratch, c->weak_list_count, c->stream);
             if (e != hipSuccess) {
                 return fail(APD_ERR_HIP, "building the WEAK pixel lists failed: %s", hipGetErrorString(e));
             }
@@ -646,7 +649,6 @@ static int launch_one(apd_context *c, int kernel_id, int iter)
         e = apd::launch_weak_kernel(c->fa, kernel_id, iter, c->stream, nullptr, nullptr);
         break;
     case APD_K2_FIND_NEAREST_STRONG:
-    case APD_K3_GEN_NEIGHBOURS:
     case APD_K8_RANSAC_FIT_PLANE:
         e = apd::launch_weak_kernel(c->fa, kernel_id, iter, c->stream, nullptr, nullptr);
         break;

@@ -1078,10 +1078,10 @@ constexpr int kSubStep = 5;
 // kRecip: kRecipExact (every denominator in the fast range) or kRecipIeee (any denominator; same bits where both are valid).
 // Two halves, so that a caller can have the nine gathers of the next sub-patch in flight while it reduces this one
 // (K9/K10, two waves per SIMD: latency is what is left once the traffic is halved).
-// Byte offsets into the texel-quad image and the two lerp weights of the nine warped samples (k = i * 3 + j, i = x offset).
 template <int kRecip = kRecipExact>
-__device__ __forceinline__ void subpatch_offsets_quad(const Homography &H, unsigned qpitch, int wm1, int hm1, int cx, int cy,
-                                                      float (&a)[kSubN * kSubN], float (&b)[kSubN * kSubN], int (&off)[kSubN * kSubN])
+__device__ __forceinline__ void subpatch_issue_quad(const Homography &H, global_quad_ptr srcq, unsigned qpitch, int wm1, int hm1, int cx,
+                                                    int cy, float (&a)[kSubN * kSubN], float (&b)[kSubN * kSubN],
+                                                    quad_t (&t)[kSubN * kSubN])
 {
     constexpr int N = kSubN * kSubN;
     float z[N], X[N], Y[N], r[N];
@@ -1128,42 +1128,36 @@ __device__ __forceinline__ void subpatch_offsets_quad(const Homography &H, unsig
         Y[k] *= r[k];
     }
     APD_STAGE();
-    int qy[N];
+    int qx[N], qy[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         a[k] = __builtin_amdgcn_fractf(X[k]);
         b[k] = __builtin_amdgcn_fractf(Y[k]);
-        off[k] = cvt_floor_i32(X[k]);
+        qx[k] = cvt_floor_i32(X[k]);
         qy[k] = cvt_floor_i32(Y[k]);
     }
     APD_STAGE();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        off[k] = med3_i32(off[k], -1, wm1);
+        qx[k] = med3_i32(qx[k], -1, wm1);
         qy[k] = med3_i32(qy[k], -1, hm1);
     }
     APD_STAGE();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        off[k] = (int)quad_byte_offset(off[k], qy[k], (int)qpitch, (int)(qpitch + kRowEntryBytes));
+        qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)qpitch, (int)(qpitch + kRowEntryBytes));
     }
     APD_STAGE();
-}
-
-// Nine warped samples in lock step (same stages as quad_row_issue), reduced in the reference's order.
-// ref_rows[i] packs the three reference texels of x offset i (y offset j in byte j).
-// kRecip: kRecipExact (every denominator in the fast range) or kRecipIeee (any denominator; same bits where both are valid).
-template <int kRecip = kRecipExact>
-__device__ __forceinline__ void subpatch_issue_quad(const Homography &H, global_quad_ptr srcq, unsigned qpitch, int wm1, int hm1, int cx,
-                                                    int cy, float (&a)[kSubN * kSubN], float (&b)[kSubN * kSubN],
-                                                    quad_t (&t)[kSubN * kSubN])
-{
-    constexpr int N = kSubN * kSubN;
-    int off[N];
-    subpatch_offsets_quad<kRecip>(H, qpitch, wm1, hm1, cx, cy, a, b, off);
+#ifdef APD_EXPERIMENT_SUB_ADDR_ZERO  // timing experiment only: every sub-patch gather hits the same L1 line
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        t[k] = quad_fetch(srcq, (unsigned)off[k]);
+        qx[k] = qx[k] & (0x80 - (int)kQuadBytes);
+    }
+    APD_STAGE();
+#endif
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        t[k] = quad_fetch(srcq, (unsigned)qx[k]);
     }
 }
 
@@ -1215,60 +1209,6 @@ __device__ __forceinline__ float subpatch_cost_quad(const Homography &H, global_
     quad_t t[kSubN * kSubN];
     subpatch_issue_quad<kRecip>(H, srcq, qpitch, wm1, hm1, cx, cy, a, b, t);
     APD_STAGE();
-    return subpatch_finish_quad(t, a, b, ref_rows, mean_r, var_r);
-}
-
-// The same sub-patch with TAP-COOPERATIVE gathers (K9/K10, 64-lane workgroups = one wave).  Lane-per-pixel gathers send every
-// lane of a wave to another far-away neighbour: one gather instruction touches ~64 different 128-byte lines and the L1 looks
-// them up one by one (the tag pipeline, not bandwidth or latency, bounds the weak sweep once its lists are ordered,
-// profiles/r03).  The nine taps of ONE sub-patch lie on three source rows: 3-4 lines.  So the wave transposes through LDS:
-// every lane writes its nine byte offsets to xchg[lane * 9 + slot] (slot = j * 3 + i: the three taps of a source row side by
-// side), gather g of nine fetches item 64 g + lane -- nine consecutive lanes serve one pixel's sub-patch -- and puts the texel
-// quad back in place, and every lane reads its own nine quads again.  Same texels, same arithmetic, same summation order:
-// bit-identical; ~7 sub-patches x ~3.5 lines per gather instead of 64.  Stride 9 is odd, so neither the owner's accesses
-// (lane * 9 + slot) nor the transposed ones (64 g + lane) conflict on LDS banks.
-// Every lane of the wave must call this (wave-uniform control flow); `active` = this lane has a sub-patch to score.
-// A lane without one lends its gathers and gets an unspecified value back.
-constexpr int kXchgDwords = 64 * kSubN * kSubN;
-#ifdef APD_LAB_COOP_IMAJOR  // A/B: taps of one source COLUMN side by side
-#define APD_COOP_SLOT(i, j) ((i) * kSubN + (j))
-#else
-#define APD_COOP_SLOT(i, j) ((j) * kSubN + (i))
-#endif
-template <int kRecip = kRecipExact>
-__device__ __forceinline__ float subpatch_cost_quad_coop(const Homography &H, global_quad_ptr srcq, unsigned qpitch, int wm1, int hm1,
-                                                         int cx, int cy, bool active, const uint32_t (&ref_rows)[kSubN], float mean_r,
-                                                         float var_r, uint32_t *xchg, int lane)
-{
-    constexpr int N = kSubN * kSubN;
-    float a[N], b[N];
-    int off[N];
-    subpatch_offsets_quad<kRecip>(H, qpitch, wm1, hm1, cx, cy, a, b, off);
-    uint32_t *mine = xchg + lane * N;
-#pragma unroll
-    for (int i = 0; i < kSubN; ++i) {
-#pragma unroll
-        for (int j = 0; j < kSubN; ++j) {
-            mine[APD_COOP_SLOT(i, j)] = active ? (uint32_t)off[i * kSubN + j] : 0u;  // offset 0 is always inside the image
-        }
-    }
-    quad_t g[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        g[k] = quad_fetch(srcq, xchg[64 * k + lane]);
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        xchg[64 * k + lane] = g[k];  // slot (k, lane) is read and written by this lane only: in place
-    }
-    quad_t t[N];
-#pragma unroll
-    for (int i = 0; i < kSubN; ++i) {
-#pragma unroll
-        for (int j = 0; j < kSubN; ++j) {
-            t[i * kSubN + j] = mine[APD_COOP_SLOT(i, j)];
-        }
-    }
     return subpatch_finish_quad(t, a, b, ref_rows, mean_r, var_r);
 }
 

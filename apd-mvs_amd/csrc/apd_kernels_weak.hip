@@ -128,18 +128,18 @@ __device__ __forceinline__ void sort_points_by_weight(short2 *pts, float *w, int
     }
 }
 
-__global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa)
+// One lane per entry of a compacted WEAK list (build_weak_lists below; K3 visits both colours): a per-pixel launch fills
+// 18 % of its lanes on a typical frame and the ray search of those diverges against nothing.  In list order the lanes of a
+// wave are image neighbours, which walk their rays in step.
+__global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa, const int *__restrict__ list, int count)
 {
-    const int px = blockIdx.x * 8 + (threadIdx.x & 7);
-    const int py = blockIdx.y * 8 + (threadIdx.x >> 3);
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= count) {
+        return;
+    }
     const int W = fa.W, H = fa.H;
-    if (px >= W || py >= H) {
-        return;
-    }
-    const int center = px + py * W;
-    if (fa.weak_info[center] != APD_WEAK) {
-        return;
-    }
+    const int center = list[gid];
+    const int py = center / W, px = center - py * W;
     const int min_margin = 6;
     const float depth_diff = fa.depth_max - fa.depth_min;
     Rng rng = rng_load(fa.rng, center);
@@ -528,24 +528,20 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
     }
 }
 
-// Every lane of the wave calls this (wave-uniform control flow: the sub-patch gathers are cooperative, see
-// subpatch_cost_quad_coop); `want` = this lane really scores (plane, view).  The value of a lane that does not is unspecified.
 template <bool kQuad, typename Ref>
 __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLdsT<kQuad> &lds,
-                                              uint32_t *xchg, int lane, int px, int py, const float4 pl, bool want)
+                                              int lane, int px, int py, const float4 pl)
 {
     float qx, qy, qz;
     plane_q(pl, qx, qy, qz);
     const Homography H = make_homography(fa, vc, qx, qy, qz);
     float cx, cy;
     correspond(H, (float)px, (float)py, cx, cy);
-    // a centre that projects outside the source image costs 2.0 (:546); such a lane scores no sub-patch either
-    const bool inside_src = want && !(cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f);
-    // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above)
-    float center_cost = 2.0f;
-    if (inside_src) {
-        center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
+        return 2.0f;
     }
+    // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above)
+    const float center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
     const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
     const unsigned qpitch = quad_row_pitch_bytes(fa.W);
     const unsigned fpitch = 16u * (unsigned)(fa.W + 1);
@@ -556,67 +552,43 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
         const int packed = lds.nb[k][lane];
-        bool active = inside_src && packed != -1;
+        if (packed == -1) {
+            continue;
+        }
         const int nbx = (int)(short)(packed & 0xFFFF), nby = packed >> 16;
         float nx, ny;
         correspond(H, (float)nbx, (float)nby, nx, ny);
-        if (active && (nx < 0 || ny < 0 || nx >= (float)fa.W || ny >= (float)fa.H)) {
-            const uint32_t vi = fa.selected_views[nbx + nby * fa.W];  // counts 2.0 only if that neighbour selected this view (:439-449)
+        if (nx < 0 || ny < 0 || nx >= (float)fa.W || ny >= (float)fa.H) {
+            const uint32_t vi = fa.selected_views[nbx + nby * fa.W];
             if (bit_test(vi, (unsigned)v)) {
                 strong_cost += 2.0f;
                 strong_count++;
             }
-            active = false;
+            continue;
         }
+        float c;
         // one nine-sample body per wave and sub-patch: the IEEE division gives the bits of the fast reciprocal wherever that
         // one is valid, so if one lane needs it (a sign change or an extreme denominator under a random normal) all take it
         const bool fast = denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep));
-        if constexpr (kQuad) {
-            if (__builtin_amdgcn_ballot_w64(active) == 0) {
-                continue;  // wave-uniform
-            }
-            const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-            float c;
-#ifdef APD_LAB_K910_NO_COOP  // A/B: every lane gathers its own nine taps
-            c = 0.0f;
-            if (active) {
-                if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
-                    c = subpatch_cost_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
-                } else {
-                    c = subpatch_cost_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
-                }
-            }
-#else
-            if (__builtin_amdgcn_ballot_w64(active && !fast) == 0) {
-                c = subpatch_cost_quad_coop<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, active, ref_rows, lds.mean[k][lane],
-                                                         lds.var[k][lane], xchg, lane);
+        if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
+            if constexpr (kQuad) {
+                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
+                c = subpatch_cost_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
             } else {
-                c = subpatch_cost_quad_coop<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, active, ref_rows, lds.mean[k][lane],
-                                                        lds.var[k][lane], xchg, lane);
-            }
-#endif
-            if (active) {
-                strong_cost += c;
-                strong_count++;
-            }
-        } else {
-            if (!active) {
-                continue;
-            }
-            float c;
-            if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
                 c = subpatch_cost_fquad<kRecipExact>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
                                                      lds.var[k][lane]);
+            }
+        } else {
+            if constexpr (kQuad) {
+                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
+                c = subpatch_cost_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
             } else {
                 c = subpatch_cost_fquad<kRecipIeee>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
                                                     lds.var[k][lane]);
             }
-            strong_cost += c;
-            strong_count++;
         }
-    }
-    if (!inside_src) {
-        return 2.0f;
+        strong_cost += c;
+        strong_count++;
     }
     if (strong_count == 0) {
         return center_cost;
@@ -655,9 +627,9 @@ static TileOrder tile_order(int W, int H)
     return o;
 }
 
-// lane -> pixel of ordered tile slot s; false for padding slots, pixels outside the image and rows the reference's HALF
-// launch never visits (APD.cu:2402)
-__device__ __forceinline__ bool weak_pixel_of_lane(const FrameArgs &fa, const TileOrder o, int colour, int s, int lane, int &center)
+// lane -> pixel of ordered tile slot s; false for padding slots and pixels outside the image / at or below row_limit (the
+// image height for K3's full launch, half_rows for K9/K10: rows the reference's HALF launch never visits, APD.cu:2402)
+__device__ __forceinline__ bool weak_pixel_of_lane(const FrameArgs &fa, const TileOrder o, int colour, int row_limit, int s, int lane, int &center)
 {
     const int super = s >> (2 * kSuperShift), within = s & (kSuperTiles * kSuperTiles - 1);
     const int sy = super / o.supers_x, sx = super - sy * o.supers_x;
@@ -665,11 +637,11 @@ __device__ __forceinline__ bool weak_pixel_of_lane(const FrameArgs &fa, const Ti
     const int py = ty * kListTileH + (lane >> 3);
     const int px = tx * kListTileW + 2 * (lane & 7) + ((py + colour) & 1);
     center = py * fa.W + px;
-    return tx < o.tiles_x && ty < o.tiles_y && px < fa.W && py < fa.H && py < fa.half_rows && fa.weak_info[center] == APD_WEAK;
+    return tx < o.tiles_x && ty < o.tiles_y && px < fa.W && py < row_limit && fa.weak_info[center] == APD_WEAK;
 }
 
 // pass 1: WEAK pixels of `colour` per ordered tile -> exclusive offsets inside a block of 64 tiles + the block's total
-__global__ __launch_bounds__(256) void k_weak_tile_counts(FrameArgs fa, TileOrder o, int colour, int *__restrict__ local_off,
+__global__ __launch_bounds__(256) void k_weak_tile_counts(FrameArgs fa, TileOrder o, int colour, int row_limit, int *__restrict__ local_off,
                                                           int *__restrict__ block_total)
 {
     __shared__ int cnt[kCountTilesPerBlock];
@@ -678,7 +650,7 @@ __global__ __launch_bounds__(256) void k_weak_tile_counts(FrameArgs fa, TileOrde
     for (int t = 0; t < kCountTilesPerBlock / 4; ++t) {
         const int s = s0 + wave * (kCountTilesPerBlock / 4) + t;
         int center;
-        const bool weak = s < o.total && weak_pixel_of_lane(fa, o, colour, s, lane, center);
+        const bool weak = s < o.total && weak_pixel_of_lane(fa, o, colour, row_limit, s, lane, center);
         const unsigned long long mask = __ballot(weak);
         if (lane == 0) {
             cnt[wave * (kCountTilesPerBlock / 4) + t] = __popcll(mask);
@@ -705,7 +677,7 @@ __global__ __launch_bounds__(256) void k_weak_tile_counts(FrameArgs fa, TileOrde
 }
 
 // pass 3 (pass 2 = k_weak_block_offsets over the block totals): write the pixel indices
-__global__ __launch_bounds__(256) void k_weak_tile_scatter(FrameArgs fa, TileOrder o, int colour, const int *__restrict__ local_off,
+__global__ __launch_bounds__(256) void k_weak_tile_scatter(FrameArgs fa, TileOrder o, int colour, int row_limit, const int *__restrict__ local_off,
                                                            const int *__restrict__ block_off, int *__restrict__ list)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -717,7 +689,7 @@ __global__ __launch_bounds__(256) void k_weak_tile_scatter(FrameArgs fa, TileOrd
             break;
         }
         int center;
-        const bool weak = weak_pixel_of_lane(fa, o, colour, s, lane, center);
+        const bool weak = weak_pixel_of_lane(fa, o, colour, row_limit, s, lane, center);
         const unsigned long long mask = __ballot(weak);
         if (weak) {
             list[base0 + local_off[s] + __popcll(mask & ((1ull << lane) - 1ull))] = center;
@@ -745,11 +717,6 @@ __device__ __forceinline__ float4 candidate_plane(const FrameArgs &fa, const sho
 
 // Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
 // plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
-//
-// One wave per workgroup, one lane per list entry.  The sub-patch gathers of ncc_deformed are cooperative, so every call of
-// it sits in wave-uniform control flow: a lane that has nothing to score for a (hypothesis, view) -- an invalid candidate, an
-// unselected view, a refinement hypothesis that can no longer win, the padding lanes of the last wave -- stays in the wave
-// with want = false while any other lane scores, and is skipped with the whole wave otherwise (ballots).
 #ifndef APD_K910_WAVES
 #define APD_K910_WAVES 2
 #endif
@@ -757,16 +724,13 @@ template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, int count, int per_xcd)
 {
     __shared__ WeakLdsT<kQuad> lds;
-    __shared__ uint32_t xchg[kQuad ? kXchgDwords : 1];
     const int lane = threadIdx.x;
-    const int first = weak_chunk_of_block(blockIdx.x, per_xcd) * 64;
-    if (first >= count) {
-        return;  // the whole wave lies beyond the list
+    const int gid = weak_chunk_of_block(blockIdx.x, per_xcd) * 64 + lane;
+    if (gid >= count) {
+        return;
     }
-    // padding lanes of the last wave repeat the last entry (they lend their gathers) and never store anything
-    const bool lane_valid = first + lane < count;
     const int W = fa.W;
-    const int center = list[min(first + lane, count - 1)];
+    const int center = list[gid];
     const int py = center / W, px = center - py * W;
     const int nsrc = fa.num_src;
     const short2 *nb = &fa.neighbours[(size_t)fa.neighbours_map[center] * APD_NEIGHBOUR_NUM];
@@ -797,11 +761,8 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
     float4 plane_now = fa.planes[center];
     float4 plane_final = plane_now;
     float depth_now = 0.0f, cost_now = 0.0f, cost_committed = 0.0f;
-    float ref_depths[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float ref_depths[5];
     float4 ref_normals[5];
-    for (int k = 0; k < 5; ++k) {
-        ref_normals[k] = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
-    }
     bool skip_refine = false;
 
     // ---- candidates: the eight reliable neighbours' planes (must still be STRONG, :1354) + the current plane ----
@@ -820,15 +781,11 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
         const ViewConst &vc = view_const(fa, v);
 #pragma unroll 1
         for (int h = 0; h < 9; ++h) {
-            const bool want = h == 8 || (flags & (1u << h)) != 0;
-            if (__builtin_amdgcn_ballot_w64(want) == 0) {
+            if (h < 8 && !(flags & (1u << h))) {
                 continue;
             }
-            const float4 pl = (h < 8 && want) ? candidate_plane(fa, nb, h) : plane_now;
-            const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, xchg, lane, px, py, pl, want);
-            if (want) {
-                cost_array[h][v] = c;
-            }
+            const float4 pl = (h < 8) ? candidate_plane(fa, nb, h) : plane_now;
+            cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
         }
     }
 
@@ -852,9 +809,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                 }
             }
             select_views<NMAX>(fa, iter, cost_array, priors, rng, vw, sel, weight_norm);
-            if (lane_valid) {
-                vw.store(fa, center);
-            }
+            vw.store(fa, center);
             float final_costs[8];
             for (int i = 0; i < 8; ++i) {
                 float f = 0.0f;
@@ -899,9 +854,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                     depth_now = d;
                     plane_now = cand_best;
                     cost_now = final_costs[best];
-                    if (lane_valid) {
-                        fa.selected_views[center] = sel;
-                    }
+                    fa.selected_views[center] = sel;
                 }
             }
             // PlaneHypothesisRefinementWeak: fit plane first (:910-936)
@@ -926,7 +879,9 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             pl = ref_normals[h - 10];
             pl.w = distance_to_origin(fa, px, py, ref_depths[h - 10], pl.x, pl.y, pl.z);
         }
-        const bool scores = !(h <= 14 && skip_refine);  // this lane evaluates hypothesis h at all
+        if (h <= 14 && skip_refine) {
+            continue;
+        }
         float tc = 0.0f;
         // hypotheses 9..14 are only compared with the running cost (:932, :974): a partial sum that has reached `lost`
         // cannot win any more and the remaining views are skipped (refinement_lost_bound, apd_sweep.h; the geometric term
@@ -934,23 +889,22 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
         const float lost = (h <= 14 && !(fa.geom_factor < 0.0f)) ? refinement_lost_bound(fa, cost_now, weight_norm) : __builtin_inff();
 #pragma unroll 1
         for (int v = 0; v < nsrc; ++v) {
-            // the cost of an unselected view is never used (:966-972); in the re-score it is multiplied by a zero weight
-            // (:1503) and, being a finite value in [0, 2], adds exactly +0.  tc only grows while it is below `lost`, so
-            // "tc >= lost" stays true once reached: the lane sits out the remaining views.
-            const bool want = scores && vw.get(v) != 0 && !(tc >= lost);
-            if (__builtin_amdgcn_ballot_w64(want) == 0) {
+            const ViewConst &vc = view_const(fa, v);
+            if (vw.get(v) == 0) {
+                // the cost of an unselected view is never used (:966-972); in the re-score it is multiplied by a zero
+                // weight (:1503) and, being a finite value in [0, 2], adds exactly +0
                 continue;
             }
-            const ViewConst &vc = view_const(fa, v);
+            if (tc >= lost) {
+                break;
+            }
             if (h == 15) {
-                if (want) {
-                    float qx, qy, qz;
-                    plane_q(pl, qx, qy, qz);
-                    tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
-                }
+                float qx, qy, qz;
+                plane_q(pl, qx, qy, qz);
+                tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
             } else {
-                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, xchg, lane, px, py, pl, want);
-                if (want) {
+                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
+                {
                     if (fa.geom_consistency) {
                         tc += (float)vw.get(v) * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
                     } else {
@@ -958,9 +912,6 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                     }
                 }
             }
-        }
-        if (!scores) {
-            continue;
         }
         if (h <= 14) {
             tc /= weight_norm;
@@ -970,14 +921,12 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                 plane_now = pl;
                 cost_now = tc;
             }
-        } else if (lane_valid) {
+        } else {
             fa.costs[center] = tc / weight_norm;
             fa.planes[center] = plane_final;
         }
     }
-    if (lane_valid) {
-        rng_store(fa.rng, center, rng);
-    }
+    rng_store(fa.rng, center, rng);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1127,15 +1076,17 @@ size_t weak_list_scratch_ints(int W, int H)
 
 // The compacted WEAK pixels of both colours (list[0] black, list[1] red; each with room for every WEAK pixel) and their
 // lengths, which come back to the host: the update kernels are launched with exact grids.  Synchronises the stream.
-hipError_t build_weak_lists(const FrameArgs &fa, int *const list[2], int *scratch, int counts[2], hipStream_t s)
+// all_rows: every row of the image (K3 is a full-frame launch in the reference); otherwise the rows its HALF launches reach.
+hipError_t build_weak_lists(const FrameArgs &fa, bool all_rows, int *const list[2], int *scratch, int counts[2], hipStream_t s)
 {
+    const int row_limit = all_rows ? fa.H : (fa.half_rows < fa.H ? fa.half_rows : fa.H);
     const TileOrder o = tile_order(fa.W, fa.H);
     const int nblocks = o.total / kCountTilesPerBlock;  // o.total is a multiple of 256
     int *local_off = scratch, *block_off = scratch + o.total;
     for (int colour = 0; colour < 2; ++colour) {
-        hipLaunchKernelGGL(k_weak_tile_counts, dim3(nblocks), dim3(256), 0, s, fa, o, colour, local_off, block_off);
+        hipLaunchKernelGGL(k_weak_tile_counts, dim3(nblocks), dim3(256), 0, s, fa, o, colour, row_limit, local_off, block_off);
         hipLaunchKernelGGL(k_weak_block_offsets, dim3(1), dim3(kMapBlock), 0, s, block_off, nblocks);
-        hipLaunchKernelGGL(k_weak_tile_scatter, dim3(nblocks), dim3(256), 0, s, fa, o, colour, (const int *)local_off,
+        hipLaunchKernelGGL(k_weak_tile_scatter, dim3(nblocks), dim3(256), 0, s, fa, o, colour, row_limit, (const int *)local_off,
                            (const int *)block_off, list[colour]);
         hipError_t e = hipMemcpyAsync(&counts[colour], block_off + nblocks, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) {
@@ -1174,7 +1125,12 @@ hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipS
         break;
     }
     case APD_K3_GEN_NEIGHBOURS:
-        hipLaunchKernelGGL(k3_gen_neighbours, dim3((fa.W + 7) / 8, (fa.H + 7) / 8), dim3(64), 0, s, fa);
+        for (int colour = 0; colour < 2 && weak_list; ++colour) {  // the lists only split the pixels by colour; K3 has no colour
+            if (weak_list[colour] && weak_count[colour] > 0) {
+                hipLaunchKernelGGL(k3_gen_neighbours, dim3((weak_count[colour] + 63) / 64), dim3(64), 0, s, fa, weak_list[colour],
+                                   weak_count[colour]);
+            }
+        }
         break;
     case APD_K4_NEIGHBOUR_UPDATE:
         hipLaunchKernelGGL(k4_neighbour_update, dim3((n + 255) / 256), dim3(256), 0, s, fa);
