@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB_PATH = os.path.join(OUT_DIR, "libapd_mi355x.so")
-SOURCES = ["apd_kernels.hip", "apd_kernels_k67w.hip", "apd_kernels_k1415w.hip", "apd_kernels_weak.hip", "apd_fusion.hip", "apd_capi.hip"]
+SOURCES = ["apd_kernels.hip", "apd_kernels_k67w.hip", "apd_kernels_k1415w.hip", "apd_kernels_weak.hip", "apd_fusion.hip", "apd_exchange.hip", "apd_capi.hip"]
 HEADERS = ["apd_device.h", "apd_sweep.h", "apd_window.h", "apd_fusion_math.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
@@ -60,14 +60,14 @@ def build_library(force=False, verbose=False, extra_flags=()):
                 if verbose and out.strip():
                     print(out)
     if jobs or not os.path.exists(LIB_PATH):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"])
     return LIB_PATH
 
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_BIN = os.path.join(OUT_DIR, "APD")
 HOST_LIB = os.path.join(OUT_DIR, "libapd_host.so")
-HOST_SOURCES = ["APD.cpp", "jpeg_gray.cpp", "fusion.cpp"]
+HOST_SOURCES = ["APD.cpp", "jpeg_gray.cpp", "fusion.cpp", "multi_device.cpp"]
 
 
 def build_host(force=False, verbose=False):
@@ -75,10 +75,10 @@ def build_host(force=False, verbose=False):
     build_library()
     cxx = os.environ.get("CXX", "g++")
     srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "apd_fusion_math.h"), os.path.join(HOST_DIR, "APD.h"), os.path.join(HOST_DIR, "main.cpp"), os.path.join(HOST_DIR, "host_capi.cpp"),
+    deps = srcs + [os.path.join(CSRC, "apd_fusion_math.h"), os.path.join(HOST_DIR, "APD.h"), os.path.join(HOST_DIR, "schedule.h"), os.path.join(HOST_DIR, "main.cpp"), os.path.join(HOST_DIR, "host_capi.cpp"),
                    os.path.join(HERE, "..", "include", "apd_mi355x.h"), LIB_PATH]
     common = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result"]  # contract C9: no FMA contraction in the fusion arithmetic
-    link = ["-L" + OUT_DIR, "-lapd_mi355x", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + OUT_DIR]
+    link = ["-L" + OUT_DIR, "-lapd_mi355x", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + OUT_DIR, "-pthread"]
 
     def run(cmd):
         if verbose:

@@ -20,6 +20,7 @@ hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipS
 size_t weak_list_scratch_ints(int W, int H);
 hipError_t build_weak_lists(const FrameArgs &fa, bool all_rows, int *const list[2], int *scratch, int counts[2], hipStream_t s);
 hipError_t launch_export_depth_normal(const FrameArgs &fa, float *depth, float *normal, hipStream_t s);
+hipError_t launch_export_state(const FrameArgs &fa, float4 *planes4, uint8_t *weak, uint32_t *views, float *depth, hipStream_t s);
 hipError_t launch_check_u8(const float *img, int n, int *flag, hipStream_t s);
 hipError_t launch_weak_index_map(const uint8_t *weak, size_t n, int *map, int *scratch, hipStream_t s);
 hipError_t launch_pack_quads(const float *img, int W, int H, quad_t *quad, hipStream_t s);
@@ -848,6 +849,21 @@ int apd_export_depth_normal_device(apd_handle c, float *depth_dev, float *normal
         return fail(APD_ERR_HIP, "export kernel failed: %s", hipGetErrorString(e));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return APD_OK;
+}
+
+int apd_export_state_device(apd_handle c, float *planes4_dev, uint8_t *weak_dev, uint32_t *views_dev, float *depth_dev)
+{
+    if (!c) {
+        return fail(APD_ERR_INVALID, "apd_export_state_device: null handle");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = apd::launch_export_state(c->fa, reinterpret_cast<float4 *>(planes4_dev), weak_dev, views_dev, depth_dev, c->stream);
+    if (e != hipSuccess) {
+        return fail(APD_ERR_HIP, "export kernel failed: %s", hipGetErrorString(e));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drain_profile(c);
     return APD_OK;
 }
 

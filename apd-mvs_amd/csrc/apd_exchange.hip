@@ -1,0 +1,328 @@
+// apd_exchange.hip -- the pieces a multi-device host needs around the PatchMatch handles (include/apd_mi355x.h, "several
+// devices in one process"): device memory for callers built without a HIP toolchain (the C++ drop-in is compiled with g++),
+// the post-processed maps of a finished pass left on the device, the reference's nearest-neighbour resampling of prior
+// state between pyramid levels on the device, and the all-gather of per-view maps across the devices of one process.
+//
+// The all-gather is RCCL's (ncclCommInitAll + one grouped ncclAllGather per call, every rank on its own stream), i.e. the
+// xGMI path.  librccl is opened at run time (dlopen): the library has no link-time dependency on it, and a device list that
+// names one device twice -- the way a one-GPU box exercises the multi-device scheduler -- or a missing librccl falls back to
+// direct copies (hipMemcpyPeerAsync), which give the same bytes.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "apd_device.h"
+
+namespace apd {
+
+// RescaleMatToTargetSize (APD.cpp:752-774): dst(r, c) = src((int)(r / scale_x), (int)(c / scale_y)) with
+// scale_x = dst_w / (float)src_w and scale_y = dst_h / (float)src_h -- the row is divided by the COLUMN ratio and the column by
+// the ROW ratio; pixels whose source index falls outside keep what `dst` held.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rescale_nearest(const T *__restrict__ src, int sw, int sh, T *__restrict__ dst, int dw, int dh)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= dw) {
+        return;
+    }
+    const float scale_x = (float)dw / (float)sw;
+    const float scale_y = (float)dh / (float)sh;
+    const int o_r = (int)((float)r / scale_x);
+    const int o_c = (int)((float)c / scale_y);
+    if (o_r < 0 || o_c < 0 || o_r >= sh || o_c >= sw) {
+        return;
+    }
+    dst[(size_t)r * dw + c] = src[(size_t)o_r * sw + o_c];
+}
+
+struct Bytes16 {
+    uint32_t v[4];
+};
+
+// ProcessProblem's post-processing (main.cpp:105-115) into the layout apd_upload_prior takes: planes4 = (world normal,
+// depth), a depth outside [depth_min, depth_max] becomes 0 and its pixel UNKNOWN.
+__global__ __launch_bounds__(256) void k_export_state(FrameArgs fa, float4 *planes4, uint8_t *weak, uint32_t *views, float *depth)
+{
+    const int center = blockIdx.x * 256 + threadIdx.x;
+    if (center >= fa.W * fa.H) {
+        return;
+    }
+    float4 pl = fa.planes[center];
+    uint8_t w = fa.weak_info[center];
+    if (pl.w < fa.depth_min || pl.w > fa.depth_max) {  // false for NaN, as in the reference
+        pl.w = 0.0f;
+        w = APD_UNKNOWN;
+    }
+    if (planes4) {
+        planes4[center] = pl;
+    }
+    if (weak) {
+        weak[center] = w;
+    }
+    if (views) {
+        views[center] = fa.selected_views[center];
+    }
+    if (depth) {
+        depth[center] = pl.w;
+    }
+}
+
+hipError_t launch_export_state(const FrameArgs &fa, float4 *planes4, uint8_t *weak, uint32_t *views, float *depth, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_export_state, dim3((fa.W * fa.H + 255) / 256), dim3(256), 0, s, fa, planes4, weak, views, depth);
+    return hipGetLastError();
+}
+
+}  // namespace apd
+
+static thread_local std::string g_exchange_error;
+
+static int xfail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_exchange_error = buf;
+    return code;
+}
+
+#define X_TRY(expr)                                                                                                        \
+    do {                                                                                                                   \
+        hipError_t e_ = (expr);                                                                                            \
+        if (e_ != hipSuccess) {                                                                                            \
+            return xfail(APD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);           \
+        }                                                                                                                  \
+    } while (0)
+
+// the six RCCL entry points, resolved with dlsym (signatures of rccl.h 2.2x)
+struct RcclApi {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t count, int datatype, void *comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load()
+    {
+        if (lib) {
+            return true;
+        }
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) {
+                break;
+            }
+        }
+        if (!lib) {
+            return false;
+        }
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString) {
+            dlclose(lib);
+            lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+static RcclApi g_rccl;
+constexpr int kNcclInt8 = 0;  // ncclDataType_t ncclInt8 / ncclChar: the payload is moved as bytes
+
+struct apd_exchange {
+    std::vector<int> devices;
+    std::vector<hipStream_t> streams;
+    std::vector<void *> comms;  // ncclComm_t per rank; empty -> direct copies
+    std::string backend;
+};
+
+extern "C" {
+
+const char *apd_exchange_last_error(void) { return g_exchange_error.c_str(); }
+
+int apd_device_malloc(int device, size_t bytes, void **out)
+{
+    if (!out) {
+        return xfail(APD_ERR_INVALID, "apd_device_malloc: null result pointer");
+    }
+    *out = nullptr;
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipMalloc(out, bytes > 0 ? bytes : 1));
+    return APD_OK;
+}
+
+int apd_device_free(int device, void *p)
+{
+    if (!p) {
+        return APD_OK;
+    }
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipFree(p));
+    return APD_OK;
+}
+
+int apd_device_memcpy(int device, void *dst, const void *src, size_t bytes)
+{
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDefault));  // host / device on either side (unified addressing)
+    return APD_OK;
+}
+
+int apd_device_memset(int device, void *dst, int value, size_t bytes)
+{
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipMemset(dst, value, bytes));
+    return APD_OK;
+}
+
+int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes)
+{
+    if (!src || !dst || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0) {
+        return xfail(APD_ERR_INVALID, "apd_rescale_nearest_device: bad argument");
+    }
+    X_TRY(hipSetDevice(device));
+    if (src_w == dst_w && src_h == dst_h) {  // the reference returns before touching dst (APD.cpp:754-756); callers want the copy
+        X_TRY(hipMemcpy(dst, src, (size_t)src_w * src_h * elem_bytes, hipMemcpyDeviceToDevice));
+        return APD_OK;
+    }
+    const dim3 grid((dst_w + 255) / 256, dst_h);
+    switch (elem_bytes) {
+    case 1: hipLaunchKernelGGL(apd::k_rescale_nearest<uint8_t>, grid, dim3(256), 0, 0, (const uint8_t *)src, src_w, src_h, (uint8_t *)dst, dst_w, dst_h); break;
+    case 4: hipLaunchKernelGGL(apd::k_rescale_nearest<uint32_t>, grid, dim3(256), 0, 0, (const uint32_t *)src, src_w, src_h, (uint32_t *)dst, dst_w, dst_h); break;
+    case 16: hipLaunchKernelGGL(apd::k_rescale_nearest<apd::Bytes16>, grid, dim3(256), 0, 0, (const apd::Bytes16 *)src, src_w, src_h, (apd::Bytes16 *)dst, dst_w, dst_h); break;
+    default: return xfail(APD_ERR_INVALID, "apd_rescale_nearest_device: element size %d (1, 4 or 16 bytes)", elem_bytes);
+    }
+    X_TRY(hipGetLastError());
+    X_TRY(hipDeviceSynchronize());
+    return APD_OK;
+}
+
+int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl)
+{
+    if (!out || num_ranks < 1 || !devices) {
+        return xfail(APD_ERR_INVALID, "apd_exchange_create: bad argument");
+    }
+    int found = 0;
+    X_TRY(hipGetDeviceCount(&found));
+    apd_exchange *x = new apd_exchange();
+    x->devices.assign(devices, devices + num_ranks);
+    bool distinct = true;
+    for (int i = 0; i < num_ranks; ++i) {
+        if (devices[i] < 0 || devices[i] >= found) {
+            delete x;
+            return xfail(APD_ERR_INVALID, "apd_exchange_create: device %d requested, %d found", devices[i], found);
+        }
+        for (int j = 0; j < i; ++j) {
+            distinct = distinct && devices[i] != devices[j];
+        }
+    }
+    x->streams.resize(num_ranks, nullptr);
+    for (int i = 0; i < num_ranks; ++i) {
+        if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&x->streams[i], hipStreamNonBlocking) != hipSuccess) {
+            apd_exchange_destroy(x);
+            return xfail(APD_ERR_HIP, "apd_exchange_create: cannot create a stream on device %d", devices[i]);
+        }
+    }
+    x->backend = "peer-copy";
+    if (prefer_rccl && distinct && g_rccl.load()) {  // one communicator per rank, all in this process
+        x->comms.assign(num_ranks, nullptr);
+        const int rc = g_rccl.CommInitAll(x->comms.data(), num_ranks, devices);
+        if (rc == 0) {
+            x->backend = "rccl";
+        } else {
+            fprintf(stderr, "apd_exchange_create: ncclCommInitAll failed (%s): using direct copies\n", g_rccl.GetErrorString(rc));
+            x->comms.clear();
+        }
+    }
+    if (x->comms.empty() && distinct) {  // direct copies between different devices: let them go over xGMI
+        for (int i = 0; i < num_ranks; ++i) {
+            for (int j = 0; j < num_ranks; ++j) {
+                int can = 0;
+                if (i != j && hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                    hipSetDevice(devices[i]);
+                    hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                        (void)hipGetLastError();
+                    }
+                }
+            }
+        }
+    }
+    *out = x;
+    return APD_OK;
+}
+
+const char *apd_exchange_backend(apd_exchange_t x) { return x ? x->backend.c_str() : ""; }
+
+// recv[r] of every rank r ends as send[0] | send[1] | ... | send[num_ranks - 1], `bytes_per_rank` each.
+int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank)
+{
+    if (!x || !send || !recv) {
+        return xfail(APD_ERR_INVALID, "apd_exchange_allgather: bad argument");
+    }
+    const int n = (int)x->devices.size();
+    if (!x->comms.empty()) {
+        int rc = g_rccl.GroupStart();
+        for (int r = 0; r < n && rc == 0; ++r) {
+            rc = g_rccl.AllGather(send[r], recv[r], bytes_per_rank, kNcclInt8, x->comms[r], x->streams[r]);
+        }
+        const int rc_end = g_rccl.GroupEnd();
+        rc = rc ? rc : rc_end;
+        if (rc != 0) {
+            return xfail(APD_ERR_HIP, "ncclAllGather failed: %s", g_rccl.GetErrorString(rc));
+        }
+    } else {
+        for (int dst = 0; dst < n; ++dst) {  // every rank pulls every block on its own stream
+            X_TRY(hipSetDevice(x->devices[dst]));
+            for (int src = 0; src < n; ++src) {
+                char *to = (char *)recv[dst] + (size_t)src * bytes_per_rank;
+                if (x->devices[src] == x->devices[dst]) {
+                    X_TRY(hipMemcpyAsync(to, send[src], bytes_per_rank, hipMemcpyDeviceToDevice, x->streams[dst]));
+                } else {
+                    X_TRY(hipMemcpyPeerAsync(to, x->devices[dst], send[src], x->devices[src], bytes_per_rank, x->streams[dst]));
+                }
+            }
+        }
+    }
+    for (int r = 0; r < n; ++r) {
+        X_TRY(hipSetDevice(x->devices[r]));
+        X_TRY(hipStreamSynchronize(x->streams[r]));
+    }
+    return APD_OK;
+}
+
+int apd_exchange_destroy(apd_exchange_t x)
+{
+    if (!x) {
+        return APD_OK;
+    }
+    for (void *c : x->comms) {
+        if (c) {
+            g_rccl.CommDestroy(c);
+        }
+    }
+    for (size_t i = 0; i < x->streams.size(); ++i) {
+        if (x->streams[i]) {
+            hipSetDevice(x->devices[i]);
+            hipStreamDestroy(x->streams[i]);
+        }
+    }
+    delete x;
+    return APD_OK;
+}
+
+}  // extern "C"

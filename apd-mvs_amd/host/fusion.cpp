@@ -17,6 +17,7 @@
 #include <unordered_map>
 
 #include "APD.h"
+#include "schedule.h"
 
 namespace {
 
@@ -74,7 +75,11 @@ long long fuse_dispatch(std::vector<FusionView> &views, const std::vector<std::v
 void SetFusionDevice(int device) { g_fusion_device = device; }
 
 // Reads every view's final maps from <dense>/APD/<id>/ and fuses them into APD/APD.ply (APD.cpp:826-977).
-void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
+void RunFusion(const path &dense_folder, const std::vector<Problem> &problems) { RunFusionWithMaps(dense_folder, problems, nullptr); }
+
+// The same with the final maps already in memory (host/multi_device.cpp gathers them from the devices): maps[i] belongs to
+// problems[i]; nullptr reads the files.
+void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps)
 {
     std::vector<FusionView> views(problems.size());
     std::unordered_map<int, int> index_of_id;
@@ -95,9 +100,15 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems)
         }
         memset(&v.cam, 0, sizeof(v.cam));
         ReadCamera(dense_folder / path("cams") / path(ToFormatIndex(problem.ref_image_id) + "_cam.txt"), v.cam);
-        ReadBinMat(problem.result_folder / path("depths.dmb"), v.depth);
-        ReadBinMat(problem.result_folder / path("normals.dmb"), v.normal);
-        ReadBinMat(problem.result_folder / path("weak.bin"), v.weak);
+        if (maps) {
+            v.depth = (*maps)[i].depth;
+            v.normal = (*maps)[i].normal;
+            v.weak = (*maps)[i].weak.clone();  // resampled in place below
+        } else {
+            ReadBinMat(problem.result_folder / path("depths.dmb"), v.depth);
+            ReadBinMat(problem.result_folder / path("normals.dmb"), v.normal);
+            ReadBinMat(problem.result_folder / path("weak.bin"), v.weak);
+        }
         if (v.depth.empty() || v.normal.empty() || v.weak.empty()) {
             std::cerr << "Missing maps of view " << problem.ref_image_id << " in " << problem.result_folder << std::endl;
             failed[i] = 1;

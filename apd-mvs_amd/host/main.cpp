@@ -1,6 +1,10 @@
 // main.cpp -- drop-in driver of the PatchMatch path.
 //
-//   APD dense_folder [gpu_index] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]
+//   APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]
+//       [--jacobi] [--no-rccl]
+//
+// One device index: the reference's driver.  A device LIST (or --jacobi): host/multi_device.cpp -- views sharded over the
+// devices, state resident on them, depth maps all-gathered after every pass (RCCL; --no-rccl: direct copies).
 //
 // Same command line, files and results as the reference driver (main.cpp:140-233), organised differently:
 //   * pair.txt is read as one token stream with diagnostics (the reference never notices a missing or short file,
@@ -21,17 +25,9 @@
 #include <string>
 
 #include "APD.h"
+#include "schedule.h"
 
 namespace {
-
-struct Options {
-    path dense_folder;
-    int gpu_index = 0;
-    uint64_t seed = 12345;
-    int iters = 3;          // PatchMatchParams::max_iterations of every pass (reference: 3)
-    int max_src = 0;        // > 0: keep only the first N sources of each pair.txt entry (they are sorted by score)
-    bool single_level = false, keep_maps = false, no_fusion = false;
-};
 
 bool ParseOptions(int argc, char **argv, Options &o)
 {
@@ -63,8 +59,30 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.keep_maps = true;
         } else if (a == "--no-fusion") {
             o.no_fusion = true;
+        } else if (a == "--jacobi") {
+            o.jacobi = true;
+        } else if (a == "--no-rccl") {
+            o.use_rccl = false;
         } else if (i == 2 && a.size() && a[0] != '-') {
-            o.gpu_index = atoi(a.c_str());  // positional, as in the reference (main.cpp:149-153)
+            // positional, as in the reference (main.cpp:149-153); additive: a comma-separated list = one scheduler rank per entry
+            o.devices.clear();
+            size_t pos = 0;
+            while (pos <= a.size()) {
+                const size_t comma = a.find(',', pos);
+                const std::string item = a.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+                char *end = nullptr;
+                const long d = strtol(item.c_str(), &end, 10);
+                if (item.empty() || *end != '\0') {
+                    fprintf(stderr, "bad device list '%s'\n", a.c_str());
+                    return false;
+                }
+                o.devices.push_back((int)d);
+                if (comma == std::string::npos) {
+                    break;
+                }
+                pos = comma + 1;
+            }
+            o.gpu_index = o.devices[0];
         } else {
             fprintf(stderr, "unknown argument '%s'\n", a.c_str());
             return false;
@@ -144,73 +162,6 @@ bool CheckImages(const std::vector<Problem> &problems, int &width, int &height)
     return !problems.empty();
 }
 
-// One pass over all views.  round_num pyramid levels, coarse to fine; per level one photometric pass and three
-// geometric ones (main.cpp:168-215).
-struct Pass {
-    int level = 0;             // i of main.cpp:168
-    int iteration = 0;         // Problem::iteration, counts passes
-    int scale_size = 1;        // 2^(round_num - 1 - level)
-    RunState state = FIRST_INIT;
-    bool geom_consistency = false, use_APD = false;
-    int weak_peak_radius = 6;
-    float ransac_threshold = 0.005f;  // only read when use_APD (the struct default otherwise, main.h:92)
-    int rotate_time = 4;
-};
-
-int RoundNum(int width, int height)  // main.cpp:72-88: halve until the longer side is <= 1000
-{
-    int rounds = 1;
-    for (int longest = std::max(width, height); longest > 1000; longest /= 2) {
-        ++rounds;
-    }
-    return rounds;
-}
-
-std::vector<Pass> BuildSchedule(int round_num, bool single_level)
-{
-    std::vector<Pass> plan;
-    for (int level = 0; level < round_num; ++level) {
-        for (int k = 0; k < 4; ++k) {  // k = 0: photometric, k = 1..3: geometric with j = k - 1
-            Pass p;
-            p.level = level;
-            p.iteration = (int)plan.size();
-            p.scale_size = single_level ? 1 : 1 << (round_num - 1 - level);
-            p.state = k > 0 ? REFINE_ITER : (level == 0 ? FIRST_INIT : REFINE_INIT);
-            p.geom_consistency = k > 0;
-            p.weak_peak_radius = k == 0 ? 6 : std::max(4 - 2 * (k - 1), 2);
-            p.use_APD = level > 0;
-            if (p.use_APD) {
-                p.ransac_threshold = (float)(0.01 - level * 0.00125);  // double arithmetic, then float, as main.cpp:180
-                p.rotate_time = std::min(1 << level, 4);
-            }
-            plan.push_back(p);
-        }
-    }
-    return plan;
-}
-
-// The reference keeps one PatchMatchParams per problem alive across passes and only overwrites some fields, so
-// ransac_threshold / rotate_time of level 0 are the struct defaults: same here.
-void Configure(Problem &problem, const Pass &pass, const Options &o)
-{
-    PatchMatchParams &q = problem.params;
-    q.state = pass.state;
-    q.use_APD = pass.use_APD;
-    if (pass.use_APD) {
-        q.ransac_threshold = pass.ransac_threshold;
-        q.rotate_time = pass.rotate_time;
-    }
-    q.geom_consistency = pass.geom_consistency;
-    q.max_iterations = o.iters;
-    q.weak_peak_radius = pass.weak_peak_radius;
-    q.seed = o.seed + (uint64_t)pass.iteration * 7919u + (uint64_t)problem.index;  // the reference seeds with clock64()
-    problem.iteration = pass.iteration;
-    problem.show_medium_result = true;
-    problem.scale_size = pass.scale_size;
-}
-
-const char *const kStateFiles[4] = {"depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"};
-
 }  // namespace
 
 // One (view, pass): the reference's ProcessProblem (main.cpp:91-138) -- run the path, post-process (depth outside the
@@ -259,12 +210,17 @@ int main(int argc, char **argv)
 {
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
-        fprintf(stderr, "USAGE: APD dense_folder [gpu_index] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]\n");
+        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--jacobi] [--no-rccl]\n");
         return EXIT_FAILURE;
     }
-    if (opt.gpu_index < 0 || opt.gpu_index >= apd_device_count()) {
-        fprintf(stderr, "Requested GPU %d, found %d device(s)\n", opt.gpu_index, apd_device_count());
-        return EXIT_FAILURE;
+    if (opt.devices.empty()) {
+        opt.devices.push_back(opt.gpu_index);
+    }
+    for (int d : opt.devices) {
+        if (d < 0 || d >= apd_device_count()) {
+            fprintf(stderr, "Requested GPU %d, found %d device(s)\n", d, apd_device_count());
+            return EXIT_FAILURE;
+        }
     }
     APD::SetDevice(opt.gpu_index);
     SetFusionDevice(opt.gpu_index);
@@ -299,6 +255,9 @@ int main(int argc, char **argv)
         }
     }
     PrefetchGrayImages(opt.dense_folder / "images", ids);  // decoded once, on several host threads
+    if (opt.devices.size() > 1 || opt.jacobi) {
+        return RunMultiDevice(opt, problems);  // host/multi_device.cpp: in memory, views sharded over the device list
+    }
     int width = 0, height = 0;
     if (!CheckImages(problems, width, height)) {
         fprintf(stderr, "Images may error, check it!\n");  // the reference's message (main.cpp:158)

@@ -1,0 +1,104 @@
+// schedule.h -- what the two schedulers of the drop-in host share: the command-line options, the pass table of the
+// reference driver (main.cpp:168-215) and the per-pass parameters of a problem.  host/main.cpp runs the table view by view
+// through files like the reference (Gauss-Seidel over views); host/multi_device.cpp runs it in memory on several devices.
+#ifndef APD_MI355X_HOST_SCHEDULE_H_
+#define APD_MI355X_HOST_SCHEDULE_H_
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "APD.h"
+
+struct Options {
+    path dense_folder;
+    int gpu_index = 0;
+    std::vector<int> devices;   // "0,1,2,3": one scheduler rank per entry (an entry may repeat: two ranks on one device)
+    bool jacobi = false;        // the in-memory scheduler of host/multi_device.cpp even with a single device
+    bool use_rccl = true;       // --no-rccl: exchange maps with direct copies
+    uint64_t seed = 12345;
+    int iters = 3;          // PatchMatchParams::max_iterations of every pass (reference: 3)
+    int max_src = 0;        // > 0: keep only the first N sources of each pair.txt entry (they are sorted by score)
+    bool single_level = false, keep_maps = false, no_fusion = false;
+};
+
+
+// One pass over all views.  round_num pyramid levels, coarse to fine; per level one photometric pass and three
+// geometric ones (main.cpp:168-215).
+struct Pass {
+    int level = 0;             // i of main.cpp:168
+    int iteration = 0;         // Problem::iteration, counts passes
+    int scale_size = 1;        // 2^(round_num - 1 - level)
+    RunState state = FIRST_INIT;
+    bool geom_consistency = false, use_APD = false;
+    int weak_peak_radius = 6;
+    float ransac_threshold = 0.005f;  // only read when use_APD (the struct default otherwise, main.h:92)
+    int rotate_time = 4;
+};
+
+inline int RoundNum(int width, int height)  // main.cpp:72-88: halve until the longer side is <= 1000
+{
+    int rounds = 1;
+    for (int longest = std::max(width, height); longest > 1000; longest /= 2) {
+        ++rounds;
+    }
+    return rounds;
+}
+
+inline std::vector<Pass> BuildSchedule(int round_num, bool single_level)
+{
+    std::vector<Pass> plan;
+    for (int level = 0; level < round_num; ++level) {
+        for (int k = 0; k < 4; ++k) {  // k = 0: photometric, k = 1..3: geometric with j = k - 1
+            Pass p;
+            p.level = level;
+            p.iteration = (int)plan.size();
+            p.scale_size = single_level ? 1 : 1 << (round_num - 1 - level);
+            p.state = k > 0 ? REFINE_ITER : (level == 0 ? FIRST_INIT : REFINE_INIT);
+            p.geom_consistency = k > 0;
+            p.weak_peak_radius = k == 0 ? 6 : std::max(4 - 2 * (k - 1), 2);
+            p.use_APD = level > 0;
+            if (p.use_APD) {
+                p.ransac_threshold = (float)(0.01 - level * 0.00125);  // double arithmetic, then float, as main.cpp:180
+                p.rotate_time = std::min(1 << level, 4);
+            }
+            plan.push_back(p);
+        }
+    }
+    return plan;
+}
+
+// The reference keeps one PatchMatchParams per problem alive across passes and only overwrites some fields, so
+// ransac_threshold / rotate_time of level 0 are the struct defaults: same here.
+inline void Configure(Problem &problem, const Pass &pass, const Options &o)
+{
+    PatchMatchParams &q = problem.params;
+    q.state = pass.state;
+    q.use_APD = pass.use_APD;
+    if (pass.use_APD) {
+        q.ransac_threshold = pass.ransac_threshold;
+        q.rotate_time = pass.rotate_time;
+    }
+    q.geom_consistency = pass.geom_consistency;
+    q.max_iterations = o.iters;
+    q.weak_peak_radius = pass.weak_peak_radius;
+    q.seed = o.seed + (uint64_t)pass.iteration * 7919u + (uint64_t)problem.index;  // the reference seeds with clock64()
+    problem.iteration = pass.iteration;
+    problem.show_medium_result = true;
+    problem.scale_size = pass.scale_size;
+}
+
+static const char *const kStateFiles[4] = {"depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"};
+
+
+// host/multi_device.cpp: every pass on all listed devices (views round-robin), state resident on the devices, depth maps
+// all-gathered after every pass.  Returns the process exit code.
+int RunMultiDevice(const Options &opt, std::vector<Problem> &problems);
+
+// APD.h:34 with the maps already in memory (index = problem index); RunFusion reads them from the result folders instead
+struct FinalMaps {
+    Mat depth, normal, weak;
+};
+void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps);
+
+#endif  // APD_MI355X_HOST_SCHEDULE_H_

@@ -169,6 +169,36 @@ size_t apd_state_bytes(apd_handle h, int which);
  * are DEVICE pointers (e.g. torch tensors handed to an RCCL all-gather). */
 int apd_export_depth_normal_device(apd_handle h, float *depth_dev, float *normal_dev);
 
+/* The same post-processing in the layout apd_upload_prior takes, left on the device (a scheduler that keeps state resident
+ * between passes): planes4 = (world normal xyz, depth w) with an out-of-range depth -> 0 and its pixel UNKNOWN in `weak`
+ * (main.cpp:109-112), selected views, and the depth map alone (what the geometric term of the next pass reads,
+ * APD.cpp:492-509).  DEVICE pointers, W*H elements each; any may be NULL. */
+int apd_export_state_device(apd_handle h, float *planes4_dev, uint8_t *weak_dev, uint32_t *views_dev, float *depth_dev);
+
+/* ---- several devices in one process (one host thread + one stream per device) ----------------------------
+ * The reference takes one device index (main.cpp:149-153).  A multi-device host shards the reference views over devices
+ * and needs, besides the handles above (one per device, each used from its own thread): device memory without a HIP
+ * toolchain, the nearest-neighbour resampling of prior state between pyramid levels (RescaleMatToTargetSize,
+ * APD.cpp:752-774, swapped factors included) on the device, and the all-gather of per-view maps after every pass -- the
+ * exchange the reference does through depths.dmb files (APD.cpp:497-500). */
+int apd_device_malloc(int device, size_t bytes, void **out);
+int apd_device_free(int device, void *p);
+int apd_device_memcpy(int device, void *dst, const void *src, size_t bytes);   /* host or device pointers on either side */
+int apd_device_memset(int device, void *dst, int value, size_t bytes);
+int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes /* 1, 4, 16 */);
+
+/* All-gather across `num_ranks` ranks of this process, rank r on devices[r]: after apd_exchange_allgather every recv[r]
+ * holds send[0] | send[1] | ... (bytes_per_rank each).  prefer_rccl != 0: RCCL (ncclCommInitAll, grouped ncclAllGather,
+ * one stream per rank; librccl is opened at run time); direct hipMemcpyPeerAsync copies when librccl is missing, when its
+ * initialisation fails or when the list names a device twice (how a one-GPU box runs the multi-device scheduler).
+ * Blocking; not thread-safe per exchange object. */
+typedef struct apd_exchange *apd_exchange_t;
+int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl);
+int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank);
+const char *apd_exchange_backend(apd_exchange_t x);   /* "rccl" or "peer-copy" */
+int apd_exchange_destroy(apd_exchange_t x);
+const char *apd_exchange_last_error(void);
+
 /* Getters of APD.h:76-81. */
 int apd_width(apd_handle h);
 int apd_height(apd_handle h);

@@ -10,7 +10,20 @@
 #include <stdint.h>
 #include <stdio.h>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
-constexpr int kIter = 512;
+constexpr int kIter = 256;
+
+// quad-level patterns: quad q of the wave sits in its own 128-byte line (q * 256 bytes apart), the four lanes of a quad are
+// `stride` bytes apart starting `shift` bytes into the line; order 0 ascending, 1 descending, 2 shuffled (0, 2, 1, 3)
+__device__ __forceinline__ uint32_t quad_pattern(uint32_t lane, uint32_t stride, uint32_t shift, int order)
+{
+    uint32_t k = lane & 3u;
+    if (order == 1) {
+        k = 3u - k;
+    } else if (order == 2) {
+        k = (k == 1u) ? 2u : (k == 2u ? 1u : k);
+    }
+    return (lane >> 2) * 256u + shift + k * stride;
+}
 
 __device__ __forceinline__ uint32_t pattern_offset(int p, uint32_t lane)
 {
@@ -21,17 +34,34 @@ __device__ __forceinline__ uint32_t pattern_offset(int p, uint32_t lane)
     case 3: return lane * 16u;                                  // 8 lines
     case 4: return lane * 64u;                                  // two lanes per line
     case 5: return lane * 128u;                                 // one line per lane
-    case 6: return (lane >> 2) * 128u + (lane & 3u) * 4u;       // quads contiguous, one line per quad
-    case 7: return (lane >> 2) * 128u + (lane & 3u) * 16u;      // quads inside one line, not contiguous
-    case 8: return (lane >> 2) * 128u;                          // quads on ONE dword, one line per quad
-    case 9: return (lane >> 4) * 128u + (lane & 15u) * 4u;      // 16 contiguous lanes per line
+    case 6: return quad_pattern(lane, 4u, 0u, 0);               // quads contiguous, one line per quad
+    case 7: return quad_pattern(lane, 16u, 0u, 0);              // quads in one line, 16 B apart
+    case 8: return quad_pattern(lane, 0u, 0u, 0);               // quads on ONE dword
+    case 9: return (lane >> 4) * 256u + (lane & 15u) * 4u;      // 16 contiguous lanes per line
     case 10: return 0u;                                         // every lane the same dword
-    case 11: return (lane >> 1) * 128u + (lane & 1u) * 4u;      // pairs contiguous
+    case 11: return (lane >> 1) * 128u + (lane & 1u) * 4u;      // pairs contiguous, one line per pair
     case 12: return ((lane * 37u) & 63u) * 4u;                  // contiguous 256 B, lanes shuffled
     case 13: return (lane / 9u) * 1536u + ((lane % 9u) / 3u) * 512u + ((lane % 9u) % 3u) * 10u;  // tap-cooperative sub-patch: 9 lanes on 3 rows, taps 10 B apart
     case 14: return (lane / 9u) * 1536u + ((lane % 9u) / 3u) * 512u + ((lane % 9u) % 3u) * 4u;   // the same with contiguous taps
     case 15: return (lane & 31u) * 4u + (lane >> 5) * 4096u;    // two half-waves, each 128 contiguous bytes
-    default: return (lane * 2654435761u >> 18) & ~3u;           // 64 scattered dwords inside the 16 KB window
+    case 16: return (lane * 2654435761u >> 18) & ~3u;           // 64 scattered dwords inside the 16 KB window
+    case 17: return quad_pattern(lane, 2u, 0u, 0);              // quad lanes 2 B apart (overlapping dwords)
+    case 18: return quad_pattern(lane, 6u, 0u, 0);              // 6 B apart
+    case 19: return quad_pattern(lane, 8u, 0u, 0);              // 8 B apart: 28 B span
+    case 20: return quad_pattern(lane, 10u, 0u, 0);             // 10 B apart (sub-patch taps): 34 B span
+    case 21: return quad_pattern(lane, 12u, 0u, 0);
+    case 22: return quad_pattern(lane, 4u, 2u, 0);              // contiguous, 2-byte aligned
+    case 23: return quad_pattern(lane, 4u, 24u, 0);             // contiguous, straddles a 32-byte boundary
+    case 24: return quad_pattern(lane, 4u, 56u, 0);             // contiguous, straddles a 64-byte boundary
+    case 25: return quad_pattern(lane, 4u, 120u, 0);            // contiguous, straddles a 128-byte line
+    case 26: return quad_pattern(lane, 4u, 0u, 1);              // contiguous, descending
+    case 27: return quad_pattern(lane, 4u, 0u, 2);              // contiguous, shuffled
+    case 28: return quad_pattern(lane, 8u, 0u, 2);              // 8 B apart, shuffled
+    case 29: return (lane >> 3) * 256u + (lane & 7u) * 4u;      // 8 contiguous lanes per line
+    case 30: return (lane >> 3) * 256u + (lane & 7u) * 4u + 2u; // the same, 2-byte aligned
+    case 31: return (lane >> 3) * 256u + ((lane & 7u) < 6u ? (lane & 7u) : 5u) * 4u + 2u;  // six taps + two repeats of the last (a 6-tap patch row in 8 lanes)
+    case 32: return (lane >> 3) * 256u + ((lane & 7u) < 6u ? (lane & 7u) * 4u + ((lane & 7u) >= 3u ? 2u : 0u) : 22u);  // six taps with one 3-px step in the middle
+    default: return (lane >> 2) * 256u + ((lane & 3u) < 3u ? (lane & 3u) * 10u : 20u);  // 33: three sub-patch taps 10 B apart + a repeat of the third
     }
 }
 
@@ -45,12 +75,14 @@ __global__ __launch_bounds__(256) void gather(const unsigned char *__restrict__ 
 #pragma unroll 8
     for (int i = 0; i < kIter; ++i) {
         uint32_t v;
-        __builtin_memcpy(&v, base + ((off + (uint32_t)i * 8192u) & 16383u), 4);  // alternate between the two halves of the window
+        const unsigned char *addr = base + off;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(addr) : "memory");  // opaque: one gather per iteration
         acc += v;
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+constexpr int kPatterns = 34;
 int main()
 {
     const uint32_t windows = 2048;  // 32 MB: stays in L2 / Infinity Cache; each wave's 16 KB window stays in its L1
@@ -60,15 +92,20 @@ int main()
     CHECK(hipMalloc(&buf, (size_t)windows * 16384u + 64));
     CHECK(hipMemset(buf, 1, (size_t)windows * 16384u + 64));
     CHECK(hipMalloc(&out, (size_t)blocks * 256 * sizeof(uint32_t)));
-    static const char *names[17] = {"lane*4 (contiguous)", "lane*4+2 (contiguous, 2-byte aligned)", "lane*8", "lane*16", "lane*64", "lane*128 (one line per lane)",
+    static const char *names[kPatterns] = {"lane*4 (contiguous)", "lane*4+2 (contiguous, 2-byte aligned)", "lane*8", "lane*16", "lane*64", "lane*128 (one line per lane)",
                                     "quads contiguous, one line per quad", "quads in one line, 16 B apart", "quads on one dword", "16 contiguous lanes per line",
                                     "all lanes one dword", "pairs contiguous, one line per pair", "contiguous 256 B, lanes shuffled",
                                     "coop sub-patch: 9 lanes, 3 rows, taps 10 B apart", "coop sub-patch: 9 lanes, 3 rows, taps contiguous",
-                                    "two half-waves, 128 B each", "64 scattered dwords in 16 KB"};
+                                    "two half-waves, 128 B each", "64 scattered dwords in 16 KB",
+                                    "quad 2 B apart", "quad 6 B apart", "quad 8 B apart", "quad 10 B apart", "quad 12 B apart", "quad contiguous, 2-byte aligned",
+                                    "quad contiguous across a 32 B boundary", "quad contiguous across a 64 B boundary", "quad contiguous across a 128 B line",
+                                    "quad contiguous, descending", "quad contiguous, shuffled", "quad 8 B apart, shuffled", "8 contiguous lanes per line",
+                                    "8 contiguous lanes per line, 2-byte aligned", "6 taps + 2 repeats in 8 lanes, 2-byte aligned", "6 taps with a 3-px step in 8 lanes",
+                                    "3 taps 10 B apart + 1 repeat per quad"};
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int p = 0; p < 17; ++p) {
+    for (int p = 0; p < kPatterns; ++p) {
         hipLaunchKernelGGL(gather, dim3(blocks), dim3(256), 0, 0, buf, p, windows, out);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
