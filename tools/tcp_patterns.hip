@@ -82,6 +82,35 @@ __global__ __launch_bounds__(256) void gather(const unsigned char *__restrict__ 
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// The same question for wider loads: does a lane that reads an ALIGNED 8- or 16-byte block pay one access or one per dword?
+// (If one, a software texture fetch that needs several neighbouring texels of a row can take them with one load.)
+// Patterns: 0 every lane its own 128-byte line, 1 quads of lanes on four consecutive blocks, 2 lane * width (contiguous).
+template <int DWORDS>
+__global__ __launch_bounds__(256) void gather_wide(const unsigned char *__restrict__ buf, int p, uint32_t windows, uint32_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const unsigned char *base = buf + (size_t)((wave * 7919u) % windows) * 16384u;
+    const uint32_t w = 4u * DWORDS;
+    const uint32_t off = p == 0 ? lane * 128u : (p == 1 ? (lane >> 2) * 256u + (lane & 3u) * w : lane * w);
+    uint32_t acc = 0;
+#pragma unroll 8
+    for (int i = 0; i < kIter; ++i) {
+        const unsigned char *addr = base + off;
+        if constexpr (DWORDS == 2) {
+            uint64_t v;
+            asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+            acc += (uint32_t)v + (uint32_t)(v >> 32);
+        } else {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            u4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+            acc += v.x + v.y + v.z + v.w;
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 constexpr int kPatterns = 34;
 int main()
 {
@@ -116,6 +145,28 @@ int main()
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         const double gathers = (double)blocks * 4 * kIter;
         printf("pattern %2d  %-52s %8.3f ms  %7.2f ns per wave-level gather per CU\n", p, names[p], ms, ms * 1e6 / (gathers / 256.0));
+    }
+    static const char *wide_names[3] = {"one 128-byte line per lane", "quads of lanes on 4 consecutive blocks, one line pair per quad", "lane * width (contiguous)"};
+    for (int width = 2; width <= 4; width += 2) {
+        for (int p = 0; p < 3; ++p) {
+            for (int rep = 0; rep < 2; ++rep) {
+                if (rep == 1) {
+                    CHECK(hipEventRecord(e0));
+                }
+                if (width == 2) {
+                    hipLaunchKernelGGL(gather_wide<2>, dim3(blocks), dim3(256), 0, 0, buf, p, windows, out);
+                } else {
+                    hipLaunchKernelGGL(gather_wide<4>, dim3(blocks), dim3(256), 0, 0, buf, p, windows, out);
+                }
+                CHECK(hipDeviceSynchronize());
+            }
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double gathers = (double)blocks * 4 * kIter;
+            printf("dwordx%d pattern %d  %-60s %8.3f ms  %7.2f ns per wave-level gather per CU\n", width, p, wide_names[p], ms, ms * 1e6 / (gathers / 256.0));
+        }
     }
     return 0;
 }
