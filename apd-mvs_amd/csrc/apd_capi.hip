@@ -520,10 +520,6 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         vc.quad = c->quads[v + 1];
         vc.quad_tiled = c->quads_tiled[v + 1];
         vc.fquad = c->fquads[v + 1];
-#ifdef APD_EXPERIMENT_ALIAS_VIEWS  // timing experiment only (wrong results): every source view reads the first one's image
-        vc.quad = c->quads[1];
-        vc.fquad = c->fquads[1];
-#endif
     }
     HIP_TRY(hipMemcpyAsync(c->views_dev, vcs.data(), vcs.size() * sizeof(ViewConst), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -128,11 +128,7 @@ struct FrameArgs {
 typedef const __attribute__((address_space(4))) ViewConst *const_view_ptr;
 __device__ __forceinline__ const ViewConst &view_const(const FrameArgs &fa, int v)
 {
-#ifdef APD_VIEWS_GENERIC
-    return fa.views[v];
-#else
     return *(const ViewConst *)((const_view_ptr)(uintptr_t)fa.views + v);
-#endif
 }
 
 
@@ -656,11 +652,7 @@ __device__ __forceinline__ void ref_patch_from_global(RefPatch &rp, const float 
 // ~5 (tools/valu_rates.hip), and only 2-3 waves fit a SIMD here, so the six samples of a patch row are
 // computed in lock step: every stage below is six independent instructions, and the scheduler is not
 // allowed to re-serialise the chains to save registers.
-#ifdef APD_NO_STAGE  // A/B: let the scheduler interleave the stages (measured slower: it re-serialises the chains to save registers)
-#define APD_STAGE() ((void)0)
-#else
 #define APD_STAGE() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 // byte offset of a 16-byte float quad entry (qx, qy): qy*pitch + (pitch + 16) + 16*qx with pitch = (W+1)*16 bytes
 __device__ __forceinline__ unsigned fquad_byte_offset(int qx, int qy, int pitch, int origin)
@@ -748,28 +740,6 @@ __device__ __forceinline__ void quad_row_issue(const Homography &H, float bx, fl
         }
     }
     APD_STAGE();
-#ifdef APD_EXPERIMENT_QUAD_SAME_ADDR  // timing experiment only (wrong results): the 4 lanes of a quad gather one address
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = __builtin_amdgcn_mov_dpp(qx[j], 0x00, 0xF, 0xF, true);
-    }
-    APD_STAGE();
-#endif
-#ifdef APD_EXPERIMENT_ADDR_ZERO  // timing experiment only: every gather hits the same L1 line
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        qx[j] = qx[j] & (0x80 - (int)kQuadBytes);
-    }
-    APD_STAGE();
-#endif
-#ifdef APD_EXPERIMENT_NO_LOADS  // timing experiment only: no gathers at all
-#pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        const uint32_t fake = (uint32_t)qx[j] * 2654435761u;
-        t[j] = fake;
-    }
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
         t[j] = quad_fetch(srcq, (unsigned)qx[j]);
@@ -921,16 +891,8 @@ template <bool kQuad, int kRecip, bool kTiled, typename Ref>
 __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H_in,
                                                   int px_in, int py_in, float &sum_s, float &sum_ss, float &sum_rs)
 {
-#ifdef APD_EXPERIMENT_TRANSPOSE  // timing experiment only (summation order differs from the contract): batches of fixed y, six x
-    Homography H;
-    H.h[0] = H_in.h[1], H.h[1] = H_in.h[0], H.h[2] = H_in.h[2];
-    H.h[3] = H_in.h[4], H.h[4] = H_in.h[3], H.h[5] = H_in.h[5];
-    H.h[6] = H_in.h[7], H.h[7] = H_in.h[6], H.h[8] = H_in.h[8];
-    const int px = py_in, py = px_in;
-#else
     const Homography &H = H_in;
     const int px = px_in, py = py_in;
-#endif
     const global_quad_ptr srcq = (global_quad_ptr)(kTiled ? vc.quad_tiled : vc.quad);
     const int W = fa.W, Hh = fa.H;
     const unsigned qpitch = kTiled ? quad_tiles_x(W) : quad_row_pitch_bytes(W);
@@ -1148,13 +1110,6 @@ __device__ __forceinline__ void subpatch_issue_quad(const Homography &H, global_
         qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)qpitch, (int)(qpitch + kRowEntryBytes));
     }
     APD_STAGE();
-#ifdef APD_EXPERIMENT_SUB_ADDR_ZERO  // timing experiment only: every sub-patch gather hits the same L1 line
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        qx[k] = qx[k] & (0x80 - (int)kQuadBytes);
-    }
-    APD_STAGE();
-#endif
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         t[k] = quad_fetch(srcq, (unsigned)qx[k]);

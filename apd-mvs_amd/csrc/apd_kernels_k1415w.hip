@@ -502,6 +502,6 @@ hipError_t launch_k15_windowed(const FrameArgs &fa, hipStream_t s)
 }  // namespace apd
 
 
-#ifdef APD_EXPERIMENT_WIN_STATS
+#ifdef APD_LAB_WIN_STATS
 APD_WIN_STATS_ACCESSOR(apd_debug_win_stats_k1415)
 #endif

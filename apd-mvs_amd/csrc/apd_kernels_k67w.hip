@@ -209,15 +209,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
         const ViewConst &vc = view_const(fa, v);
-#ifdef APD_EXPERIMENT_SKIP_GLOBAL
-        SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
-        w.valid |= (iter >= APD_EXPERIMENT_SKIP_GLOBAL) ? 2 : 0;
-#elif defined(APD_EXPERIMENT_STAGE_TWICE)  // timing experiment (same results): what staging a window costs
-        stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
         const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
-#else
-        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
-#endif
         if (alive) {
             // The candidate planes are re-read per view: eight float4 do not fit the register budget.  Hiding that read was
             // tried twice in round 2 and is not worth it: loading candidate h + 1 into registers before candidate h is scored
@@ -323,15 +315,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
             continue;  // nobody in the wave has anything left to score in this view
         }
         const ViewConst &vc = view_const(fa, v);
-#ifdef APD_EXPERIMENT_SKIP_GLOBAL
-        SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
-        w.valid |= (iter >= APD_EXPERIMENT_SKIP_GLOBAL) ? 2 : 0;
-#elif defined(APD_EXPERIMENT_STAGE_TWICE)  // timing experiment (same results): what staging a window costs
-        stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
         const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
-#else
-        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
-#endif
         if (open != 0) {
 #pragma unroll 1
             for (int k = 0; k < 5; ++k) {
@@ -424,6 +408,6 @@ hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStr
 }  // namespace apd
 
 
-#ifdef APD_EXPERIMENT_WIN_STATS
+#ifdef APD_LAB_WIN_STATS
 APD_WIN_STATS_ACCESSOR(apd_debug_win_stats)
 #endif

@@ -66,7 +66,7 @@ __device__ __forceinline__ WinTaps<E> lds_read_pair(int addr)
     return t;
 }
 
-#ifdef APD_EXPERIMENT_WIN_STATS  // diagnostic build only: [0] NCCs through the window, [1] global fast, [2] global slow,
+#ifdef APD_LAB_WIN_STATS  // diagnostic build only: [0] NCCs through the window, [1] global fast, [2] global slow,
                                  // [3] wave-level NCC calls, [4] of those with both window and global lanes, [5] windows staged
 static __device__ unsigned long long g_k67w_stats[8];  // one copy per translation unit (no relocatable device code)
 #define APD_WIN_COUNT(i, n) atomicAdd(&g_k67w_stats[i], (unsigned long long)(n))
@@ -438,7 +438,7 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
         const float yl = fminf(fminf(Y00, Y01), fminf(Y10, Y11)), yh = fmaxf(fmaxf(Y00, Y01), fmaxf(Y10, Y11));
         in_window = xl >= w.lo_x && xh < w.hi_x && yl >= w.lo_y && yh < w.hi_y;
     }
-#ifdef APD_EXPERIMENT_WIN_STATS
+#ifdef APD_LAB_WIN_STATS
     {
         const unsigned long long m_all = __builtin_amdgcn_ballot_w64(true), m_in = __builtin_amdgcn_ballot_w64(in_window);
         if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_all)) {
@@ -459,11 +459,6 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
     const bool fast_body = fast_recip;
 #endif
     float sum_s, sum_ss, sum_rs;
-#ifdef APD_EXPERIMENT_SKIP_GLOBAL  // timing experiment only (wrong results): what the NCCs outside the window cost
-    if (!in_window && (w.valid & 2)) {  // bit 1 is set by K6/K7 from iteration APD_EXPERIMENT_SKIP_GLOBAL on
-        return 2.0f;
-    }
-#endif
     if (in_window) {
         ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
     } else if constexpr (kApprox) {

@@ -1,4 +1,4 @@
-"""Window hit statistics of the K6/K7 LDS-window kernel, per iteration (library built with -DAPD_EXPERIMENT_WIN_STATS).
+"""Window hit statistics of the K6/K7 LDS-window kernel, per iteration (library built with -DAPD_LAB_WIN_STATS).
 Usage: python tools/win_stats.py [W H N iters]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
