@@ -784,7 +784,11 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             if (h < 8 && !(flags & (1u << h))) {
                 continue;
             }
-            const float4 pl = (h < 8) ? candidate_plane(fa, nb, h) : plane_now;
+            float4 pl = plane_now;
+            if (h < 8) {  // the neighbour's position is already in LDS (weak_prepare_neighbours): one global load instead of two dependent ones
+                const int packed = lds.nb[h][lane];
+                pl = fa.planes[(int)(short)(packed & 0xFFFF) + (packed >> 16) * W];
+            }
             cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
         }
     }

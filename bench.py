@@ -37,6 +37,7 @@ NUM_SIMDS = 1024
 MAX_CLOCK_GHZ = 2.4
 VALU_CYCLES_PER_WAVE_INST = 2.0
 VALU_PEAK_GINST = NUM_SIMDS * MAX_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INST  # G wave64 instructions / s
+TCP_ACCESSES_PER_CLOCK = 1.85  # L1 tag accesses per clock and CU with every access a hit (profiles/r02/unaligned_gather.txt: 59 in 32 cycles)
 
 WORKLOADS = {
     # name: (width, height, num_src)
@@ -249,7 +250,7 @@ def main():
     h.profile_enable(False)
 
     # after the timed region: post-loop kernels + all-gather of depth/normal maps (before fusion)
-    allgather_ms = None
+    allgather_ms = pass_allgather_ms = None
     t_post0 = time.perf_counter()
     for kid in (pkg.K11, pkg.K12, pkg.K13):
         h.run_kernel(kid)
@@ -262,6 +263,8 @@ def main():
         torch.cuda.synchronize()
         ta = time.perf_counter()
         gathered_d = sharding.allgather_maps({rank: depth.view(H, W, 1)}, world)   # view index == rank here
+        torch.cuda.synchronize()
+        pass_allgather_ms = (time.perf_counter() - ta) * 1e3   # what every pass ends with: the sources' depth maps for the next one
         gathered_n = sharding.allgather_maps({rank: normal}, world)
         torch.cuda.synchronize()
         allgather_ms = (time.perf_counter() - ta) * 1e3
@@ -326,6 +329,7 @@ def main():
                                 % (args.workload, args.steps, args.warmup))
     kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0], 3) for k, v in sorted(prof.items())}
     weak_path = None
+    weak_roofline = None
     if apd_mode:
         k9, k10 = prof.get(pkg.K9, (0.0, 0)), prof.get(pkg.K10, (0.0, 0))
         wl = k9[1] + k10[1]
@@ -337,6 +341,35 @@ def main():
         # what bounds K9/K10: its scattered sub-patch gathers -- L1 tag look-ups per gather and the bytes the
         # misses pull through the fabric; counters from the profile of this same command line, time measured live
         wp = load_pmc_profile(args.workload, args.steps, args.warmup, "k910")
+        # K9/K10 owns most of an APD iteration: it is the dominant kernel of this workload and the line's `roofline`; the
+        # strong sweep's block moves to `strong_path`.  Bound: the L1 (TCP) tag pipeline -- a scattered dword gather costs one
+        # tag access per lane whatever the lines (tools/tcp_patterns.hip, profiles/r03/tcp_patterns.txt), and the pipeline
+        # sustains 1.85 accesses per clock and CU (tools/unaligned_gather.hip, profiles/r02/unaligned_gather.txt).
+        tag_peak = 256 * MAX_CLOCK_GHZ * TCP_ACCESSES_PER_CLOCK   # G accesses / s
+        weak_roofline = {"bound": "l1-tag-pipeline", "kernel": "k910_update_weak (Black/RedPixelUpdateWeak)", "achieved": None,
+                         "peak": round(tag_peak, 1), "unit": "Gaccess/s", "frac": None, "traffic": None, "avg_launch_ms": round(wms, 3),
+                         "launches": wl,
+                         "peak_note": "256 CUs x %.1f GHz x %.2f L1 tag accesses per clock (all-hit dword gathers, tools/unaligned_gather.hip)"
+                                      % (MAX_CLOCK_GHZ, TCP_ACCESSES_PER_CLOCK),
+                         "algorithmic": {"bytes_per_launch_nominal_max": wbytes, "bytes_per_weak_pixel_iter_nominal_max": algorithmic_bytes_per_weak_pixel(N),
+                                         "GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0,
+                                         "note": "SURVEY 8(d) nominal maximum (15 N NCCNew of 108 samples + N NCCOld, 20 B per sample); counts cache "
+                                                 "hits and early-outed hypotheses: NOT a roofline"},
+                         "pmc_source": None}
+        if wp and wms > 0 and wp.get("tcp_tag_accesses_per_launch"):
+            acc = wp["tcp_tag_accesses_per_launch"] / (wms * 1e-3) / 1e9
+            hbm_b = wp["hbm_bytes_per_launch"]
+            weak_roofline.update({"achieved": round(acc, 1), "frac": round(acc / tag_peak, 4), "traffic": hbm_b,
+                                  "tag_accesses_per_launch": wp["tcp_tag_accesses_per_launch"],
+                                  "hbm": {"achieved": round(hbm_b / (wms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "frac": round(hbm_b / (wms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": hbm_b,
+                                          "note": "2 x FETCH_SIZE + WRITE_SIZE per launch"},
+                                  "valu": {"achieved": round(wp["valu_insts_per_launch"] / (wms * 1e-3) / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1),
+                                           "unit": "Gwave-inst/s", "frac": round(wp["valu_insts_per_launch"] / (wms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)},
+                                  "pmc_source": wp["source"], "pmc_launch_ms": wp.get("launch_ms")})
+        else:
+            weak_roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s steps=%d warmup=%d under profiles/"
+                                         % (args.workload, args.steps, args.warmup))
         if wp and wms > 0 and wp.get("fetch_bytes_per_launch") and wp.get("vmem_rd_insts_per_launch"):
             fabric = wp["fetch_bytes_per_launch"] / (wms * 1e-3) / 1e9
             gathers = wp["vmem_rd_insts_per_launch"]
@@ -373,7 +406,8 @@ def main():
                        "state": "REFINE_INIT+APD" if apd_mode else "FIRST_INIT",
                        "views_per_gpu": 1, "parallelism": "views sharded, %d rank(s)" % world,
                        "backend": "nccl" if distributed else "single process", "options": args.opt},
-            "roofline": roofline,
+            "roofline": weak_roofline if apd_mode else roofline,
+            "strong_path": roofline if apd_mode else None,
             "cpu_baseline": cpu_baseline,
             "weak_path": weak_path,
             "iterations": {"first_ms": round(first_iter_s * 1e3, 3),
@@ -384,6 +418,9 @@ def main():
             "kernel_ms_timed_region": kernel_ms,
             "post_loop_ms": round(post_ms, 1),
             "allgather_ms": None if allgather_ms is None else round(allgather_ms, 3),
+            "pass_allgather_ms": None if pass_allgather_ms is None else round(pass_allgather_ms, 3),
+            "allgather_note": "RCCL all-gather over the ranks after the timed region: depth maps (the exchange that ends every pass, "
+                              "pass_allgather_ms) + normal maps (before fusion; allgather_ms is both)",
             "quality_within_1pct_depth": round(within, 4),
         }
         print(json.dumps(out), flush=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Recomputes every `roofline` field of the committed bench lines from the committed counter files, nothing else.
 
-    python tools/recompute_roofline.py [profiles/r02]
+    python tools/recompute_roofline.py [profiles/r03]
 
 For each bench line under the directory (bench_default.json, bench_driver_s20_w5.json, bench_apd_s3_w1.json, ...) it finds the
 counter profile of the same workload / --steps / --warmup (pmc_bench_<workload>_s<steps>_w<warmup>.json, written by
@@ -15,7 +15,9 @@ tools/profile_bench.py from separate rocprofv3 --pmc passes), re-derives
     valu_busy_estimate = SQ_INSTS_VALU x mean issue cycles of the window body (valu_mix_k67w.json) / (1024 x 2.4 GHz x time)
     profile vs live    = launch duration in the rocprofv3 kernel trace against the HIP-event duration of the bench line
 
-and compares them with what the line says.  Exits non-zero on any mismatch; tests/test_profiles_consistent.py runs it."""
+(for an APD workload, whose `roofline` is the weak sweep's against the L1 tag pipeline: TCP_TOTAL_CACHE_ACCESSES per launch / live
+launch time / (256 CUs x 2.4 GHz x 1.85 accesses per clock), its `strong_path` block like a K6/K7 roofline) and compares them
+with what the line says.  Exits non-zero on any mismatch; tests/test_profiles_consistent.py runs it."""
 import glob
 import json
 import os
@@ -30,9 +32,77 @@ def close(a, b, rel):
     return abs(a - b) <= rel * max(abs(a), abs(b), 1e-30)
 
 
+TAG_PEAK = 256 * 2.4 * 1.85  # G L1 tag accesses / s (bench.py: TCP_ACCESSES_PER_CLOCK)
+
+
+def load_mix(directory):
+    """valu_mix_k67w.json of this directory, else the newest one of an earlier round (the window body has not changed)."""
+    cands = [os.path.join(directory, "valu_mix_k67w.json")] + sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "valu_mix_k67w.json")), reverse=True)
+    for c in cands:
+        if os.path.exists(c):
+            return json.load(open(c))["window_body"]["mean_cycles_per_inst"]
+    raise SystemExit("no valu_mix_k67w.json under profiles/")
+
+
+def check_k67(tag, roof, k, mix, problems):
+    pd = k["per_dispatch_timed"]
+    n = k["launches_timed"]
+    mean = lambda c: sum(pd[c][-n:]) / n
+    insts = mean("SQ_INSTS_VALU")
+    traffic = mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024
+    t = roof["avg_launch_ms"] * 1e-3
+    achieved = insts / t / 1e9
+    for what, got, want, rel in (
+            ("launches", roof["launches"], n, 0),
+            ("valu_insts_per_launch", roof["valu_insts_per_launch"], insts, 1e-9),
+            ("achieved", roof["achieved"], achieved, 1e-3),
+            ("frac", roof["frac"], achieved / PEAK, 1e-3),
+            ("peak", roof["peak"], PEAK, 1e-6),
+            ("traffic", roof["traffic"], traffic, 1e-9),
+            ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
+            ("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),
+            ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03)):
+        ok = got == want if rel == 0 else close(got, want, rel)
+        if not ok:
+            problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
+    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or roof["valu_busy_estimate"]["frac"] > 1:
+        problems.append("%s: a fraction above 1" % tag)
+    return "k67 frac %.4f  hbm %.4f  busy %.4f  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
+        achieved / PEAK, traffic / t / 1e9 / HBM, insts * mix / (1024 * 2.4e9 * t), n, t * 1e3, mean("duration_ns@trace") * 1e-6)
+
+
+def check_k910(tag, roof, k, problems):
+    """APD workloads: the line's roofline is the weak sweep's, against the L1 tag pipeline."""
+    pd = k["per_dispatch_timed"]
+    n = k["launches_timed"]
+    mean = lambda c: sum(pd[c][-n:]) / n
+    acc = mean("TCP_TOTAL_CACHE_ACCESSES_sum")
+    insts = mean("SQ_INSTS_VALU")
+    traffic = mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024
+    t = roof["avg_launch_ms"] * 1e-3
+    achieved = acc / t / 1e9
+    for what, got, want, rel in (
+            ("launches", roof["launches"], n, 0),
+            ("tag_accesses_per_launch", roof["tag_accesses_per_launch"], acc, 1e-9),
+            ("achieved", roof["achieved"], achieved, 1e-3),
+            ("frac", roof["frac"], achieved / TAG_PEAK, 1e-3),
+            ("peak", roof["peak"], TAG_PEAK, 1e-3),
+            ("traffic", roof["traffic"], traffic, 1e-9),
+            ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
+            ("valu.frac", roof["valu"]["frac"], insts / t / 1e9 / PEAK, 2e-3),
+            ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03)):
+        ok = got == want if rel == 0 else close(got, want, rel)
+        if not ok:
+            problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
+    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or roof["valu"]["frac"] > 1:
+        problems.append("%s: a fraction above 1" % tag)
+    return "k910 tag frac %.4f  hbm %.4f  valu %.4f  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
+        achieved / TAG_PEAK, traffic / t / 1e9 / HBM, insts / t / 1e9 / PEAK, n, t * 1e3, mean("duration_ns@trace") * 1e-6)
+
+
 def check(directory):
     problems, lines = [], 0
-    mix = json.load(open(os.path.join(directory, "valu_mix_k67w.json")))["window_body"]["mean_cycles_per_inst"]
+    mix = load_mix(directory)
     for path in sorted(glob.glob(os.path.join(directory, "bench_*.json"))):
         with open(path) as f:
             first = f.readline()
@@ -49,34 +119,17 @@ def check(directory):
         if not os.path.exists(prof_path):
             problems.append("%s: cites counters but %s is not committed" % (os.path.basename(path), name))
             continue
-        k = json.load(open(prof_path))["kernels"]["k67"]
-        pd = k["per_dispatch_timed"]
-        n = k["launches_timed"]
-        mean = lambda c: sum(pd[c][-n:]) / n
-        insts = mean("SQ_INSTS_VALU")
-        traffic = mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024
-        t = roof["avg_launch_ms"] * 1e-3
-        achieved = insts / t / 1e9
+        kernels = json.load(open(prof_path))["kernels"]
         tag = os.path.basename(path)
         lines += 1
-        for what, got, want, rel in (
-                ("launches", roof["launches"], n, 0),
-                ("valu_insts_per_launch", roof["valu_insts_per_launch"], insts, 1e-9),
-                ("achieved", roof["achieved"], achieved, 1e-3),
-                ("frac", roof["frac"], achieved / PEAK, 1e-3),
-                ("peak", roof["peak"], PEAK, 1e-6),
-                ("traffic", roof["traffic"], traffic, 1e-9),
-                ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
-                ("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),
-                ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03)):
-            ok = got == want if rel == 0 else close(got, want, rel)
-            if not ok:
-                problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
-        if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or roof["valu_busy_estimate"]["frac"] > 1:
-            problems.append("%s: a fraction above 1" % tag)
-        print("%-28s %s  frac %.4f  hbm %.4f  busy %.4f  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
-            tag, cfg["workload"], achieved / PEAK, traffic / t / 1e9 / HBM, insts * mix / (1024 * 2.4e9 * t), n, t * 1e3,
-            mean("duration_ns@trace") * 1e-6))
+        if roof.get("bound") == "l1-tag-pipeline":
+            msg = check_k910(tag, roof, kernels["k910"], problems)
+            strong = line.get("strong_path")
+            if strong and strong.get("achieved") is not None:
+                msg += " | " + check_k67(tag + " strong_path", strong, kernels["k67"], mix, problems)
+        else:
+            msg = check_k67(tag, roof, kernels["k67"], mix, problems)
+        print("%-36s %s  %s" % (tag, cfg["workload"], msg))
     return problems, lines
 
 
