@@ -435,35 +435,51 @@ APD::~APD()
     }
 }
 
+// InuputInitialization (sic, APD.cpp:399-583) in five steps; the log lines are the reference's.
 void APD::InuputInitialization()
 {
-    images.clear();
-    cameras.clear();
-    const path image_folder = problem.dense_folder / path("images");
-    const path cam_folder = problem.dense_folder / path("cams");
-    // reference image then source images (APD.cpp:409-427)
-    std::vector<int> ids;
-    ids.push_back(problem.ref_image_id);
-    for (int id : problem.src_image_ids) {
-        ids.push_back(id);
-    }
-    for (size_t i = 0; i < ids.size(); ++i) {
-        Mat image_float;
-        if (!ReadGrayImage(image_folder / path(ToFormatIndex(ids[i])), image_float)) {
+    const std::vector<int> ids = LoadViewSet();
+    ApplyPyramidLevel(ids);
+    std::cout << "Image size: " << width << " * " << height << std::endl;
+    // The device path keeps every view as width x height floats (apd_upload_views copies exactly that much from every
+    // pointer): a source image of another size than the reference image is refused here, with the message the reference's
+    // CheckImages prints for mismatching reference images (main.cpp:51-70, :158).
+    for (int i = 0; i < num_images; ++i) {
+        const Mat &im = images[i];
+        if (im.cols != width || im.rows != height || im.type != MAT_32FC1) {
+            std::cerr << "Images may error, check it! (image " << ids[i] << " is " << im.cols << " * " << im.rows << ", expected " << width
+                      << " * " << height << ")\n";
             exit(EXIT_FAILURE);
         }
-        if (i == 0) {
-            width = image_float.cols;
-            height = image_float.rows;
-        }
-        images.push_back(image_float);
     }
-    if (images.size() > MAX_IMAGES) {
-        std::cerr << "Can't process so much images: " << images.size() << std::endl;
+    LoadGeometricDepths();
+    LoadWeakMap();
+    LoadPriorState();
+}
+
+// Reference image first, then the sources in pair.txt order, with their cameras (APD.cpp:409-461); the depth search range
+// is [0.6 depth_min, 1.2 depth_max] of the reference camera.
+std::vector<int> APD::LoadViewSet()
+{
+    std::vector<int> ids{problem.ref_image_id};
+    ids.insert(ids.end(), problem.src_image_ids.begin(), problem.src_image_ids.end());
+    if (ids.size() > MAX_IMAGES) {
+        std::cerr << "Can't process so much images: " << ids.size() << std::endl;
         exit(EXIT_FAILURE);
     }
+    const path image_folder = problem.dense_folder / path("images");
+    const path cam_folder = problem.dense_folder / path("cams");
+    images.assign(ids.size(), Mat());
+    cameras.assign(ids.size(), Camera());
     for (size_t i = 0; i < ids.size(); ++i) {
-        Camera cam;
+        if (!ReadGrayImage(image_folder / path(ToFormatIndex(ids[i])), images[i])) {
+            exit(EXIT_FAILURE);
+        }
+    }
+    width = images[0].cols;
+    height = images[0].rows;
+    for (size_t i = 0; i < ids.size(); ++i) {
+        Camera &cam = cameras[i];
         memset(&cam, 0, sizeof(cam));
         if (!ReadCamera(cam_folder / path(ToFormatIndex(ids[i]) + "_cam.txt"), cam)) {
             std::cerr << "Can't read camera " << ids[i] << std::endl;
@@ -471,163 +487,164 @@ void APD::InuputInitialization()
         }
         cam.width = width;
         cam.height = height;
-        cameras.push_back(cam);
     }
+    num_images = (int)ids.size();
+    params_host.num_images = num_images;
     params_host.depth_min = cameras[0].depth_min * 0.6f;
     params_host.depth_max = cameras[0].depth_max * 1.2f;
-    params_host.num_images = (int)images.size();
-    num_images = (int)images.size();
     std::cout << "Read images and camera done\n";
     std::cout << "Depth range: " << params_host.depth_min << " " << params_host.depth_max << std::endl;
     std::cout << "Num images: " << params_host.num_images << std::endl;
-    // scale images and intrinsics (APD.cpp:464-488)
-    if (problem.scale_size != 1) {
-        for (int i = 0; i < num_images; ++i) {
-            const float factor = 1.0f / (float)(problem.scale_size);
-            const int new_cols = (int)std::round(images[i].cols * factor);
-            const int new_rows = (int)std::round(images[i].rows * factor);
-            const float scale_x = new_cols / static_cast<float>(images[i].cols);
-            const float scale_y = new_rows / static_cast<float>(images[i].rows);
-            // the resampled level image of a file is the same for every (view, pass) of the run: computed once per
-            // process (see ReadGrayImage for the rationale), handed out as a copy
-            static std::unordered_map<std::string, Mat> level_cache;
-            const std::string key = (image_folder / path(ToFormatIndex(ids[i]))).string() + "@" + std::to_string(new_cols) + "x" +
-                                    std::to_string(new_rows);
+    return ids;
+}
+
+// Images and intrinsics of pyramid level `scale_size` (APD.cpp:464-488): new size = round(old / scale), cv::resize
+// INTER_LINEAR on the float image, K scaled with the actual ratios.  The resampled image of a file is the same for every
+// (view, pass) of the run: computed once per process (see ReadGrayImage for the rationale) and handed out as a copy.
+void APD::ApplyPyramidLevel(const std::vector<int> &ids)
+{
+    if (problem.scale_size == 1) {
+        return;
+    }
+    static std::unordered_map<std::string, Mat> level_cache;
+    static const bool cache_on = getenv("APD_IMAGE_CACHE_MB") == nullptr || atoll(getenv("APD_IMAGE_CACHE_MB")) > 0;
+    const path image_folder = problem.dense_folder / path("images");
+    const float factor = 1.0f / (float)(problem.scale_size);
+    for (int i = 0; i < num_images; ++i) {
+        const int old_cols = images[i].cols, old_rows = images[i].rows;
+        const int new_cols = (int)std::round(old_cols * factor);
+        const int new_rows = (int)std::round(old_rows * factor);
+        const std::string key = (image_folder / path(ToFormatIndex(ids[i]))).string() + "@" + std::to_string(new_cols) + "x" + std::to_string(new_rows);
+        const auto hit = level_cache.find(key);
+        if (hit != level_cache.end()) {
+            images[i] = hit->second.clone();
+        } else {
             Mat scaled;
-            auto hit = level_cache.find(key);
-            if (hit != level_cache.end()) {
-                scaled = hit->second.clone();
-            } else {
-                ResizeLinear(images[i], scaled, new_cols, new_rows);
-                if (getenv("APD_IMAGE_CACHE_MB") == nullptr || atoll(getenv("APD_IMAGE_CACHE_MB")) > 0) {
-                    level_cache.emplace(key, scaled.clone());
-                }
+            ResizeLinear(images[i], scaled, new_cols, new_rows);
+            if (cache_on) {
+                level_cache.emplace(key, scaled.clone());
             }
             images[i] = scaled;
-            width = scaled.cols;
-            height = scaled.rows;
-            cameras[i].K[0] *= scale_x;
-            cameras[i].K[2] *= scale_x;
-            cameras[i].K[4] *= scale_y;
-            cameras[i].K[5] *= scale_y;
-            cameras[i].width = width;
-            cameras[i].height = height;
         }
-        std::cout << "Scale images and cameras done\n";
+        const float scale_x = new_cols / static_cast<float>(old_cols);
+        const float scale_y = new_rows / static_cast<float>(old_rows);
+        Camera &cam = cameras[i];
+        cam.K[0] *= scale_x;
+        cam.K[2] *= scale_x;
+        cam.K[4] *= scale_y;
+        cam.K[5] *= scale_y;
+        cam.width = width = new_cols;
+        cam.height = height = new_rows;
     }
-    std::cout << "Image size: " << width << " * " << height << std::endl;
-    // The device path keeps every view as width x height floats (apd_upload_views copies exactly that much from every
-    // pointer): a source image of another size than the reference image is refused here, with the message the reference's
-    // CheckImages prints for mismatching reference images (main.cpp:51-70, :158).
-    for (int i = 0; i < num_images; ++i) {
-        if (images[i].cols != width || images[i].rows != height || images[i].type != MAT_32FC1) {
-            std::cerr << "Images may error, check it! (image " << ids[i] << " is " << images[i].cols << " * " << images[i].rows
-                      << ", expected " << width << " * " << height << ")\n";
-            exit(EXIT_FAILURE);
-        }
-    }
-    // depth maps of the previous pass for the geometric term (APD.cpp:492-510)
+    std::cout << "Scale images and cameras done\n";
+}
+
+// Depth maps of the previous pass for the geometric term (APD.cpp:492-510): the view's own, then one per source, resampled
+// to this level with the reference's nearest-neighbour rule.
+void APD::LoadGeometricDepths()
+{
     depths.clear();
-    if (params_host.geom_consistency) {
-        Mat ref_depth;
-        ReadBinMat(problem.result_folder / path("depths.dmb"), ref_depth);
-        depths.push_back(ref_depth);
-        for (int src_idx : problem.src_image_ids) {
-            Mat src_depth;
-            const path src_folder = problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx));
-            if (!std::filesystem::exists(src_folder)) {
-                // A source that is not reconstructed itself (no pair.txt entry, hence no result folder): the reference reads a
-                // file that is not there and goes on with an unspecified matrix (APD.cpp:497-506); here the view has no
-                // estimate anywhere (depth 0), which the geometric term prices like any pixel without a depth.
-                src_depth.create(height, width, MAT_32FC1);  // zero-filled
-            } else {
-                ReadBinMat(src_folder / path("depths.dmb"), src_depth);
-            }
-            depths.push_back(src_depth);
-        }
-        for (auto &depth : depths) {
-            if (depth.empty()) {
-                std::cerr << "Missing depth map of a previous pass\n";
-                exit(EXIT_FAILURE);
-            }
-            if (depth.type != MAT_32FC1) {
-                std::cerr << "depths.dmb of a previous pass is not a float map\n";
-                exit(EXIT_FAILURE);
-            }
-            if (depth.cols != width || depth.rows != height) {
-                RescaleMatToTargetSize<float>(depth, depth, width, height);
-            }
-        }
+    if (!params_host.geom_consistency) {
+        return;
     }
-    // weak map (APD.cpp:513-548)
-    if (params_host.use_APD) {
-        const path weak_info_path = problem.result_folder / path("weak.bin");
-        if (!std::filesystem::exists(weak_info_path)) {
-            std::cerr << "Can't find weak info file: " << weak_info_path.string() << std::endl;
+    auto load = [&](const path &folder, bool must_exist) {
+        Mat depth;
+        if (!must_exist && !std::filesystem::exists(folder)) {
+            // A source that is not reconstructed itself (no pair.txt entry, hence no result folder): the reference reads a
+            // file that is not there and goes on with an unspecified matrix (APD.cpp:497-506); here the view has no
+            // estimate anywhere (depth 0), which the geometric term prices like any pixel without a depth.
+            depth.create(height, width, MAT_32FC1);  // zero-filled
+            return depth;
+        }
+        ReadBinMat(folder / path("depths.dmb"), depth);
+        if (depth.empty()) {
+            std::cerr << "Missing depth map of a previous pass\n";
             exit(EXIT_FAILURE);
         }
-        ReadBinMat(weak_info_path, weak_info_host);
-        if (weak_info_host.empty() || weak_info_host.type != MAT_8UC1) {
-            std::cerr << "Unreadable or mistyped weak info file: " << weak_info_path.string() << std::endl;
+        if (depth.type != MAT_32FC1) {
+            std::cerr << "depths.dmb of a previous pass is not a float map\n";
             exit(EXIT_FAILURE);
         }
-        if (weak_info_host.cols != width || weak_info_host.rows != height) {
-            std::cerr << "Weak info doesn't match the images' size!\n";
-            RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
-            std::cout << "Scale done\n";
+        if (depth.cols != width || depth.rows != height) {
+            RescaleMatToTargetSize<float>(depth, depth, width, height);
         }
-        weak_count = 0;
-        for (int r = 0; r < height; ++r) {
-            for (int c = 0; c < width; ++c) {
-                if (weak_info_host.at<uint8_t>(r, c) == WEAK) {
-                    weak_count++;
-                }
-            }
-        }
-        std::cout << "Weak count: " << weak_count << " / " << width * height << " = "
-                  << (float)weak_count / (float)(width * height) * 100 << "%" << std::endl;
-    } else {
+        return depth;
+    };
+    depths.push_back(load(problem.result_folder, true));
+    for (int src_idx : problem.src_image_ids) {
+        depths.push_back(load(problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx)), false));
+    }
+}
+
+// weak.bin of the previous pass when the adaptive patches are on (APD.cpp:513-548); every pixel STRONG otherwise.
+void APD::LoadWeakMap()
+{
+    weak_count = 0;
+    if (!params_host.use_APD) {
         weak_info_host.create(height, width, MAT_8UC1);
         memset(weak_info_host.data(), STRONG, (size_t)width * height);
-        weak_count = 0;
+        return;
     }
+    const path weak_info_path = problem.result_folder / path("weak.bin");
+    if (!std::filesystem::exists(weak_info_path)) {
+        std::cerr << "Can't find weak info file: " << weak_info_path.string() << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    ReadBinMat(weak_info_path, weak_info_host);
+    if (weak_info_host.empty() || weak_info_host.type != MAT_8UC1) {
+        std::cerr << "Unreadable or mistyped weak info file: " << weak_info_path.string() << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    if (weak_info_host.cols != width || weak_info_host.rows != height) {
+        std::cerr << "Weak info doesn't match the images' size!\n";
+        RescaleMatToTargetSize<uint8_t>(weak_info_host, weak_info_host, width, height);
+        std::cout << "Scale done\n";
+    }
+    const uint8_t *w = weak_info_host.ptr<uint8_t>();
+    for (size_t k = 0, n = (size_t)width * height; k < n; ++k) {
+        weak_count += w[k] == WEAK;
+    }
+    std::cout << "Weak count: " << weak_count << " / " << width * height << " = " << (float)weak_count / (float)(width * height) * 100 << "%"
+              << std::endl;
+}
+
+// (world normal, depth) planes and selected views of the previous pass (APD.cpp:552-581), resampled to this level.
+void APD::LoadPriorState()
+{
     plane_hypotheses_host.assign((size_t)width * height, float4{0, 0, 0, 0});
     selected_views_host.create(height, width, MAT_32SC1);
-    has_prior = false;
-    if (params_host.state != FIRST_INIT) {  // APD.cpp:552-581
-        Mat depth, normal;
-        ReadBinMat(problem.result_folder / path("depths.dmb"), depth);
-        ReadBinMat(problem.result_folder / path("normals.dmb"), normal);
-        if (depth.empty() || normal.empty() || depth.type != MAT_32FC1 || normal.type != MAT_32FC3) {
-            std::cerr << "Missing or mistyped depths.dmb / normals.dmb of a previous pass\n";
-            exit(EXIT_FAILURE);
+    has_prior = params_host.state != FIRST_INIT;
+    if (!has_prior) {
+        return;
+    }
+    Mat depth, normal;
+    ReadBinMat(problem.result_folder / path("depths.dmb"), depth);
+    ReadBinMat(problem.result_folder / path("normals.dmb"), normal);
+    if (depth.empty() || normal.empty() || depth.type != MAT_32FC1 || normal.type != MAT_32FC3) {
+        std::cerr << "Missing or mistyped depths.dmb / normals.dmb of a previous pass\n";
+        exit(EXIT_FAILURE);
+    }
+    if (depth.cols != width || depth.rows != height || normal.cols != width || normal.rows != height) {
+        std::cerr << "Depth and Normal doesn't match the images' size!\n";
+        RescaleMatToTargetSize<float>(depth, depth, width, height);
+        RescaleMatToTargetSize<Vec3f>(normal, normal, width, height);
+    }
+    ParallelFor((size_t)height, [&](size_t r) {
+        const float *d = depth.ptr<float>((int)r);
+        const Vec3f *n = normal.ptr<Vec3f>((int)r);
+        float4 *p = &plane_hypotheses_host[r * (size_t)width];
+        for (int col = 0; col < width; ++col) {
+            p[col] = float4{n[col][0], n[col][1], n[col][2], d[col]};
         }
-        if (depth.cols != width || depth.rows != height || normal.cols != width || normal.rows != height) {
-            std::cerr << "Depth and Normal doesn't match the images' size!\n";
-            RescaleMatToTargetSize<float>(depth, depth, width, height);
-            RescaleMatToTargetSize<Vec3f>(normal, normal, width, height);
-        }
-        ParallelFor((size_t)height, [&](size_t r) {
-            const int row = (int)r;
-            for (int col = 0; col < width; ++col) {
-                float4 &p = plane_hypotheses_host[(size_t)row * width + col];
-                const Vec3f &n = normal.at<Vec3f>(row, col);
-                p.w = depth.at<float>(row, col);
-                p.x = n[0];
-                p.y = n[1];
-                p.z = n[2];
-            }
-        }, 0);
-        ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
-        if (selected_views_host.empty() || selected_views_host.type != MAT_32SC1) {
-            std::cerr << "Missing or mistyped selected_views.bin of a previous pass\n";
-            exit(EXIT_FAILURE);
-        }
-        if (selected_views_host.cols != width || selected_views_host.rows != height) {
-            std::cerr << "Select view doesn't match the images' size!\n";
-            RescaleMatToTargetSize<uint32_t>(selected_views_host, selected_views_host, width, height);
-        }
-        has_prior = true;
+    }, 0);
+    ReadBinMat(problem.result_folder / path("selected_views.bin"), selected_views_host);
+    if (selected_views_host.empty() || selected_views_host.type != MAT_32SC1) {
+        std::cerr << "Missing or mistyped selected_views.bin of a previous pass\n";
+        exit(EXIT_FAILURE);
+    }
+    if (selected_views_host.cols != width || selected_views_host.rows != height) {
+        std::cerr << "Select view doesn't match the images' size!\n";
+        RescaleMatToTargetSize<uint32_t>(selected_views_host, selected_views_host, width, height);
     }
 }
 

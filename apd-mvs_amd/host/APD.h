@@ -164,6 +164,13 @@ public:
     static void SetDevice(int device);
 
 private:
+    // the steps of InuputInitialization
+    std::vector<int> LoadViewSet();
+    void ApplyPyramidLevel(const std::vector<int> &ids);
+    void LoadGeometricDepths();
+    void LoadWeakMap();
+    void LoadPriorState();
+
     int num_images = 0;
     int width = 0;
     int height = 0;
