@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <cmath>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -131,6 +132,45 @@ static void relative_pose(const apd_camera &ref, const apd_camera &src, float Rr
     }
 }
 
+// K3 tests `dist / dd < thr` 1,600 times per WEAK pixel (APD.cu:1911), dist >= 0, dd = depth_max - depth_min.  For dd > 0 the
+// map x -> RN(x / dd) is monotone non-decreasing, so the non-negative floats that pass form an initial segment [0, cut): the
+// kernel compares with `cut` instead of dividing.  The end of the segment is found here with the same IEEE binary32
+// divisions (this translation unit is compiled without fast-math): start at RN(thr * dd) and walk single floats until
+// cut fails the test and its predecessor passes it.  Returns false when the parameters leave no such cut.
+static bool ransac_distance_cut(float dd, float thr, float *cut)
+{
+    if (!(dd > 0.0f) || !std::isfinite(dd) || !std::isfinite(thr)) {
+        return false;
+    }
+    if (!(thr > 0.0f)) {  // x / dd >= 0 is never below a threshold <= 0
+        *cut = 0.0f;
+        return true;
+    }
+    volatile float g = thr * dd;
+    int steps = 0;
+    while (std::isfinite(g) && (float)(g / dd) < thr) {
+        g = std::nextafterf(g, INFINITY);
+        if (++steps > 256) {
+            return false;
+        }
+    }
+    if (!std::isfinite(g)) {
+        return false;
+    }
+    while (g > 0.0f) {
+        const volatile float below = std::nextafterf(g, 0.0f);
+        if ((float)(below / dd) < thr) {
+            break;
+        }
+        g = below;
+        if (++steps > 512) {
+            return false;
+        }
+    }
+    *cut = g;
+    return true;
+}
+
 static void refresh_frame_args(apd_context *c)
 {
     FrameArgs &fa = c->fa;
@@ -162,6 +202,8 @@ static void refresh_frame_args(apd_context *c)
     fa.k3_cone = (float)cos((double)(angle / 2.0f) * M_PI / (double)180.0f);
     int shift = (int)(tan((double)(angle / 2.0f) * M_PI / (double)180.0f) * 20);
     fa.k3_shift_range = shift < 1 ? 1 : shift;
+    fa.k3_dist_cut = 0.0f;
+    fa.k3_cut_valid = ransac_distance_cut(p.depth_max - p.depth_min, p.ransac_threshold, &fa.k3_dist_cut) ? 1 : 0;
     fa.ref_img = c->images.empty() ? nullptr : c->images[0];
     fa.views = c->views_dev;
     fa.planes = c->planes;
@@ -210,6 +252,16 @@ void apd_default_params(apd_params *p)
 
 const char *apd_last_error(void) { return g_last_error.c_str(); }
 int apd_version(void) { return 100; }
+
+int apd_ransac_distance_cut(float depth_min, float depth_max, float ransac_threshold, float *cut)
+{
+    float c = 0.0f;
+    const bool ok = ransac_distance_cut(depth_max - depth_min, ransac_threshold, &c);
+    if (cut) {
+        *cut = c;
+    }
+    return ok ? 1 : 0;
+}
 
 int apd_device_count(void)
 {

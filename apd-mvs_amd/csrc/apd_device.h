@@ -98,6 +98,10 @@ struct FrameArgs {
     // K3 constants evaluated on the host in double (APD.cu:1791-1795)
     float k3_cos_angle, k3_sin_angle, k3_cone;
     int k3_shift_range;
+    // K3's inlier test `dist / (depth_max - depth_min) < ransac_threshold` as `dist < k3_dist_cut` (exact; ransac_distance_cut,
+    // apd_capi.hip); k3_cut_valid = 0: no such cut exists for these parameters, the kernel divides
+    float k3_dist_cut;
+    int k3_cut_valid;
     // reference camera
     float K[9], R[9], t[3], c[3];
     float ifx, ify;    // correctly rounded 1/K[0], 1/K[4]

@@ -131,6 +131,16 @@ __device__ __forceinline__ void sort_points_by_weight(short2 *pts, float *w, int
 // One lane per entry of a compacted WEAK list (build_weak_lists below; K3 visits both colours): a per-pixel launch fills
 // 18 % of its lanes on a typical frame and the ray search of those diverges against nothing.  In list order the lanes of a
 // wave are image neighbours, which walk their rays in step.
+//
+// kCut: `dist / depth_diff < ransac_threshold` (:1911, :1946) is evaluated as `dist < fa.k3_dist_cut`.  x -> RN(x / d) is
+// monotone for d > 0, so the set of non-negative floats that pass the test is an initial segment; the host finds its end
+// with IEEE divisions (ransac_distance_cut, apd_capi.hip) -- 1,600 divisions per WEAK pixel become comparisons, same bits.
+// kNoJitter: with the reference's rotate_time = 4 the jitter range (int)(tan(5.625 deg) * 20) is 1, every `% range` is 0 and
+// the four attempts of a (slot, radius) probe the same pixel: one probe, and the twelve draws of the three repeats are
+// skipped over when it fails.
+// The candidate points live twice: compacted in scratch memory for the three randomly indexed reads of a RANSAC draw, and
+// slot-indexed in registers for the inlier count, which visits all of them in a fixed order (an integer count has no order).
+template <bool kCut, bool kNoJitter>
 __global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa, const int *__restrict__ list, int count)
 {
     const int gid = blockIdx.x * 64 + threadIdx.x;
@@ -172,9 +182,17 @@ __global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa, const int 
                     if (tx < 0 || ty < 0 || tx >= (float)W || ty >= (float)H) {
                         break;
                     }
-                    for (int attempt = 0; attempt < 4; ++attempt) {
-                        const int sx = jitter_shift(rng, shift_range);
-                        const int sy = jitter_shift(rng, shift_range);
+                    for (int attempt = 0; attempt < (kNoJitter ? 1 : 4); ++attempt) {
+                        int sx = 0, sy = 0;
+                        if constexpr (kNoJitter) {
+                            rng_next(rng);
+                            rng_next(rng);
+                            rng_next(rng);
+                            rng_next(rng);
+                        } else {
+                            sx = jitter_shift(rng, shift_range);
+                            sy = jitter_shift(rng, shift_range);
+                        }
                         float dirx = odx * 20 + (float)sx, diry = ody * 20 + (float)sy;
                         normalize2(dirx, diry);
                         short2 q = make_short2((short)((float)px + dirx * (float)radius), (short)((float)py + diry * (float)radius));
@@ -202,6 +220,12 @@ __global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa, const int 
                     if (dir_valid & (1u << slot)) {
                         break;
                     }
+                    if constexpr (kNoJitter) {  // the three repeats of the failed probe: four draws each
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) {
+                            rng_next(rng);
+                        }
+                    }
                 }
                 {
                     float rdx = odx * fa.k3_cos_angle - ody * fa.k3_sin_angle;
@@ -223,17 +247,23 @@ __global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa, const int 
     bool has_plane = false;
     short2 pts[32];
     float3 pts3d[32];
+    float rx[32], ry[32], rz[32];  // slot-indexed copy, static indices only: registers
     int valid = 0;
     float Xc, Yc, Zc;
     point3d(fa, px, py, fa.planes[center].w, Xc, Yc, Zc);  // .w still holds the DEPTH before K5 (:1866)
+#pragma unroll
     for (int i = 0; i < 32; ++i) {
         pts[i] = make_short2(-1, -1);
+        rx[i] = ry[i] = rz[i] = 0.0f;
         if (dir_valid & (1u << i)) {
             const short2 sp = strong_pts[i];
             pts[valid] = sp;
             float X, Y, Z;
             point3d(fa, sp.x, sp.y, fa.planes[sp.x + sp.y * W].w, X, Y, Z);
             pts3d[valid] = make_float3(X, Y, Z);
+            rx[i] = X;
+            ry[i] = Y;
+            rz[i] = Z;
             valid++;
         }
     }
@@ -263,12 +293,11 @@ __global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa, const int 
             normalize3(nx, ny, nz);
             const float nw = -(nx * A.x + ny * A.y + nz * A.z);
             int count = 0;
-            for (int k = 0; k < valid; ++k) {
-                const float3 P = pts3d[k];
-                const float dist = fabsf(nx * P.x + ny * P.y + nz * P.z + nw);
-                if (dist / depth_diff < fa.ransac_threshold) {
-                    count++;
-                }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const float dist = fabsf(nx * rx[k] + ny * ry[k] + nz * rz[k] + nw);
+                const bool inlier = kCut ? dist < fa.k3_dist_cut : dist / depth_diff < fa.ransac_threshold;
+                count += (((dir_valid >> k) & 1u) != 0u && inlier) ? 1 : 0;
             }
             if (count < 6) {
                 continue;
@@ -302,7 +331,7 @@ __global__ __launch_bounds__(64) void k3_gen_neighbours(FrameArgs fa, const int 
     for (int i = 0; i < valid; ++i) {
         const float3 P = pts3d[i];
         float dist = fabsf(best_plane.x * P.x + best_plane.y * P.y + best_plane.z * P.z + best_plane.w);
-        if (dist / depth_diff >= fa.ransac_threshold) {
+        if (kCut ? dist >= fa.k3_dist_cut : dist / depth_diff >= fa.ransac_threshold) {
             pts[i] = make_short2(-1, -1);
             weight[i] = FLT_MAX;
             continue;
@@ -1131,8 +1160,17 @@ hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipS
     case APD_K3_GEN_NEIGHBOURS:
         for (int colour = 0; colour < 2 && weak_list; ++colour) {  // the lists only split the pixels by colour; K3 has no colour
             if (weak_list[colour] && weak_count[colour] > 0) {
-                hipLaunchKernelGGL(k3_gen_neighbours, dim3((weak_count[colour] + 63) / 64), dim3(64), 0, s, fa, weak_list[colour],
-                                   weak_count[colour]);
+                const dim3 grid((weak_count[colour] + 63) / 64);
+                const bool cut = fa.k3_cut_valid != 0, no_jitter = fa.k3_shift_range == 1;
+                if (cut && no_jitter) {
+                    hipLaunchKernelGGL((k3_gen_neighbours<true, true>), grid, dim3(64), 0, s, fa, weak_list[colour], weak_count[colour]);
+                } else if (cut) {
+                    hipLaunchKernelGGL((k3_gen_neighbours<true, false>), grid, dim3(64), 0, s, fa, weak_list[colour], weak_count[colour]);
+                } else if (no_jitter) {
+                    hipLaunchKernelGGL((k3_gen_neighbours<false, true>), grid, dim3(64), 0, s, fa, weak_list[colour], weak_count[colour]);
+                } else {
+                    hipLaunchKernelGGL((k3_gen_neighbours<false, false>), grid, dim3(64), 0, s, fa, weak_list[colour], weak_count[colour]);
+                }
             }
         }
         break;

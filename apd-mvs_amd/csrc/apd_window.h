@@ -222,40 +222,50 @@ __device__ __forceinline__ int win_byte_address(int qx, int qy, int addr0)
 }
 
 // quad_row_issue / fquad_row_issue for samples known to lie inside the window: no clamps, LDS addresses.
-template <bool kQuad, int kPitch, bool kApprox = false>
+// kEnds: the positions of samples 0 and kPatchN - 1 of this row are patch corners the caller has already computed with
+// corner_position (the same instructions on the same operands, hence the same bits): (Xa, Ya) and (Xb, Yb).
+template <bool kQuad, int kPitch, bool kApprox = false, bool kEnds = false>
 __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, float by, float bz, const float (&yf)[kPatchN], int addr0,
                                               float (&a)[kPatchN], float (&b)[kPatchN],
-                                              WinTaps<typename WinEntry<kQuad>::type> (&t)[kPatchN])
+                                              WinTaps<typename WinEntry<kQuad>::type> (&t)[kPatchN], float Xa = 0.0f, float Ya = 0.0f,
+                                              float Xb = 0.0f, float Yb = 0.0f)
 {
+    constexpr int j0 = kEnds ? 1 : 0, j1 = kEnds ? kPatchN - 1 : kPatchN;
     float z[kPatchN], X[kPatchN], Y[kPatchN], r[kPatchN];
 #pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
+    for (int j = j0; j < j1; ++j) {
         z[j] = fmaf(H.h[7], yf[j], bz);
         X[j] = fmaf(H.h[1], yf[j], bx);
         Y[j] = fmaf(H.h[4], yf[j], by);
     }
     APD_STAGE();
 #pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
+    for (int j = j0; j < j1; ++j) {
         r[j] = __builtin_amdgcn_rcpf(z[j]);
     }
     APD_STAGE();
     if constexpr (!kApprox) {  // Newton step: the correctly rounded reciprocal (tolerance mode APD_OPT_FAST_RCP stops at v_rcp_f32)
 #pragma unroll
-        for (int j = 0; j < kPatchN; ++j) {
+        for (int j = j0; j < j1; ++j) {
             z[j] = fmaf(-z[j], r[j], 1.0f);
         }
         APD_STAGE();
 #pragma unroll
-        for (int j = 0; j < kPatchN; ++j) {
+        for (int j = j0; j < j1; ++j) {
             r[j] = fmaf(z[j], r[j], r[j]);
         }
         APD_STAGE();
     }
 #pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
+    for (int j = j0; j < j1; ++j) {
         X[j] *= r[j];
         Y[j] *= r[j];
+    }
+    if constexpr (kEnds) {
+        X[0] = Xa;
+        Y[0] = Ya;
+        X[kPatchN - 1] = Xb;
+        Y[kPatchN - 1] = Yb;
     }
     APD_STAGE();
     // LDS address of entry (floor X, floor Y) in binary32.  On gfx950 the plain binary32 multiply / add / FMA issue in 2
@@ -336,10 +346,16 @@ __device__ __forceinline__ void win_row_lerp(const WinTaps<typename WinEntry<kQu
 }
 
 // ncc_fixed_moments (fast reciprocal) reading the window.
+// cX / cY: positions of the four corner samples {(x0,y0), (x0,y1), (x1,y0), (x1,y1)} from the caller's window test; rows 0 and
+// kPatchN - 1 take their end samples from there instead of computing them a second time (APD_WIN_CORNER_REUSE=0: recompute).
+#ifndef APD_WIN_CORNER_REUSE
+#define APD_WIN_CORNER_REUSE 1
+#endif
 template <bool kQuad, int kPitch, bool kApprox, typename Ref>
 __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homography &H, int px, int py, int addr0, float &sum_s,
-                                                   float &sum_ss, float &sum_rs)
+                                                   float &sum_ss, float &sum_rs, const float (&cX)[4], const float (&cY)[4])
 {
+    constexpr bool kReuse = APD_WIN_CORNER_REUSE != 0;
     float yf[kPatchN];
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
@@ -358,8 +374,8 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
     WinTaps<typename WinEntry<kQuad>::type> t[2][kPatchN];
     {
         const float xf = (float)(px - kPatchRadius);
-        win_row_issue<kQuad, kPitch, kApprox>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf, addr0,
-                                              a[0], b[0], t[0]);
+        win_row_issue<kQuad, kPitch, kApprox, kReuse>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf,
+                                                      addr0, a[0], b[0], t[0], cX[0], cY[0], cX[1], cY[1]);
     }
 #pragma unroll
     for (int i = 0; i < kPatchN; ++i) {
@@ -372,10 +388,14 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
             ref[j] = rp.at(i, j);
         }
         APD_STAGE();
-        if (i + 1 < kPatchN) {
+        if (i + 2 < kPatchN) {
             const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
             win_row_issue<kQuad, kPitch, kApprox>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf,
                                                   addr0, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
+        } else if (i + 1 < kPatchN) {
+            const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
+            win_row_issue<kQuad, kPitch, kApprox, kReuse>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf,
+                                                          addr0, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1], cX[2], cY[2], cX[3], cY[3]);
         }
         APD_STAGE();
         win_row_lerp<kQuad>(t[i & 1], a[i & 1], b[i & 1], v);
@@ -426,16 +446,16 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
     // tolerance mode: every denominator goes through v_rcp_f32; the corner test below still needs one sign
     const bool fast_recip = denominators_fast(H, x0, x1, y0, y1);
     bool in_window = false;
+    float cX[4], cY[4];  // only read when in_window, i.e. after the block below has written them
     if (fast_recip && w.valid) {
         // x/z and y/z are monotone along every row and every column of the sample grid while z keeps its sign, so the
         // four corner samples bound all 36
-        float X00, Y00, X01, Y01, X10, Y10, X11, Y11;
-        corner_position<kApprox>(H, x0, y0, X00, Y00);
-        corner_position<kApprox>(H, x0, y1, X01, Y01);
-        corner_position<kApprox>(H, x1, y0, X10, Y10);
-        corner_position<kApprox>(H, x1, y1, X11, Y11);
-        const float xl = fminf(fminf(X00, X01), fminf(X10, X11)), xh = fmaxf(fmaxf(X00, X01), fmaxf(X10, X11));
-        const float yl = fminf(fminf(Y00, Y01), fminf(Y10, Y11)), yh = fmaxf(fmaxf(Y00, Y01), fmaxf(Y10, Y11));
+        corner_position<kApprox>(H, x0, y0, cX[0], cY[0]);
+        corner_position<kApprox>(H, x0, y1, cX[1], cY[1]);
+        corner_position<kApprox>(H, x1, y0, cX[2], cY[2]);
+        corner_position<kApprox>(H, x1, y1, cX[3], cY[3]);
+        const float xl = fminf(fminf(cX[0], cX[1]), fminf(cX[2], cX[3])), xh = fmaxf(fmaxf(cX[0], cX[1]), fmaxf(cX[2], cX[3]));
+        const float yl = fminf(fminf(cY[0], cY[1]), fminf(cY[2], cY[3])), yh = fmaxf(fmaxf(cY[0], cY[1]), fmaxf(cY[2], cY[3]));
         in_window = xl >= w.lo_x && xh < w.hi_x && yl >= w.lo_y && yh < w.hi_y;
     }
 #ifdef APD_LAB_WIN_STATS
@@ -460,7 +480,7 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
 #endif
     float sum_s, sum_ss, sum_rs;
     if (in_window) {
-        ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs);
+        ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs, cX, cY);
     } else if constexpr (kApprox) {
         ncc_fixed_moments<kQuad, kRecipApprox, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else if (__builtin_expect(fast_body, 1)) {

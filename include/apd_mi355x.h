@@ -251,6 +251,12 @@ int apd_fuse_views(int device, int num_views, const apd_camera *cameras, const f
                    long long *num_points);
 const char *apd_fusion_last_error(void);
 
+/* Host-side constant of K3 (GenNeighbours, APD.cu:1911 / :1946): its inlier test `dist / (depth_max - depth_min) <
+ * ransac_threshold` (dist >= 0) is evaluated on the device as `dist < cut`, the same predicate for every binary32 dist because
+ * x -> RN(x / d) is monotone.  Returns 1 and the cut, or 0 when the parameters admit none (the kernel then divides).  Needs
+ * no device; exported so that the equivalence can be tested on any machine (tests/test_host_constants.py). */
+int apd_ransac_distance_cut(float depth_min, float depth_max, float ransac_threshold, float *cut);
+
 const char *apd_last_error(void);
 int apd_version(void);
 int apd_device_count(void);
