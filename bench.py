@@ -290,7 +290,7 @@ def main():
     # K6/K7 skip WEAK pixels; the weak fraction is the one at upload time (K4 only ever lowers it)
     bytes_per_launch = (W * H / 2.0) * (1.0 - weak_fraction) * algorithmic_bytes_per_strong_pixel(N)
     alg_gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    pmc = load_pmc_profile(args.workload, args.steps, args.warmup, "k67")
+    pmc = load_pmc_profile(args.workload, args.steps, args.warmup, "k67", args.opt, args.seed)
     roofline = {
         "bound": "valu-issue", "kernel": "k67w_update_strong (Black/RedPixelUpdateStrong, LDS source windows)",
         "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwave-inst/s", "frac": None, "traffic": None,
@@ -314,7 +314,8 @@ def main():
             "valu_insts_per_launch": insts,
             "hbm": {"achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4),
                     "bytes_per_launch": traffic, "note": "2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction of the guide)"},
-            "pmc_source": pmc["source"], "pmc_launch_ms": pmc.get("launch_ms"),
+            "pmc_source": pmc["source"], "pmc_launch_ms": pmc.get("launch_ms"), "pmc_profile_steps": pmc["profile_steps"],
+            "pmc_extrapolated_launches": pmc["extrapolated_launches"],
         })
         mix = load_valu_mix()
         if mix is not None:
@@ -324,9 +325,9 @@ def main():
                 "note": "VALU instructions per launch x mean issue cycles of the kernel's LDS-window body (static mix, measured "
                         "per-class costs) / (1024 SIMDs x 2.4 GHz x launch time); an estimate, the counters do not split by class"}
     else:
-        roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s steps=%d warmup=%d under profiles/: "
+        roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s options=%s seed=%d under profiles/: "
                                 "achieved / frac / traffic are null rather than borrowed from another configuration"
-                                % (args.workload, args.steps, args.warmup))
+                                % (args.workload, args.opt, args.seed))
     kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0], 3) for k, v in sorted(prof.items())}
     weak_path = None
     weak_roofline = None
@@ -340,7 +341,7 @@ def main():
                      "achieved_GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0}
         # what bounds K9/K10: its scattered sub-patch gathers -- L1 tag look-ups per gather and the bytes the
         # misses pull through the fabric; counters from the profile of this same command line, time measured live
-        wp = load_pmc_profile(args.workload, args.steps, args.warmup, "k910")
+        wp = load_pmc_profile(args.workload, args.steps, args.warmup, "k910", args.opt, args.seed)
         # K9/K10 owns most of an APD iteration: it is the dominant kernel of this workload and the line's `roofline`; the
         # strong sweep's block moves to `strong_path`.  Bound: the L1 (TCP) tag pipeline -- a scattered dword gather costs one
         # tag access per lane whatever the lines (tools/tcp_patterns.hip, profiles/r03/tcp_patterns.txt), and the pipeline
@@ -366,10 +367,11 @@ def main():
                                           "note": "2 x FETCH_SIZE + WRITE_SIZE per launch"},
                                   "valu": {"achieved": round(wp["valu_insts_per_launch"] / (wms * 1e-3) / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1),
                                            "unit": "Gwave-inst/s", "frac": round(wp["valu_insts_per_launch"] / (wms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)},
-                                  "pmc_source": wp["source"], "pmc_launch_ms": wp.get("launch_ms")})
+                                  "pmc_source": wp["source"], "pmc_launch_ms": wp.get("launch_ms"), "pmc_profile_steps": wp["profile_steps"],
+                                  "pmc_extrapolated_launches": wp["extrapolated_launches"]})
         else:
-            weak_roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s steps=%d warmup=%d under profiles/"
-                                         % (args.workload, args.steps, args.warmup))
+            weak_roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s options=%s seed=%d under profiles/"
+                                         % (args.workload, args.opt, args.seed))
         if wp and wms > 0 and wp.get("fetch_bytes_per_launch") and wp.get("vmem_rd_insts_per_launch"):
             fabric = wp["fetch_bytes_per_launch"] / (wms * 1e-3) / 1e9
             gathers = wp["vmem_rd_insts_per_launch"]
@@ -471,13 +473,41 @@ def selftest_cpu(args, world, rank):
     return 0
 
 
-def load_pmc_profile(workload, steps, warmup, kernel):
-    """Counter profile of THIS command line (workload, steps, warm-up) from the newest profiles/rNN/pmc_bench_*.json written by
-    tools/profile_bench.py: separate rocprofv3 --pmc passes (SQ_INSTS_VALU; FETCH_SIZE; WRITE_SIZE), reduced over the timed
-    launches of `kernel` only.  PMC counters cannot be read inside this process; a profile of another configuration is never
-    substituted (returns None)."""
+PMC_COUNTERS = {  # field of the returned record -> counter of tools/profile_bench.py
+    "valu_insts_per_launch": "SQ_INSTS_VALU", "vmem_rd_insts_per_launch": "SQ_INSTS_VMEM_RD",
+    "tcp_tag_accesses_per_launch": "TCP_TOTAL_CACHE_ACCESSES_sum", "launch_ns": "duration_ns@trace",
+    "fetch_kib": "FETCH_SIZE", "write_kib": "WRITE_SIZE"}
+
+
+def pmc_timed_series(kernel_rec, profiled_steps, launches):
+    """Per-dispatch counter values of the first `launches` timed launches, from a profile that timed 2 * profiled_steps of
+    them.  Timed launch j of any command line of a workload is launch j of the profiled one (the pass is re-initialised
+    after the warm-up, no kernel reads max_iterations), so a shorter run reads a prefix.  A longer run repeats the last
+    profiled iteration (black, red) for the launches beyond the profile -- converged launches, whose counters are flat -- and
+    the number of such launches is returned so that the line can say so."""
+    pd = kernel_rec.get("per_dispatch_timed") or {}
+    have = 2 * profiled_steps
+    out, extrapolated = {}, max(0, launches - have)
+    for field, cname in PMC_COUNTERS.items():
+        v = pd.get(cname)
+        if not v or len(v) < have:
+            out[field] = None
+            continue
+        t = list(v[-have:])
+        while len(t) < launches:
+            t += t[have - 2:have]
+        out[field] = t[:launches]
+    return out, extrapolated
+
+
+def load_pmc_profile(workload, steps, warmup, kernel, options=(), seed=12345):
+    """Counter profile of THIS workload from the newest profiles/rNN/pmc_bench_*.json written by tools/profile_bench.py:
+    separate rocprofv3 --pmc passes (SQ_*; TCP_* / TCC_*; FETCH_SIZE; WRITE_SIZE) with per-dispatch values, reduced here over
+    the launches this command line times (pmc_timed_series).  PMC counters cannot be read inside this process.  Never
+    substituted: a profile of another workload, of other --opt options or of another seed (returns None)."""
     import glob
-    best = None
+    best, best_rank = None, None
+    launches = 2 * steps
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_bench_*.json"))):
         try:
             with open(path) as f:
@@ -485,15 +515,25 @@ def load_pmc_profile(workload, steps, warmup, kernel):
         except (OSError, ValueError):
             continue
         cfg = rec.get("config", {})
-        if cfg.get("workload") != workload or cfg.get("steps") != steps or cfg.get("warmup") != warmup:
+        if cfg.get("workload") != workload or list(cfg.get("options", [])) != list(options) or cfg.get("seed", 12345) != seed:
             continue
         k = rec.get("kernels", {}).get(kernel)
-        if not k or not k.get("valu_insts_per_launch") or k.get("hbm_bytes_per_launch") is None:
+        if not k or not cfg.get("steps"):
             continue
-        best = {"valu_insts_per_launch": k["valu_insts_per_launch"], "hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
-                "launch_ms": k.get("launch_ms"), "source": os.path.relpath(path, ROOT),
-                "fetch_bytes_per_launch": k.get("fetch_bytes_per_launch"), "vmem_rd_insts_per_launch": k.get("vmem_rd_insts_per_launch"),
-                "tcp_tag_accesses_per_launch": k.get("tcp_tag_accesses_per_launch")}
+        series, extrapolated = pmc_timed_series(k, cfg["steps"], launches)
+        if series["valu_insts_per_launch"] is None or series["fetch_kib"] is None or series["write_kib"] is None:
+            continue
+        mean = lambda f_: None if series[f_] is None else sum(series[f_]) / len(series[f_])
+        fe, wr = mean("fetch_kib"), mean("write_kib")
+        cand = {"valu_insts_per_launch": mean("valu_insts_per_launch"), "hbm_bytes_per_launch": fe * 1024 * 2 + wr * 1024,
+                "launch_ms": None if mean("launch_ns") is None else mean("launch_ns") / 1e6, "source": os.path.relpath(path, ROOT),
+                "fetch_bytes_per_launch": fe * 1024 * 2, "vmem_rd_insts_per_launch": mean("vmem_rd_insts_per_launch"),
+                "tcp_tag_accesses_per_launch": mean("tcp_tag_accesses_per_launch"),
+                "profile_steps": cfg["steps"], "profile_warmup": cfg.get("warmup"), "extrapolated_launches": extrapolated}
+        # the newest round's profiles describe today's kernels; within a round: covered without extrapolation, then the exact command line
+        rank = (os.path.basename(os.path.dirname(path)), extrapolated == 0, cfg["steps"] == steps and cfg.get("warmup") == warmup)
+        if best is None or rank >= best_rank:
+            best, best_rank = cand, rank
     return best
 
 

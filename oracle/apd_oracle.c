@@ -567,10 +567,23 @@ static inline float fetch_texel(const float *img, int W, int H, int x, int y)
     return img[(size_t)clampi(y, 0, H - 1) * W + clampi(x, 0, W - 1)];
 }
 
+/* Study knob, NOT part of the contract and off by default (tools/sampler_sensitivity.py): the CUDA texture unit the
+ * reference samples with (APD.cpp:598-602, cudaFilterModeLinear) keeps the two interpolation weights in 9-bit fixed point
+ * with 8 fractional bits (CUDA C Programming Guide, "Linear Filtering").  Contract C7 uses the float weights frac(x),
+ * frac(y); with the knob on they are rounded to the nearest 1/256 first, which is the closest a CPU can get to what a
+ * physical run of the reference computes.  Used to measure how far such a run may end from the contract's bits. */
+static int g_study_weights_q8 = 0;
+void orc_set_study_weights_q8(int on) { g_study_weights_q8 = on; }
+int orc_get_study_weights_q8(void) { return g_study_weights_q8; }
+
 float orc_sample_bilinear(const float *img, int W, int H, float sx, float sy)
 {
     const float fx = floorf(sx), fy = floorf(sy);
-    const float a = sx - fx, b = sy - fy;
+    float a = sx - fx, b = sy - fy;
+    if (g_study_weights_q8) {
+        a = rintf(a * 256.0f) * (1.0f / 256.0f);
+        b = rintf(b * 256.0f) * (1.0f / 256.0f);
+    }
     /* clamp in float first so the int conversion is defined for NaN/huge inputs (NaN -> -1) */
     const int x0 = (int)fminf(fmaxf(fx, -1.0f), (float)W);
     const int y0 = (int)fminf(fmaxf(fy, -1.0f), (float)H);

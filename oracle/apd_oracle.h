@@ -108,6 +108,9 @@ orc_state *orc_create(int width, int height, const orc_params *params, const orc
 void orc_destroy(orc_state *s);
 
 void orc_set_threads(int n);
+/* study knob, off by default and not part of the contract: bilinear weights rounded to 8 fractional bits (the CUDA texture unit) */
+void orc_set_study_weights_q8(int on);
+int orc_get_study_weights_q8(void);
 int orc_get_threads(void);
 
 /* Region of interest: the kernels only visit (and write) pixels of [x0, x1) x [y0, y1); arrays keep their full size.

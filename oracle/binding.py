@@ -95,6 +95,8 @@ def lib():
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_get_threads.restype = C.c_int
     L.orc_set_roi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_set_study_weights_q8.argtypes = [C.c_int]
+    L.orc_get_study_weights_q8.restype = C.c_int
     L.orc_run_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_run.argtypes = [C.c_void_p]
     L.orc_run_sweeps.argtypes = [C.c_void_p, C.c_int, C.c_int]

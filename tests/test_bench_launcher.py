@@ -77,4 +77,7 @@ def test_committed_counter_profiles_give_roofline_fractions_below_one():
             got = bench.load_pmc_profile(cfg["workload"], 6, 1, "k67")
             assert got is not None and got["source"].startswith("profiles/")
     assert seen_default, "the default bench command line needs a committed profile"
-    assert bench.load_pmc_profile("eth3d_office_fullres_8src", 7, 1, "k67") is None  # never borrowed from another configuration
+    # another --steps of the same workload is the same launches, one by one (tests/test_profiles_consistent.py); what is
+    # never borrowed is a profile of another workload, of other options or of another seed
+    assert bench.load_pmc_profile("eth3d_pipes_fullres_10src", 6, 1, "k67") is None
+    assert bench.load_pmc_profile("eth3d_office_fullres_8src", 6, 1, "k67", options=["early_out=0"]) is None

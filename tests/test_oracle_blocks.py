@@ -57,6 +57,25 @@ def test_sampler_texel_centres_half_texels_and_clamp(ob):
     assert np.isnan(L.orc_sample_bilinear(p, W, H, float("nan"), 1.0))
 
 
+def test_study_knob_for_fixed_point_weights_is_off_by_default_and_quantises_to_1_256(ob):
+    """orc_set_study_weights_q8 (tools/sampler_sensitivity.py): the CUDA texture unit's 8 fractional weight bits.  Not part of
+    the contract: off unless a study switches it on, and it must be switched off again."""
+    L = ob.lib()
+    assert L.orc_get_study_weights_q8() == 0
+    W, H = 4, 3
+    img = np.array([[0, 256, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]], np.float32)
+    p = img.ctypes.data_as(C.POINTER(C.c_float))
+    x = 0.3  # weight 0.3 -> contract: 0.3 * 256; 8-bit weight: round(76.8) / 256 * 256 = 77
+    assert abs(L.orc_sample_bilinear(p, W, H, x, 0.0) - np.float32(x) * 256) < 1e-4
+    L.orc_set_study_weights_q8(1)
+    try:
+        assert L.orc_sample_bilinear(p, W, H, x, 0.0) == 77.0
+        assert L.orc_sample_bilinear(p, W, H, 0.5, 0.0) == 128.0 and L.orc_sample_bilinear(p, W, H, 1.0, 0.0) == 256.0
+    finally:
+        L.orc_set_study_weights_q8(0)
+    assert L.orc_get_study_weights_q8() == 0
+
+
 def _cam(ob, f, cx, cy, R, t, W, H):
     return ob.make_camera([f, 0, cx, 0, f, cy, 0, 0, 1], R, t, W, H, 1.0, 4.0)
 

@@ -21,3 +21,35 @@ def test_roofline_fields_follow_from_the_committed_counters(round_dir):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     assert r.stdout.count("frac") >= 3, r.stdout  # default line, driver line, APD line
+
+
+def test_one_profile_serves_every_steps_and_warmup_of_its_workload():
+    """bench.py's timed launch j is the same work whatever --steps / --warmup say (the pass is re-initialised after the warm-up):
+    a shorter run reads a prefix of the profiled launches, a longer one repeats the last profiled iteration and reports how
+    many launches it extrapolated."""
+    sys.path.insert(0, ROOT)
+    import bench
+    steps = 4
+    rec = {"per_dispatch_timed": {c: [100.0 * (j + 1) for j in range(2 * steps)] for c in bench.PMC_COUNTERS.values()}}
+    series, extra = bench.pmc_timed_series(rec, steps, 2 * steps)
+    assert extra == 0 and series["valu_insts_per_launch"] == [100.0 * (j + 1) for j in range(8)]
+    series, extra = bench.pmc_timed_series(rec, steps, 4)       # --steps 2: the first two iterations
+    assert extra == 0 and series["fetch_kib"] == [100.0, 200.0, 300.0, 400.0]
+    series, extra = bench.pmc_timed_series(rec, steps, 12)      # --steps 6: two iterations beyond the profile
+    assert extra == 4 and series["write_kib"][8:] == [700.0, 800.0, 700.0, 800.0]
+    # warm-up launches recorded before the timed ones are ignored (the timed launches are the last 2 * steps)
+    rec2 = {"per_dispatch_timed": {c: [-1.0, -1.0] + v for c, v in rec["per_dispatch_timed"].items()}}
+    assert bench.pmc_timed_series(rec2, steps, 8)[0] == bench.pmc_timed_series(rec, steps, 8)[0]
+    # a counter the profile lacks is reported as missing, not as zero
+    del rec["per_dispatch_timed"]["FETCH_SIZE"]
+    assert bench.pmc_timed_series(rec, steps, 8)[0]["fetch_kib"] is None
+
+
+def test_profiles_of_other_options_or_seeds_are_never_borrowed():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.load_pmc_profile("eth3d_office_fullres_8src", 6, 1, "k67", options=["fast_rcp=1"]) is None
+    assert bench.load_pmc_profile("eth3d_office_fullres_8src", 6, 1, "k67", seed=99) is None
+    assert bench.load_pmc_profile("no_such_workload", 6, 1, "k67") is None
+    got = bench.load_pmc_profile("eth3d_office_fullres_8src", 6, 1, "k67")
+    assert got is not None and got["extrapolated_launches"] == 0 and got["valu_insts_per_launch"] > 1e9

@@ -14,8 +14,15 @@ run_case() {  # name width height views src
   local t1=$(date +%s%N)
   apd-mvs_amd/_build/APD ${d}_b 0 --seed 12345 > /tmp/e2e_bin.log 2>&1 || tail -5 /tmp/e2e_bin.log
   local t2=$(date +%s%N)
-  echo "== $1: $4 views of $2x$3, $5 sources: in-memory pipeline $(( (t1 - t0) / 1000000 )) ms (python start-up included), drop-in binary $(( (t2 - t1) / 1000000 )) ms"
+  # the C++ multi-device scheduler with one rank (host/multi_device.cpp: state resident, depth maps exchanged in memory;
+  # Jacobi over views, so its cloud differs slightly from the two Gauss-Seidel runs above by construction)
+  rm -rf ${d}_c; cp -r ${d}_b ${d}_c; rm -rf ${d}_c/APD
+  local t3=$(date +%s%N)
+  apd-mvs_amd/_build/APD ${d}_c 0 --jacobi --seed 12345 > /tmp/e2e_mem.log 2>&1 || tail -5 /tmp/e2e_mem.log
+  local t4=$(date +%s%N)
+  echo "== $1: $4 views of $2x$3, $5 sources: in-memory pipeline $(( (t1 - t0) / 1000000 )) ms (python start-up included), drop-in binary $(( (t2 - t1) / 1000000 )) ms, drop-in binary with the in-memory scheduler (APD folder 0 --jacobi) $(( (t4 - t3) / 1000000 )) ms"
   grep -iE "fusion|points|total|pass" /tmp/e2e_pipe.log | tail -4
+  grep -iE "fus|points|total|exchange|gather" /tmp/e2e_mem.log | tail -6
   md5sum $d/APD/APD.ply ${d}_b/APD/APD.ply
 }
 if [ "$WHAT" != big ]; then run_case small 1920 1080 12 8; fi

@@ -1,5 +1,6 @@
 """Per-kernel timing of a three-pass pipeline (FIRST_INIT -> REFINE_INIT+APD -> REFINE_ITER+APD+geom) at a given size.
-Usage: python tools/pass_timing.py [W H N textureless]"""
+Usage: python tools/pass_timing.py [W H N textureless [float]]      float: non-integer grey values, i.e. the float-image path that
+every pyramid level but the finest takes (APD.cpp:474)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +13,8 @@ import common
 W, H, N = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (4096, 3072, 8)))
 tl = float(sys.argv[4]) if len(sys.argv) > 4 else 0.2
 sc = synth.make_scene(W, H, N, seed=3, textureless=tl, device="cuda")
+if len(sys.argv) > 5 and sys.argv[5] == "float":
+    sc.images = [im * 0.97 + 0.3 for im in sc.images]
 cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
 dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
 passes = [dict(state=0, use_APD=0, weak_peak_radius=6),

@@ -102,7 +102,8 @@ def main():
                     g.write(f.read())
         subprocess.call(["rm", "-rf", raw])
 
-    out = {"config": {"workload": workload, "steps": steps, "warmup": warmup, "flags": flags},
+    out = {"config": {"workload": workload, "steps": steps, "warmup": warmup, "flags": flags, "seed": flag(flags, "--seed", 12345),
+                      "options": [flags[i + 1] for i, f_ in enumerate(flags) if f_ == "--opt"]},
            "method": "rocprofv3 --kernel-trace + one --pmc pass per counter group; timed launches = last 2*steps dispatches of the kernel; "
                      "FETCH_SIZE in KiB doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE in KiB as reported",
            "kernels": {}}
@@ -116,6 +117,10 @@ def main():
             k["per_dispatch_timed"][cname] = timed
             for i, v in enumerate(timed):
                 rows_csv.append([key, cname, i, v])
+        # Timed launch j of ANY command line of this workload (same seed, same options) is launch j of this one: bench.py
+        # re-initialises the pass after the warm-up, so its timed region is always iterations 0..steps-1, black then red,
+        # and no kernel reads max_iterations.  bench.py therefore serves shorter runs from a prefix of these values
+        # (and says so: roofline.pmc_profile_steps).
 
         def mean(cname):
             v = k["per_dispatch_timed"].get(cname)

@@ -44,16 +44,31 @@ def load_mix(directory):
     raise SystemExit("no valu_mix_k67w.json under profiles/")
 
 
-def check_k67(tag, roof, k, mix, problems):
-    pd = k["per_dispatch_timed"]
-    n = k["launches_timed"]
-    mean = lambda c: sum(pd[c][-n:]) / n
+def timed_mean(k, profiled_steps, launches):
+    """Mean of a counter over the first `launches` timed launches.  Timed launch j of any command line of a workload is launch j
+    of the profiled one (bench.py re-initialises the pass after the warm-up); launches beyond the profile repeat its last
+    iteration (black, red).  The same rule as bench.py's pmc_timed_series, written a second time."""
+    pd, have = k["per_dispatch_timed"], 2 * profiled_steps
+
+    def mean(c):
+        v = pd[c][-have:]
+        assert len(v) == have, (c, len(v), have)
+        vals = [v[j] if j < have else v[have - 2 + (j - have) % 2] for j in range(launches)]
+        return sum(vals) / launches
+    return mean
+
+
+def check_k67(tag, roof, k, mix, problems, profiled_steps):
+    n = roof["launches"]
+    mean = timed_mean(k, profiled_steps, n)
+    if roof.get("pmc_extrapolated_launches", 0) != max(0, n - 2 * profiled_steps):
+        problems.append("%s: pmc_extrapolated_launches is %r, the profile covers %d of %d launches" % (
+            tag, roof.get("pmc_extrapolated_launches"), 2 * profiled_steps, n))
     insts = mean("SQ_INSTS_VALU")
     traffic = mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024
     t = roof["avg_launch_ms"] * 1e-3
     achieved = insts / t / 1e9
     for what, got, want, rel in (
-            ("launches", roof["launches"], n, 0),
             ("valu_insts_per_launch", roof["valu_insts_per_launch"], insts, 1e-9),
             ("achieved", roof["achieved"], achieved, 1e-3),
             ("frac", roof["frac"], achieved / PEAK, 1e-3),
@@ -71,18 +86,16 @@ def check_k67(tag, roof, k, mix, problems):
         achieved / PEAK, traffic / t / 1e9 / HBM, insts * mix / (1024 * 2.4e9 * t), n, t * 1e3, mean("duration_ns@trace") * 1e-6)
 
 
-def check_k910(tag, roof, k, problems):
+def check_k910(tag, roof, k, problems, profiled_steps):
     """APD workloads: the line's roofline is the weak sweep's, against the L1 tag pipeline."""
-    pd = k["per_dispatch_timed"]
-    n = k["launches_timed"]
-    mean = lambda c: sum(pd[c][-n:]) / n
+    n = roof["launches"]
+    mean = timed_mean(k, profiled_steps, n)
     acc = mean("TCP_TOTAL_CACHE_ACCESSES_sum")
     insts = mean("SQ_INSTS_VALU")
     traffic = mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024
     t = roof["avg_launch_ms"] * 1e-3
     achieved = acc / t / 1e9
     for what, got, want, rel in (
-            ("launches", roof["launches"], n, 0),
             ("tag_accesses_per_launch", roof["tag_accesses_per_launch"], acc, 1e-9),
             ("achieved", roof["achieved"], achieved, 1e-3),
             ("frac", roof["frac"], achieved / TAG_PEAK, 1e-3),
@@ -114,21 +127,27 @@ def check(directory):
         if not roof or roof.get("achieved") is None:
             continue
         cfg = line["config"]
-        name = "pmc_bench_%s_s%d_w%d.json" % (cfg["workload"], line["steps"], line["warmup"])
-        prof_path = os.path.join(directory, name)
-        if not os.path.exists(prof_path):
-            problems.append("%s: cites counters but %s is not committed" % (os.path.basename(path), name))
+        # the profile the line names (any --steps / --warmup of a workload is served by one profile of that workload, see timed_mean)
+        prof_path = os.path.join(ROOT, roof.get("pmc_source") or "")
+        if not roof.get("pmc_source") or not os.path.exists(prof_path):
+            problems.append("%s: cites counters but %r is not committed" % (os.path.basename(path), roof.get("pmc_source")))
             continue
-        kernels = json.load(open(prof_path))["kernels"]
+        prof = json.load(open(prof_path))
+        kernels, pcfg = prof["kernels"], prof["config"]
         tag = os.path.basename(path)
+        if pcfg["workload"] != cfg["workload"] or list(pcfg.get("options", [])) != list(cfg.get("options", [])):
+            problems.append("%s: profile %s is of workload %s options %s" % (tag, roof["pmc_source"], pcfg["workload"], pcfg.get("options")))
+            continue
+        if line["steps"] * 2 != roof["launches"]:
+            problems.append("%s: %d launches for %d steps" % (tag, roof["launches"], line["steps"]))
         lines += 1
         if roof.get("bound") == "l1-tag-pipeline":
-            msg = check_k910(tag, roof, kernels["k910"], problems)
+            msg = check_k910(tag, roof, kernels["k910"], problems, pcfg["steps"])
             strong = line.get("strong_path")
             if strong and strong.get("achieved") is not None:
-                msg += " | " + check_k67(tag + " strong_path", strong, kernels["k67"], mix, problems)
+                msg += " | " + check_k67(tag + " strong_path", strong, kernels["k67"], mix, problems, pcfg["steps"])
         else:
-            msg = check_k67(tag, roof, kernels["k67"], mix, problems)
+            msg = check_k67(tag, roof, kernels["k67"], mix, problems, pcfg["steps"])
         print("%-36s %s  %s" % (tag, cfg["workload"], msg))
     return problems, lines
 
