@@ -23,7 +23,7 @@ namespace apd {
 
 // RescaleMatToTargetSize (APD.cpp:752-774): dst(r, c) = src((int)(r / scale_x), (int)(c / scale_y)) with
 // scale_x = dst_w / (float)src_w and scale_y = dst_h / (float)src_h -- the row is divided by the COLUMN ratio and the column by
-// the ROW ratio; pixels whose source index falls outside keep what `dst` held.
+// the ROW ratio; pixels whose source index falls outside become 0 (what host/APD.cpp and pipeline.py define for the reference's unwritten pixels).
 template <typename T>
 __global__ __launch_bounds__(256) void k_rescale_nearest(const T *__restrict__ src, int sw, int sh, T *__restrict__ dst, int dw, int dh)
 {
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void k_rescale_nearest(const T *__restrict__ s
     const int o_r = (int)((float)r / scale_x);
     const int o_c = (int)((float)c / scale_y);
     if (o_r < 0 || o_c < 0 || o_r >= sh || o_c >= sw) {
+        dst[(size_t)r * dw + c] = T();  // the reference leaves these pixels of a fresh cv::Mat unwritten; the host restatements define them as 0
         return;
     }
     dst[(size_t)r * dw + c] = src[(size_t)o_r * sw + o_c];
@@ -179,6 +180,9 @@ int apd_device_memcpy(int device, void *dst, const void *src, size_t bytes)
 {
     X_TRY(hipSetDevice(device));
     X_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDefault));  // host / device on either side (unified addressing)
+    // a device-to-device hipMemcpy may return before the copy has run; callers hand `dst` to other streams (the exchange's
+    // are non-blocking ones, which do not wait for the null stream) and to other threads
+    X_TRY(hipStreamSynchronize(nullptr));
     return APD_OK;
 }
 
@@ -186,6 +190,7 @@ int apd_device_memset(int device, void *dst, int value, size_t bytes)
 {
     X_TRY(hipSetDevice(device));
     X_TRY(hipMemset(dst, value, bytes));
+    X_TRY(hipStreamSynchronize(nullptr));  // hipMemset of device memory is asynchronous
     return APD_OK;
 }
 
@@ -197,6 +202,7 @@ int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h
     X_TRY(hipSetDevice(device));
     if (src_w == dst_w && src_h == dst_h) {  // the reference returns before touching dst (APD.cpp:754-756); callers want the copy
         X_TRY(hipMemcpy(dst, src, (size_t)src_w * src_h * elem_bytes, hipMemcpyDeviceToDevice));
+        X_TRY(hipStreamSynchronize(nullptr));
         return APD_OK;
     }
     const dim3 grid((dst_w + 255) / 256, dst_h);
@@ -275,6 +281,14 @@ int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *cons
         return xfail(APD_ERR_INVALID, "apd_exchange_allgather: bad argument");
     }
     const int n = (int)x->devices.size();
+    // The send buffers were written on other streams (the handles' own, the null stream of the pack copies); the exchange's
+    // streams are non-blocking ones and would not wait for any of them.  Blocking collective: everything the devices were
+    // given before this call has finished before the first byte moves.  (Found the hard way: at 3100 x 2065 the planes of
+    // views 1.. reached the fusion partly or not at all while the 1100 x 64 test passed.)
+    for (int r = 0; r < n; ++r) {
+        X_TRY(hipSetDevice(x->devices[r]));
+        X_TRY(hipDeviceSynchronize());
+    }
     if (!x->comms.empty()) {
         int rc = g_rccl.GroupStart();
         for (int r = 0; r < n && rc == 0; ++r) {

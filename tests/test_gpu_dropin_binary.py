@@ -249,6 +249,42 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
         assert ok.mean() > 0.5
         close.append(float((np.abs(a[ok] - b[ok]) <= 0.02 * b[ok]).mean()))
     assert min(close) > 0.9, close
+    n_jacobi, n_files = len(_read_ply(ref / "APD" / "APD.ply")[0]), len(_read_ply(fd / "APD" / "APD.ply")[0])
+    assert 0.8 * n_files < n_jacobi < 1.25 * n_files, (n_jacobi, n_files)
+
+
+def test_multi_device_scheduler_at_a_size_where_copies_take_time(gpu_pkg, synth, tmp_path):
+    """The same comparison at 2200 x 1500 (two levels, 3.3 Mpix per map): every view of the in-memory run must come out
+    valid and close to the file-based run, and the clouds must be of comparable size.  (At this size a pack copy that has not
+    finished when the exchange starts shows: before apd_exchange_allgather waited for the devices, views 1.. arrived partly
+    or not at all, and the fused cloud had a seventh of the points.)"""
+    import shutil
+    W, H, nviews, seed = 2200, 1500, 4, 5
+    base = tmp_path / "base"
+    base.mkdir()
+    _write_dense_folder(base, synth, W, H, nviews, jpeg=False)
+    runs = {}
+    for name, dev, extra in (("jacobi", "0", ["--jacobi"]), ("two", "0,0", []), ("files", "0", [])):
+        d = tmp_path / name
+        shutil.copytree(base, d)
+        r = subprocess.run([APD_BIN, str(d), dev, "--seed", str(seed), "--iters", "1", "--keep-maps"] + extra, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout[-3000:]
+        runs[name] = d
+    for idx in range(nviews):
+        a = _read_dmb(runs["jacobi"] / "APD" / ("%08d" % idx) / "depths.dmb")
+        b = _read_dmb(runs["files"] / "APD" / ("%08d" % idx) / "depths.dmb")
+        c = _read_dmb(runs["two"] / "APD" / ("%08d" % idx) / "depths.dmb")
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), idx
+        assert abs(float((a > 0).mean()) - float((b > 0).mean())) < 0.02, (idx, float((a > 0).mean()), float((b > 0).mean()))
+        ok = (a > 0) & (b > 0)
+        assert float((np.abs(a[ok] - b[ok]) <= 0.02 * b[ok]).mean()) > 0.9, idx
+        wa = _read_dmb(runs["jacobi"] / "APD" / ("%08d" % idx) / "weak.bin")
+        wb = _read_dmb(runs["files"] / "APD" / ("%08d" % idx) / "weak.bin")
+        assert float((wa == wb).mean()) > 0.9, idx
+    n_j, n_f = len(_read_ply(runs["jacobi"] / "APD" / "APD.ply")[0]), len(_read_ply(runs["files"] / "APD" / "APD.ply")[0])
+    assert (runs["jacobi"] / "APD" / "APD.ply").read_bytes() == (runs["two"] / "APD" / "APD.ply").read_bytes()
+    assert 0.8 * n_f < n_j < 1.25 * n_f, (n_j, n_f)
 
 
 def _read_ply(path):
