@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "apd_device.h"
 
 namespace apd {
@@ -144,12 +146,41 @@ struct RcclApi {
 static RcclApi g_rccl;
 constexpr int kNcclInt8 = 0;  // ncclDataType_t ncclInt8 / ncclChar: the payload is moved as bytes
 
+// RCCL's set-up (dlopen of a library with code objects for every architecture + ncclCommInitAll) takes seconds -- 5.6 s for
+// ONE device on the MI355X box, more than all eight passes of a 12-view 1080p reconstruction (4.0 s) -- and it cannot be
+// hidden: run on a background thread while the first passes compute, it stalls their launches for as long as it takes
+// (passes 4.0 -> 9.9 s, measured), so it runs before the first pass or not at all.  A caller with one rank has nothing to
+// exchange between devices and should ask for direct copies (host/multi_device.cpp does).
+enum { kRcclOff = 0, kRcclPending = 1, kRcclReady = 2, kRcclFailed = 3 };
+
 struct apd_exchange {
     std::vector<int> devices;
     std::vector<hipStream_t> streams;
-    std::vector<void *> comms;  // ncclComm_t per rank; empty -> direct copies
-    std::string backend;
+    std::vector<void *> comms;  // ncclComm_t per rank; used only once rccl_state == kRcclReady
+    std::atomic<int> rccl_state{kRcclOff};
+    std::string rccl_error;
+    int exchanges_rccl = 0, exchanges_copy = 0;
+    std::string backend;        // what apd_exchange_backend last reported
 };
+
+static void rccl_initialise(apd_exchange *x)
+{
+    const int n = (int)x->devices.size();
+    if (!g_rccl.load()) {
+        x->rccl_error = "librccl not found";
+        x->rccl_state.store(kRcclFailed);
+        return;
+    }
+    x->comms.assign(n, nullptr);
+    const int rc = g_rccl.CommInitAll(x->comms.data(), n, x->devices.data());
+    if (rc != 0) {
+        x->rccl_error = g_rccl.GetErrorString(rc);
+        x->comms.clear();
+        x->rccl_state.store(kRcclFailed);
+        return;
+    }
+    x->rccl_state.store(kRcclReady);
+}
 
 extern "C" {
 
@@ -243,18 +274,14 @@ int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, 
             return xfail(APD_ERR_HIP, "apd_exchange_create: cannot create a stream on device %d", devices[i]);
         }
     }
-    x->backend = "peer-copy";
-    if (prefer_rccl && distinct && g_rccl.load()) {  // one communicator per rank, all in this process
-        x->comms.assign(num_ranks, nullptr);
-        const int rc = g_rccl.CommInitAll(x->comms.data(), num_ranks, devices);
-        if (rc == 0) {
-            x->backend = "rccl";
-        } else {
-            fprintf(stderr, "apd_exchange_create: ncclCommInitAll failed (%s): using direct copies\n", g_rccl.GetErrorString(rc));
-            x->comms.clear();
+    if (prefer_rccl && distinct) {  // one communicator per rank, all in this process
+        x->rccl_state.store(kRcclPending);
+        rccl_initialise(x);
+        if (x->rccl_state.load() == kRcclFailed) {
+            fprintf(stderr, "apd_exchange_create: RCCL is not available (%s): using direct copies\n", x->rccl_error.c_str());
         }
     }
-    if (x->comms.empty() && distinct) {  // direct copies between different devices: let them go over xGMI
+    if (distinct && x->rccl_state.load() != kRcclReady) {  // direct copies between different devices: let them go over xGMI
         for (int i = 0; i < num_ranks; ++i) {
             for (int j = 0; j < num_ranks; ++j) {
                 int can = 0;
@@ -272,7 +299,28 @@ int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, 
     return APD_OK;
 }
 
-const char *apd_exchange_backend(apd_exchange_t x) { return x ? x->backend.c_str() : ""; }
+const char *apd_exchange_backend(apd_exchange_t x)
+{
+    if (!x) {
+        return "";
+    }
+    x->backend = x->rccl_state.load() == kRcclReady ? "rccl" : "peer-copy";
+    return x->backend.c_str();
+}
+
+int apd_exchange_counts(apd_exchange_t x, int *with_rccl, int *with_copies)
+{
+    if (!x) {
+        return xfail(APD_ERR_INVALID, "apd_exchange_counts: null exchange");
+    }
+    if (with_rccl) {
+        *with_rccl = x->exchanges_rccl;
+    }
+    if (with_copies) {
+        *with_copies = x->exchanges_copy;
+    }
+    return APD_OK;
+}
 
 // recv[r] of every rank r ends as send[0] | send[1] | ... | send[num_ranks - 1], `bytes_per_rank` each.
 int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank)
@@ -289,7 +337,8 @@ int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *cons
         X_TRY(hipSetDevice(x->devices[r]));
         X_TRY(hipDeviceSynchronize());
     }
-    if (!x->comms.empty()) {
+    if (x->rccl_state.load() == kRcclReady) {
+        x->exchanges_rccl++;
         int rc = g_rccl.GroupStart();
         for (int r = 0; r < n && rc == 0; ++r) {
             rc = g_rccl.AllGather(send[r], recv[r], bytes_per_rank, kNcclInt8, x->comms[r], x->streams[r]);
@@ -300,6 +349,7 @@ int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *cons
             return xfail(APD_ERR_HIP, "ncclAllGather failed: %s", g_rccl.GetErrorString(rc));
         }
     } else {
+        x->exchanges_copy++;
         for (int dst = 0; dst < n; ++dst) {  // every rank pulls every block on its own stream
             X_TRY(hipSetDevice(x->devices[dst]));
             for (int src = 0; src < n; ++src) {

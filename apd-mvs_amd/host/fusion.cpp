@@ -8,6 +8,7 @@
 //
 // Outside the PatchMatch path proper.  Like the reference, the images are re-read in colour for the
 // point colours (cv::imread(IMREAD_COLOR), APD.cpp:859; host/jpeg_gray.cpp decodes to the same BGR bytes as libjpeg).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +82,7 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems) {
 // problems[i]; nullptr reads the files.
 void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps)
 {
+    const auto t_inputs = std::chrono::steady_clock::now();
     std::vector<FusionView> views(problems.size());
     std::unordered_map<int, int> index_of_id;
     const path block_folder = dense_folder / path("blocks");
@@ -167,7 +169,10 @@ void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &pro
         }
     }
     const path ply_path = dense_folder / path("APD") / path("APD.ply");
+    const auto t_fuse = std::chrono::steady_clock::now();
+    std::cout << "Fusion inputs ready: " << std::chrono::duration_cast<std::chrono::milliseconds>(t_fuse - t_inputs).count() << " ms" << std::endl;
     const long long n = fuse_dispatch(views, sources, ply_path);
+    std::cout << "Fusion + PLY: " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_fuse).count() << " ms" << std::endl;
     if (n < 0) {
         exit(EXIT_FAILURE);  // like every other device error of the reference (CudaSafeCall, APD.cpp:315-323)
     }

@@ -1,10 +1,11 @@
 // main.cpp -- drop-in driver of the PatchMatch path.
 //
 //   APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]
-//       [--jacobi] [--no-rccl]
+//       [--jacobi] [--no-rccl] [--rccl]
 //
 // One device index: the reference's driver.  A device LIST (or --jacobi): host/multi_device.cpp -- views sharded over the
-// devices, state resident on them, depth maps all-gathered after every pass (RCCL; --no-rccl: direct copies).
+// devices, state resident on them, depth maps all-gathered after every pass (RCCL when there is more than one rank -- its set-up takes seconds
+// -- direct copies for a single rank; --rccl: RCCL even then; --no-rccl: direct copies only).
 //
 // Same command line, files and results as the reference driver (main.cpp:140-233), organised differently:
 //   * pair.txt is read as one token stream with diagnostics (the reference never notices a missing or short file,
@@ -63,6 +64,8 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.jacobi = true;
         } else if (a == "--no-rccl") {
             o.use_rccl = false;
+        } else if (a == "--rccl") {
+            o.force_rccl = true;
         } else if (i == 2 && a.size() && a[0] != '-') {
             // positional, as in the reference (main.cpp:149-153); additive: a comma-separated list = one scheduler rank per entry
             o.devices.clear();
@@ -210,7 +213,7 @@ int main(int argc, char **argv)
 {
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
-        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--jacobi] [--no-rccl]\n");
+        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--jacobi] [--no-rccl] [--rccl]\n");
         return EXIT_FAILURE;
     }
     if (opt.devices.empty()) {

@@ -107,8 +107,23 @@ apd_params ToAbi(const PatchMatchParams &q)
 
 }  // namespace
 
+namespace {
+struct StageClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    long long lap()
+    {
+        const auto now = std::chrono::steady_clock::now();
+        const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(now - t).count();
+        t = now;
+        return ms;
+    }
+};
+}  // namespace
+
 int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
 {
+    StageClock stage;
+    long long ms_load = 0, ms_setup = 0, ms_passes = 0, ms_gather = 0, ms_fusion = 0;
     const std::vector<int> &devices = opt.devices;
     const int G = (int)devices.size(), V = (int)problems.size();
     if (G < 1 || V < 1) {
@@ -146,6 +161,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             return EXIT_FAILURE;
         }
     }
+    ms_load = stage.lap();
     const int W0 = full[0].cols, H0 = full[0].rows;
     const size_t pix0 = (size_t)W0 * H0;
     const int round_num = opt.single_level ? 1 : RoundNum(W0, H0);
@@ -179,14 +195,19 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             s.views.alloc(k.device, pix0 * 4);
         }
     }
+    const long long ms_alloc = stage.lap();
     apd_exchange_t exchange = nullptr;
-    Check(apd_exchange_create(&exchange, G, devices.data(), opt.use_rccl ? 1 : 0), "apd_exchange_create");
+    // RCCL's set-up costs seconds (5.6 s for one device on the MI355X box, against 4.0 s for all eight passes of a 12-view 1080p
+    // folder) and cannot be overlapped with the passes: a single rank, which exchanges with itself, does without unless --rccl
+    Check(apd_exchange_create(&exchange, G, devices.data(), (opt.use_rccl && (G > 1 || opt.force_rccl)) ? 1 : 0), "apd_exchange_create");
+    printf("Device buffers: %lld ms, exchange set-up: %lld ms\n", ms_alloc, stage.lap());
     printf("Exchange of depth maps between passes: %s\n", apd_exchange_backend(exchange));
 
     auto block_of_view = [&](const Rank &k, int v, size_t pix) {  // view v inside a gathered block
         return k.recv.as<float>() + ((size_t)(v % G) * slots + (size_t)(v / G)) * pix;
     };
 
+    ms_setup = ms_alloc + stage.lap();
     int level_scale = 0, LW = 0, LH = 0;   // current level
     int gathered_w = 0, gathered_h = 0;    // size of the depth maps in `recv`
     std::vector<Camera> cams(N);
@@ -332,6 +353,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         fflush(stdout);
     }
 
+    ms_passes = stage.lap();
     // ---- before fusion: planes (world normal + depth) and weak maps of all views on every rank ----
     const size_t pix = (size_t)LW * LH;
     std::vector<FinalMaps> maps(V);
@@ -423,13 +445,22 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         k.scratch_weak.release();
         k.scratch_views.release();
     }
+    {
+        int with_rccl = 0, with_copies = 0;
+        apd_exchange_counts(exchange, &with_rccl, &with_copies);
+        printf("Exchanges: %d through RCCL, %d through direct copies\n", with_rccl, with_copies);
+    }
     apd_exchange_destroy(exchange);
     const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_all).count();
     printf("All passes done: %lld ms\n", (long long)ms);
+    ms_gather = stage.lap();
     if (!opt.no_fusion) {
         std::filesystem::create_directories(opt.dense_folder / "APD");
         RunFusionWithMaps(opt.dense_folder, problems, &maps);
     }
+    ms_fusion = stage.lap();
+    printf("Stages: images + cameras %lld ms, device set-up %lld ms, passes %lld ms, final gather + maps %lld ms, fusion %lld ms\n", ms_load,
+           ms_setup, ms_passes, ms_gather, ms_fusion);
     printf("All done\n");
     return EXIT_SUCCESS;
 }

@@ -16,6 +16,7 @@ struct Options {
     std::vector<int> devices;   // "0,1,2,3": one scheduler rank per entry (an entry may repeat: two ranks on one device)
     bool jacobi = false;        // the in-memory scheduler of host/multi_device.cpp even with a single device
     bool use_rccl = true;       // --no-rccl: exchange maps with direct copies
+    bool force_rccl = false;    // --rccl: RCCL even for a single rank (which has nothing to exchange between devices and uses direct copies otherwise)
     uint64_t seed = 12345;
     int iters = 3;          // PatchMatchParams::max_iterations of every pass (reference: 3)
     int max_src = 0;        // > 0: keep only the first N sources of each pair.txt entry (they are sorted by score)

@@ -193,9 +193,13 @@ int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h
  * initialisation fails or when the list names a device twice (how a one-GPU box runs the multi-device scheduler).
  * Blocking; not thread-safe per exchange object. */
 typedef struct apd_exchange *apd_exchange_t;
+/* prefer_rccl != 0: RCCL, set up before the call returns.  That takes seconds (librccl + ncclCommInitAll: 5.6 s for ONE device on
+ * the MI355X box) and cannot be hidden behind the first passes (on a background thread it stalls their launches for as long
+ * as it runs); a caller with a single rank should pass 0. */
 int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl);
 int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank);
 const char *apd_exchange_backend(apd_exchange_t x);   /* "rccl" or "peer-copy" */
+int apd_exchange_counts(apd_exchange_t x, int *with_rccl, int *with_copies);   /* exchanges served by either backend so far */
 int apd_exchange_destroy(apd_exchange_t x);
 const char *apd_exchange_last_error(void);
 

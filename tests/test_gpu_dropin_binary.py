@@ -218,20 +218,24 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     base.mkdir()
     _write_dense_folder(base, synth, W, H, nviews, jpeg=False)
     runs = {}
-    for name, dev, extra in (("one", "0", ["--jacobi"]), ("one_copy", "0", ["--jacobi", "--no-rccl"]), ("three", "0,0,0", []), ("two", "0,0", []),
-                             ("files", "0", [])):
+    for name, dev, extra in (("one", "0", ["--jacobi", "--rccl"]), ("one_default", "0", ["--jacobi"]), ("one_copy", "0", ["--jacobi", "--no-rccl"]),
+                             ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", [])):
         d = tmp_path / name
         shutil.copytree(base, d)
         r = subprocess.run([APD_BIN, str(d), dev, "--seed", str(seed), "--iters", "1", "--keep-maps"] + extra, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:]
         runs[name] = (d, r.stdout)
-    assert "Exchange of depth maps between passes: rccl" in runs["one"][1], runs["one"][1][-2000:]
+    assert "Exchange of depth maps between passes: rccl\n" in runs["one"][1], runs["one"][1][-2000:]
+    assert "through RCCL, 0 through direct copies" in runs["one"][1]
+    # a single rank has nothing to exchange between devices: direct copies unless --rccl (RCCL's set-up takes seconds)
+    assert "Exchange of depth maps between passes: peer-copy" in runs["one_default"][1], runs["one_default"][1][-2000:]
+    assert "Exchanges: 0 through RCCL" in runs["one_default"][1]
     assert "Exchange of depth maps between passes: peer-copy" in runs["one_copy"][1]
     assert "Exchange of depth maps between passes: peer-copy" in runs["three"][1]   # one device named three times: RCCL needs distinct devices
     assert "Round nums: 2" in runs["one"][1] and "rank 2 (device 0)" in runs["three"][1]
     ref = runs["one"][0]
-    for name in ("one_copy", "three", "two"):
+    for name in ("one_default", "one_copy", "three", "two"):
         d = runs[name][0]
         for idx in range(nviews):
             for f in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):

@@ -22,6 +22,7 @@ def _lib(pkg):
     L.apd_exchange_backend.argtypes = [C.c_void_p]
     L.apd_exchange_backend.restype = C.c_char_p
     L.apd_exchange_destroy.argtypes = [C.c_void_p]
+    L.apd_exchange_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.apd_exchange_last_error.restype = C.c_char_p
     return L
 
@@ -71,6 +72,9 @@ def test_allgather_waits_for_the_copies_that_fill_its_send_buffers(gpu_pkg, devi
                 got = np.empty(per_rank * n, np.uint8)
                 assert L.apd_device_memcpy(0, _host_ptr(got), recv[r], per_rank * n) == 0
                 assert np.array_equal(got, want), (round_, r, int((got != want).sum()))
+        a, b = C.c_int(), C.c_int()
+        assert L.apd_exchange_counts(x, C.byref(a), C.byref(b)) == 0
+        assert (a.value, b.value) == ((3, 0) if backend == b"rccl" else (0, 3))
     finally:
         for p in src + send + recv:
             L.apd_device_free(0, p)
