@@ -142,3 +142,35 @@ def test_isa_contract_exhaustive():
     assert facts.get("CHECK_fract_finite_mismatches") == "0", out
     assert facts.get("CHECK_fract_nonfinite_not_nan") == "0", out
     assert facts.get("CHECK_cvt_flr_non_nan_mismatches") == "0", out
+
+
+@pytest.mark.parametrize("threshold,rotate", [(float("inf"), 4), (0.0, 4), (0.005, 3), (1e-30, 2)])
+def test_gen_neighbours_with_and_without_a_distance_cut(gpu_pkg, ob, synth, threshold, rotate):
+    """K3's inlier test is a comparison with a host-computed cut where one exists (csrc/apd_capi.hip: ransac_distance_cut) and
+    the reference's division where none does (an infinite threshold); with rotate_time 4 the jitter range is 1 and a
+    (slot, radius) is probed once instead of four identical times, with 3 it is 2 and the four attempts differ.  Every
+    combination must leave the oracle's bits: neighbours, reliability, RNG words."""
+    W, H, N = 96, 72, 4
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=3, textureless=0.25)
+    prior = None
+    weak_seen = 0
+    for pi, extra in enumerate([dict(state=0, use_APD=0, weak_peak_radius=6),
+                                dict(state=1, use_APD=1, weak_peak_radius=6, rotate_time=rotate, ransac_threshold=threshold)]):
+        p = common.base_params(sc, N, seed=11, **extra)
+        h = common.make_handle(gpu_pkg, sc, imgs, N, p, prior=prior)
+        o = common.make_oracle(ob, sc, imgs, N, p, prior=prior)
+        weak_seen = max(weak_seen, h.weak_count)
+        sched = [1, 2] + ([3, 4] if h.weak_count else []) + [5]
+        for i in range(p["max_iterations"]):
+            sched += [(6, i), (7, i), (8, i)] + ([(9, i), (10, i)] if h.weak_count else [])
+        sched += [11, 12, 13, 14, 15]
+        for s in sched:
+            kid, it = (s, 0) if isinstance(s, int) else s
+            h.run_kernel(kid, it)
+            o.run_kernel(kid, it)
+            common.assert_state_equal(gpu_pkg, h, o, "threshold %r rotate %d pass %d after K%d" % (threshold, rotate, pi, kid))
+        planes, weak, views = h.download()
+        prior = common.postprocess(planes, weak, views, p["depth_min"], p["depth_max"])
+        h.close()
+        o.close()
+    assert weak_seen > 50
