@@ -122,7 +122,8 @@ __device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewCon
 #define APD_K15W_WAVES 3  // 4 waves/SIMD (100 VGPRs spilled) 30.5, 3 waves 27.1
 #endif
 #ifndef APD_K1415W_WAVES_F32
-#define APD_K1415W_WAVES_F32 2  // float windows: 16.9 KB per wave, two workgroups per CU
+#define APD_K1415W_WAVES_F32 3  // float windows (single-texel entries, 9.5 KB per wave like the 8-bit ones); ms at 2048x1536, 8 views, K14 / K15:
+                                // 2 waves/SIMD 41.6 / 3.77, 3 waves 34.5 / 3.18, 4 waves 36.5 / 3.87 (8-byte pair entries, 2 waves: 40.4 / 3.80)
 #endif
 template <bool kQuad>
 __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32) void k14w_depth_to_weak(FrameArgs fa)

@@ -126,7 +126,8 @@ constexpr float kTrustedCost = APD_WIN_TRUST;
 #define APD_K67W_WAVES 4
 #endif
 #ifndef APD_K67W_WAVES_F32
-#define APD_K67W_WAVES_F32 3  // float windows are twice the size: three workgroups per CU
+#define APD_K67W_WAVES_F32 3  // float windows: three waves per SIMD also with the single-texel entries (4 waves, 128 VGPRs: 32.4 against 29.1 ms
+                              // for the first iteration at 2048x1536, 16.0 against 14.6 later)
 #endif
 // kTiled: NCCs that miss the window (all of them while the windows are off) gather from the tiled copy of the quad image
 // kApprox: tolerance mode APD_OPT_FAST_RCP (bare v_rcp_f32 in the sample loops; not bit-identical to the oracle)

@@ -19,8 +19,16 @@ namespace apd {
 // and a four-way conflict for the 8x8 footprint of K14/K15 (a group reads four rows of the same eight columns); those
 // kernels use pitch 72, which moves consecutive rows by 8 (binary16 pairs) / 16 (binary32 pairs) banks.
 constexpr int kWinW = 64;
+// Float images: an entry is the texel alone (4 bytes) and the horizontal difference t(x+1) - t(x) is formed after the read --
+// the same rounded subtraction the {texel, difference} pairs of the float texel-quad image store, two more plain FP32
+// instructions per sample, half the LDS (K6/K7 47 -> 26 KB, K14/K15 79 -> 41 KB per workgroup: the occupancy of the 8-bit
+// kernels).  -DAPD_WIN_F32_PAIRS=1 rebuilds the 8-byte {texel, difference} entries of rounds 1-2.
+#ifndef APD_WIN_F32_PAIRS
+#define APD_WIN_F32_PAIRS 0
+#endif
+constexpr bool kWinF32Pairs = APD_WIN_F32_PAIRS != 0;
 // LDS dwords of a window with WINH rows of fetch positions (+ the row below the last one)
-constexpr int window_dwords(bool quad, int winh, int pitch = kWinW) { return pitch * (winh + 1) * (quad ? 1 : 2); }
+constexpr int window_dwords(bool quad, int winh, int pitch = kWinW) { return pitch * (winh + 1) * ((quad || !kWinF32Pairs) ? 1 : 2); }
 static_assert(kQuadShift == 2, "the window is staged from dword fetches of the quad image");
 
 template <bool kQuad> struct WinEntry;
@@ -29,8 +37,8 @@ template <> struct WinEntry<true> {
     static constexpr int kShift = 2;
 };
 template <> struct WinEntry<false> {
-    typedef pair_t type;     // {binary32 t, binary32 dx}
-    static constexpr int kShift = 3;
+    typedef pair_t type;     // what a tap read returns: {binary32 t, binary32 dx} (pairs) or {t(x), t(x + 1)} (single texels)
+    static constexpr int kShift = kWinF32Pairs ? 3 : 2;
 };
 
 typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
@@ -62,6 +70,24 @@ __device__ __forceinline__ WinTaps<E> lds_read_pair(int addr)
     t.bot = p[kPitch];
 #else
     t.top = t.bot = E();
+#endif
+    return t;
+}
+
+// single-texel float entries: {t(x, y), t(x + 1, y)} and the same of the row below -- two two-address reads
+template <int kPitch>
+__device__ __forceinline__ WinTaps<pair_t> lds_read_texels(int addr)
+{
+    WinTaps<pair_t> t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) float *lds_ptr;
+    const lds_ptr p = (lds_ptr)(uintptr_t)(uint32_t)addr;
+    t.top.x = p[0];
+    t.top.y = p[1];
+    t.bot.x = p[kPitch];
+    t.bot.y = p[kPitch + 1];
+#else
+    t.top = t.bot = pair_t();
 #endif
     return t;
 }
@@ -175,6 +201,23 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
                 win[k * kPitch + lane] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, dx));
             }
         }
+    } else if constexpr (!kWinF32Pairs) {
+        // texel (clamp(x), clamp(y)) of the plain float image: coalesced 256-byte row reads; the clamp makes the difference
+        // formed after the read the one the float texel quads store (0 left of, right of and at the last column of the image)
+        typedef const __attribute__((address_space(1))) float *global_float_ptr;
+        const global_float_ptr img = (global_float_ptr)vc.img;
+        float *winf = reinterpret_cast<float *>(win);
+        const int cx = med3_i32(wx0 + lane, 0, fa.W - 1);
+        float tmp[kWinRows];
+#pragma unroll
+        for (int k = 0; k < kWinRows; ++k) {
+            const int gy = min(max(wy0 + k, 0), fa.H - 1);  // wave-uniform
+            tmp[k] = img[(unsigned)(gy * fa.W + cx)];
+        }
+#pragma unroll
+        for (int k = 0; k < kWinRows; ++k) {
+            winf[k * kPitch + lane] = tmp[k];
+        }
     } else {
         // the pair of texel row gy is the first half of float quad (., gy); the row below the image (gy == H, a copy
         // of row H - 1 by the clamp) is the second half of quad (., H - 1)
@@ -204,7 +247,8 @@ __device__ __forceinline__ SrcWindow stage_window_around(const FrameArgs &fa, co
     // (samples left of / above the image, where both taps are the clamped edge texel, take the global path: the window
     // path computes its LDS addresses in binary32 and relies on X, Y >= 0)
     w.lo_x = (float)max(wx0 + 1, 0);
-    w.hi_x = (float)(wx0 + kWinW - 1);
+    // single-texel float entries: a fetch at column c also reads column c + 1
+    w.hi_x = (float)(wx0 + kWinW - ((kQuad || kWinF32Pairs) ? 1 : 2));
     w.lo_y = (float)max(wy0 + 1, 0);
     w.hi_y = (float)(wy0 + WINH - 1);
     w.addr0 = __builtin_amdgcn_readfirstlane(lds_address(win) - (wy0 * kPitch + wx0) * (1 << kShift));
@@ -313,7 +357,11 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
     APD_STAGE();
 #pragma unroll
     for (int j = 0; j < kPatchN; ++j) {
-        t[j] = lds_read_pair<typename WinEntry<kQuad>::type, kPitch>(addr[j]);
+        if constexpr (kQuad || kWinF32Pairs) {
+            t[j] = lds_read_pair<typename WinEntry<kQuad>::type, kPitch>(addr[j]);
+        } else {
+            t[j] = lds_read_texels<kPitch>(addr[j]);
+        }
     }
 }
 
@@ -328,9 +376,12 @@ __device__ __forceinline__ void win_row_lerp(const WinTaps<typename WinEntry<kQu
         if constexpr (kQuad) {
             top[j] = lerp_f16_pair(a[j], t[j].top);
             bot[j] = lerp_f16_pair(a[j], t[j].bot);
-        } else {
+        } else if constexpr (kWinF32Pairs) {
             top[j] = fmaf(a[j], t[j].top.y, t[j].top.x);
             bot[j] = fmaf(a[j], t[j].bot.y, t[j].bot.x);
+        } else {  // {t(x), t(x + 1)}: the difference the pairs store, formed here
+            top[j] = fmaf(a[j], t[j].top.y - t[j].top.x, t[j].top.x);
+            bot[j] = fmaf(a[j], t[j].bot.y - t[j].bot.x, t[j].bot.x);
         }
     }
     APD_STAGE();
