@@ -125,6 +125,9 @@ constexpr float kTrustedCost = APD_WIN_TRUST;
 #ifndef APD_K67W_WAVES
 #define APD_K67W_WAVES 4
 #endif
+#ifndef APD_K67_COMPACT_REFINE
+#define APD_K67_COMPACT_REFINE 1  // the refinement phase walks a compacted table of open (lane, hypothesis) pairs; 0: one NCC per hypothesis any lane has open
+#endif
 #ifndef APD_K67W_WAVES_F32
 #define APD_K67W_WAVES_F32 3  // float windows: three waves per SIMD also with the single-texel entries (4 waves, 128 VGPRs: 32.4 against 29.1 ms
                               // for the first iteration at 2048x1536, 16.0 against 14.6 later)
@@ -136,6 +139,10 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 {
     __shared__ float tile[kLdsH * kLdsPitch];
     __shared__ uint32_t windows[4][window_dwords(kQuad, kWinH)];
+#if APD_K67_COMPACT_REFINE
+    __shared__ uint16_t refine_items[4][5 * 64];  // per wave: (hypothesis << 6) | owner lane of every open (lane, hypothesis), hypothesis-major
+    __shared__ float refine_cost[4][5][64];       // per wave: the cost a worker lane computed for (hypothesis, owner lane)
+#endif
     const TilePixel t = checkerboard_pixel(fa, colour);
     // stage the reference tile + 5 px halo (clamp-to-edge, as the texture unit would)
     for (int idx = threadIdx.x; idx < kLdsW * kLdsH; idx += 256) {
@@ -302,6 +309,102 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
     // skipped and the accept test below rejects it exactly as it would reject the full sum.  In converged iterations
     // that removes most NCCs of the two random-depth hypotheses, which are also the ones that miss the windows.
     const float lost = refinement_lost_bound(fa, cost_now, weight_norm);
+#if APD_K67_COMPACT_REFINE
+    // Which (lane, hypothesis) pairs are still open differs from lane to lane -- a view a pixel did not select, a hypothesis
+    // that has already lost -- and a wave runs an NCC whenever ANY of its lanes needs it: in converged iterations the lanes
+    // need 11 refinement NCCs per pixel and the waves execute 25 (tools/win_stats.py).  So the open pairs of a view are
+    // compacted: every lane enters its pairs into a per-wave table (hypothesis-major, ranks from ballots), the wave walks
+    // the table 64 entries at a time, and the lane that gets entry (owner, hypothesis) fetches the owner's hypothesis and
+    // reference moments through ds_bpermute, scores it from the owner's pixel position (same window, same reference tile:
+    // both belong to the wave) and leaves the cost in LDS for the owner, who adds it to its running sum in view order
+    // exactly as before.  Same NCCs on the same operands: same bits; ceil(pairs / 64) wave-level NCCs per view instead
+    // of one per hypothesis anybody still has open.
+    const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
+    uint16_t *items = refine_items[wave_id];
+    float(*costs_out)[64] = refine_cost[wave_id];
+    const int wave_lx0 = (wave_id % kWavesX) * kWaveW, wave_ly0 = (wave_id / kWavesX) * kWaveH;
+#pragma unroll 1
+    for (int v = 0; v < nsrc; ++v) {
+        const uint32_t wv = alive ? vw.get(v) : 0u;
+        unsigned open = 0;  // hypotheses of this lane that can still win
+        if (wv > 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                open |= (tc[k] >= lost) ? 0u : (1u << k);
+            }
+        }
+        // table order: the hypotheses that keep the pixel's depth first (random normal, perturbed normal, perturbed depth: their
+        // patches land where the window is), the two random-depth ones last -- a slot takes the global path as soon as one of its
+        // entries misses the window, so the misses are collected in the last, partly filled slot
+        constexpr int kOrder[5] = {1, 3, 4, 0, 2};
+        int off[6];
+        off[0] = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = kOrder[j];
+            const unsigned long long m = __builtin_amdgcn_ballot_w64((open >> k) & 1u);
+            if ((open >> k) & 1u) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                items[off[j] + rank] = (uint16_t)((k << 6) | lane);
+            }
+            off[j + 1] = off[j] + __builtin_popcountll(m);
+        }
+        const int total = off[5];
+        if (total == 0) {
+            continue;  // nobody in the wave has anything left to score in this view
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the table is read by other lanes of the wave
+        __builtin_amdgcn_wave_barrier();
+        const ViewConst &vc = view_const(fa, v);
+        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
+#pragma unroll 1
+        for (int first = 0; first < total; first += 64) {
+            const int idx = first + lane;
+            const bool valid = idx < total;
+            const unsigned item = valid ? (unsigned)items[idx] : 0u;
+            const int owner = (int)(item & 63u), hyp = (int)(item >> 6);
+            // the entries of one slot span few hypotheses (the table is hypothesis-major): fetch only those
+            const int last = min(total, first + 64) - 1;
+            int j_lo = 0, j_hi = 0;
+#pragma unroll
+            for (int j = 1; j < 5; ++j) {
+                j_lo += off[j] <= first ? 1 : 0;
+                j_hi += off[j] <= last ? 1 : 0;
+            }
+            float4 pl = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
+#pragma unroll 1
+            for (int j = j_lo; j <= j_hi; ++j) {
+                const int k = (0x20431 >> (4 * j)) & 7;  // kOrder[j]
+                const float nx = __shfl(ref_normals[k].x, owner), ny = __shfl(ref_normals[k].y, owner), nz = __shfl(ref_normals[k].z, owner);
+                const float nw = __shfl(ref_w[k], owner);
+                if (hyp == k) {
+                    pl = make_float4(nx, ny, nz, nw);
+                }
+            }
+            RefPatchLds<kLdsPitch> orp;
+            orp.mean = __shfl(rp.mean, owner);
+            orp.var = __shfl(rp.var, owner);
+            const int oly = wave_ly0 + owner / kWaveLanesX;
+            const int olx = wave_lx0 + 2 * (owner % kWaveLanesX) + ((oly + colour) & 1);
+            orp.base = &tile[oly * kLdsPitch + olx];
+            if (valid) {
+                float qx, qy, qz;
+                plane_q(pl, qx, qy, qz);
+                costs_out[hyp][owner] = ncc_fixed_windowed<kQuad, kWinW, kTiled, kApprox>(fa, vc, w, orp, t.tx0 + olx, t.ty0 + oly, qx, qy, qz);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if ((open >> k) & 1u) {
+                tc[k] += (float)wv * costs_out[k][lane];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the table and the costs are rewritten for the next view
+        __builtin_amdgcn_wave_barrier();
+    }
+#else
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
         const uint32_t wv = alive ? vw.get(v) : 0u;
@@ -331,6 +434,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
             }
         }
     }
+#endif
 
     if (!alive) {
         return;

@@ -26,6 +26,12 @@ for it in range(iters):
     lane = max(s[0] + s[1] + s[2], 1)
     print("iter %d: lane-NCCs %.3g  window %.1f%%  global fast %.1f%%  global slow %.2f%% | wave-NCCs %.3g, mixed %.1f%% | windows staged %d"
           % (it, lane, 100.0 * s[0] / lane, 100.0 * s[1] / lane, 100.0 * s[2] / lane, s[3], 100.0 * s[4] / max(s[3], 1), s[5]))
+    # lane utilisation: NCCs the lanes need against 64 x the NCCs the waves execute; phase A (9 hypotheses x N views) runs with full
+    # waves, so what is left is the refinement (5 hypotheses x selected views, early-outs per lane, one wave-level NCC if ANY lane needs it)
+    pixels = W * H  # two launches per iteration, each over half the pixels
+    per_px, per_wave = lane / pixels, s[3] * 64.0 / pixels
+    print("        per pixel: %.1f NCCs needed, %.1f executed by its wave (utilisation %.3f); beyond the 9 x %d of phase A: %.1f needed, %.1f executed (%.3f)"
+          % (per_px, per_wave, per_px / per_wave, N, per_px - 9 * N, per_wave - 9 * N, (per_px - 9 * N) / max(per_wave - 9 * N, 1e-9)))
 
 # post-loop kernels of the same pass: K11..K13, then K14 and K15 with their own counters
 for k in (pkg.K11, pkg.K12, pkg.K13):
