@@ -10,6 +10,21 @@
 
 namespace apd {
 
+#ifdef APD_LAB_WIN_STATS  // diagnostic build only (tools/weak_stats.py): lane-level against wave-level work of K9/K10
+// [0] lane NCCNew of the propagation phase, [1] wave-level ones, [2] / [3] the same for hypotheses 9..14, [4] lane sub-patches, [5] wave sub-patches
+static __device__ unsigned long long g_weak_stats[8];
+#define APD_WEAK_COUNT(i, n) atomicAdd(&g_weak_stats[i], (unsigned long long)(n))
+#define APD_WEAK_COUNT_WAVE(i)                                                                     \
+    do {                                                                                           \
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {       \
+            APD_WEAK_COUNT(i, 1);                                                                  \
+        }                                                                                          \
+    } while (0)
+#else
+#define APD_WEAK_COUNT(i, n) ((void)0)
+#define APD_WEAK_COUNT_WAVE(i) ((void)0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // K2  FindNearestStrongPoint (APD.cu:2234-2270)
 // ------------------------------------------------------------------------------------------------
@@ -596,6 +611,8 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
             continue;
         }
         float c;
+        APD_WEAK_COUNT(4, 1);
+        APD_WEAK_COUNT_WAVE(5);
         // one nine-sample body per wave and sub-patch: the IEEE division gives the bits of the fast reciprocal wherever that
         // one is valid, so if one lane needs it (a sign change or an extreme denominator under a random normal) all take it
         const bool fast = denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep));
@@ -749,10 +766,17 @@ __device__ __forceinline__ float4 candidate_plane(const FrameArgs &fa, const sho
 #ifndef APD_K910_WAVES
 #define APD_K910_WAVES 2
 #endif
+#ifndef APD_K910_COMPACT_REFINE
+#define APD_K910_COMPACT_REFINE 1
+#endif
 template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, int count, int per_xcd)
 {
     __shared__ WeakLdsT<kQuad> lds;
+    // texel-quad mode: hypotheses 9..14 walk a compacted table of open (lane, hypothesis) pairs (see below)
+    constexpr bool kCompact = kQuad && APD_K910_COMPACT_REFINE != 0;
+    __shared__ uint16_t refine_items[kCompact ? 5 * 64 : 1];
+    __shared__ float refine_cost[kCompact ? 5 : 1][64];
     const int lane = threadIdx.x;
     const int gid = weak_chunk_of_block(blockIdx.x, per_xcd) * 64 + lane;
     if (gid >= count) {
@@ -818,12 +842,19 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                 const int packed = lds.nb[h][lane];
                 pl = fa.planes[(int)(short)(packed & 0xFFFF) + (packed >> 16) * W];
             }
+            APD_WEAK_COUNT(0, 1);
+            APD_WEAK_COUNT_WAVE(1);
             cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
         }
     }
 
 #pragma unroll 1
     for (int h = 9; h < 16; ++h) {
+        if constexpr (kCompact) {
+            if (h >= 10 && h <= 14) {
+                continue;  // scored by the compacted stages at h == 9
+            }
+        }
         float4 pl;
         if (h == 9) {
             // ---- joint view selection (:1365-1434), adopt (:1436-1485) ----
@@ -912,6 +943,156 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             pl = ref_normals[h - 10];
             pl.w = distance_to_origin(fa, px, py, ref_depths[h - 10], pl.x, pl.y, pl.z);
         }
+        if constexpr (kCompact) {
+            if (h == 9) {
+                // Hypotheses 9..14 in two stages -- the fit plane, then the five random refinements around whatever it left
+                // (:910-980) -- each evaluated view by view over a compacted table: which (lane, hypothesis) pairs are still
+                // open differs from lane to lane (unselected views, pixels without a fit plane, partial sums that have
+                // already lost), and a wave runs an NCC whenever ANY lane needs it: 33.7 needed against 56.5 executed per
+                // WEAK pixel (tools/weak_stats.py).  Every open pair of a view is entered into a per-wave table, the wave walks
+                // it one entry per lane, and the lane that gets (owner, hypothesis) scores it from the owner's position with
+                // the owner's neighbour data (LDS columns) and hypothesis (ds_bpermute) and leaves the cost in LDS; the owner
+                // adds it to its sum in view order, as before.  All five refinements are bounded by the cost the stage
+                // starts from (the hypothesis-major loop tightened the bound after every accepted one: a superset of the
+                // NCCs, identical sums for every hypothesis that can still win, identical decisions).
+                const unsigned long long live = __builtin_amdgcn_ballot_w64(true);
+                const int wid = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
+                const int nworkers = __builtin_popcountll(live);
+                float4 hyp_n[5];
+                float hyp_w[5], tcs[5];
+#pragma unroll 1
+                for (int stage = 0; stage < 2; ++stage) {
+                    const int nh = stage == 0 ? 1 : 5;
+                    if (stage == 0) {
+                        hyp_n[0] = pl;
+                        hyp_w[0] = pl.w;
+                    } else if (!skip_refine) {
+                        make_refinement_set(fa, px, py, rng, plane_now, depth_now, ref_depths, ref_normals);
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            hyp_n[k] = ref_normals[k];
+                            hyp_w[k] = distance_to_origin(fa, px, py, ref_depths[k], ref_normals[k].x, ref_normals[k].y, ref_normals[k].z);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        tcs[k] = 0.0f;
+                    }
+                    const float lost = !(fa.geom_factor < 0.0f) ? refinement_lost_bound(fa, cost_now, weight_norm) : __builtin_inff();
+#pragma unroll 1
+                    for (int v = 0; v < nsrc; ++v) {
+                        const uint32_t wv = skip_refine ? 0u : vw.get(v);
+                        unsigned open = 0;
+                        if (wv > 0) {
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) {
+                                open |= (k < nh && !(tcs[k] >= lost)) ? (1u << k) : 0u;
+                            }
+                        }
+                        int off[6];
+                        off[0] = 0;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64((open >> k) & 1u);
+                            if ((open >> k) & 1u) {
+                                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                refine_items[off[k] + rank] = (uint16_t)((k << 6) | lane);
+                            }
+                            off[k + 1] = off[k] + __builtin_popcountll(m);
+                        }
+                        const int total = off[5];
+                        if (total == 0) {
+                            continue;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const ViewConst &vc = view_const(fa, v);
+#ifdef APD_LAB_K910_IDENTITY  // diagnostic: every lane scores its own pairs, one hypothesis per slot (no cross-lane motion)
+                        const int slot_step = 1, slot_end = 5;
+#else
+                        const int slot_step = nworkers, slot_end = total;
+#endif
+#pragma unroll 1
+                        for (int first = 0; first < slot_end; first += slot_step) {
+#ifdef APD_LAB_K910_IDENTITY
+                            const bool valid = ((open >> first) & 1u) != 0;
+                            const unsigned item = (unsigned)((first << 6) | lane);
+                            const int owner = (int)(item & 63u), hyp = (int)(item >> 6);
+                            const int last = first;
+                            if (__builtin_amdgcn_ballot_w64(valid) == 0) {
+                                continue;
+                            }
+#else
+                            const int idx = first + wid;
+                            const bool valid = idx < total;
+                            const unsigned item = valid ? (unsigned)refine_items[idx] : (unsigned)lane;
+                            const int owner = (int)(item & 63u), hyp = (int)(item >> 6);
+                            const int last = min(total, first + nworkers) - 1;
+#endif
+                            int k_lo = 0, k_hi = 0;
+#ifdef APD_LAB_K910_IDENTITY
+                            k_lo = k_hi = first;
+                            (void)last;
+#else
+#pragma unroll
+                            for (int k = 1; k < 5; ++k) {
+                                k_lo += off[k] <= first ? 1 : 0;
+                                k_hi += off[k] <= last ? 1 : 0;
+                            }
+#endif
+                            float4 hp = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
+#pragma unroll 1
+                            for (int k = k_lo; k <= k_hi; ++k) {
+                                const float nx = __shfl(hyp_n[k].x, owner), ny = __shfl(hyp_n[k].y, owner), nz = __shfl(hyp_n[k].z, owner);
+                                const float nw = __shfl(hyp_w[k], owner);
+                                if (hyp == k) {
+                                    hp = make_float4(nx, ny, nz, nw);
+                                }
+                            }
+                            RefPatchBytes orp;
+                            orp.base = &lds.centre[0][owner];
+                            orp.mean = __shfl(rp.mean, owner);
+                            orp.var = __shfl(rp.var, owner);
+                            const int opx = __shfl(px, owner), opy = __shfl(py, owner);
+                            if (valid) {
+                                APD_WEAK_COUNT(2, 1);
+                                APD_WEAK_COUNT_WAVE(3);
+                                float c = ncc_deformed<kQuad>(fa, vc, v, orp, lds, owner, opx, opy, hp);
+                                if (fa.geom_consistency) {
+                                    c = c + fa.geom_factor * geom_cost(fa, vc, opx, opy, hp);
+                                }
+                                refine_cost[hyp][owner] = c;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            if ((open >> k) & 1u) {
+                                tcs[k] += (float)wv * refine_cost[k][lane];
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (!skip_refine) {
+#pragma unroll 1
+                        for (int k = 0; k < nh; ++k) {  // accept tests in the reference's order (:932, :974)
+                            float4 hp = hyp_n[k];
+                            hp.w = hyp_w[k];
+                            const float c = tcs[k] / weight_norm;
+                            const float d = depth_from_plane(fa, hp, px, py);
+                            if (d >= fa.depth_min && d <= fa.depth_max && c < cost_now) {
+                                depth_now = d;
+                                plane_now = hp;
+                                cost_now = c;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
+        }
         if (h <= 14 && skip_refine) {
             continue;
         }
@@ -936,6 +1117,8 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                 plane_q(pl, qx, qy, qz);
                 tc += (float)vw.get(v) * ncc_fixed<kQuad>(fa, vc, rp, px, py, qx, qy, qz);
             } else {
+                APD_WEAK_COUNT(2, 1);
+                APD_WEAK_COUNT_WAVE(3);
                 const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
                 {
                     if (fa.geom_consistency) {
@@ -1204,3 +1387,17 @@ hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipS
 }
 
 }  // namespace apd
+
+
+#ifdef APD_LAB_WIN_STATS
+extern "C" int apd_debug_weak_stats(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(apd::g_weak_stats), sizeof(apd::g_weak_stats));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(apd::g_weak_stats), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
