@@ -33,6 +33,12 @@ static_assert(kFwWinPitch >= kWinW && kFwWinPitch <= 127, "window pitch: at leas
 #define APD_K14_WIN_H_F32 32
 #endif
 template <bool kQuad> constexpr int k14_win_h() { return kQuad ? APD_K14_WIN_H : APD_K14_WIN_H_F32; }
+#ifndef APD_K14_COMPACT
+#define APD_K14_COMPACT 1  // K14 may walk the (sample, lane) pairs of a chunk 64 at a time instead of one sample per wave-level NCC (0: never)
+#endif
+#ifndef APD_K14_PAIRS_FROM_N
+#define APD_K14_PAIRS_FROM_N 10  // ... in launches with at least this many source views
+#endif
 #ifndef APD_K14_CHUNK
 #define APD_K14_CHUNK 8  // depth samples per staged window (K14 ms at 4096x3072, 8 views: 4: 144.7, 6: 138.8, 8: 135.6, 16: 140.6, 31: 161.1)
 #endif
@@ -125,7 +131,12 @@ __device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewCon
 #define APD_K1415W_WAVES_F32 3  // float windows (single-texel entries, 9.5 KB per wave like the 8-bit ones); ms at 2048x1536, 8 views, K14 / K15:
                                 // 2 waves/SIMD 41.6 / 3.77, 3 waves 34.5 / 3.18, 4 waves 36.5 / 3.87 (8-byte pair entries, 2 waves: 40.4 / 3.80)
 #endif
-template <bool kQuad>
+// kPairs: the kernel may walk the (sample, lane) pairs of a chunk instead of its samples (see the chunk loop).  Carrying that
+// second loop costs the sample loop registers (4096x3072, 8 sources: 119.6 -> 124.0 ms; float images 34.5 -> 40.1 at 2048x1536),
+// so the launcher picks it where views are selected sparsely enough for it to pay: from ten sources on (15 draws over N views;
+// K14 ms at 2048x1536, photometric / geometric pass: N = 10 38.0 / 47.4 -> 38.4 / 44.3, N = 12 46.3 / 58.3 -> 44.3 / 51.2,
+// N = 16 61.6 / 76.6 -> 51.9 / 59.8).
+template <bool kQuad, bool kPairs>
 __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32) void k14w_depth_to_weak(FrameArgs fa)
 {
     __shared__ float tile[kFwLds * kFwPitch];
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
     fw_pixel(px, py);
     const RefPatchLds<kFwPitch> rp = fw_stage_ref(fa, tile, px, py);
     uint32_t *win = windows[threadIdx.x >> 6];
+    const int wave_id = threadIdx.x >> 6;
     const int W = fa.W, H = fa.H;
     const int min_margin = 6;
     const int center = px + py * W;
@@ -227,33 +239,126 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                 }
                 const int mid = (c0 + c1) >> 1;
                 const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use && ((in_range >> mid) & 1ull) != 0, px, py, origin, pw[mid]);
-                // pw[] and pc[] are indexed dynamically and live in scratch memory: the two reads of sample i + 1 are issued
-                // before sample i is scored instead of stalling its start and its end
+                // A lane scores a view only if its pixel selected it (6.5 of 8 views on the synthetic 8-source scenes, 8.8 of 16 on the
+                // 16-source one, fewer on real ones), and a wave runs an NCC for a depth sample if ANY lane does.  When every lane of
+                // the view has every sample of the chunk (the regular case: all in [depth_min, depth_max]) the n x U (sample, lane)
+                // pairs of the chunk can be walked 64 at a time, sample-major: pair idx is sample idx / U of the lane of rank idx % U
+                // (rank -> lane through one ds_permute), its worker fetches that lane's ray, plane distance and reference
+                // moments through ds_bpermute, scores the pair from the owner's pixel position against the same window and
+                // reference tile (both belong to the wave), and the owner pulls the cost back with another ds_bpermute and
+                // adds it to pc[] in view order as before: ceil(n U / 64) wave-level NCCs per chunk instead of n, same
+                // operands, same bits.  A slot of pairs costs about a tenth more than a slot of one sample (the fetches, the
+                // pull, the arrays of the chunk), so this path is taken when it saves two slots of the chunk, or one when every
+                // NCC also pays the geometric term.  K14 ms at 2048x1536, photometric / geometric pass: 16 sources (U = 35 of 64)
+                // 61.6 / 76.6 -> 51.9 / 59.8; with 8 sources (U = 52) a chunk saves one slot at best and stays on the sample loop.
+                const int n = c1 - c0;
+                const unsigned long long um = __builtin_amdgcn_ballot_w64(use);
+                const int U = __builtin_popcountll(um);
+                const unsigned chunk_bits = (unsigned)((in_range >> c0) & ((1ull << n) - 1ull));
+                bool regular = false;
+                if constexpr (kPairs) {
+                    regular = ((n * U + 63) >> 6) + (fa.geom_consistency ? 1 : 2) <= n &&
+                              __builtin_amdgcn_ballot_w64(use && chunk_bits != ((1u << n) - 1u)) == 0;
+                }
+                if (kPairs && regular) {
+                    const int lane_id = threadIdx.x & 63;
+                    const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                    int rank_to_lane;
+                    {  // a full permutation: owners take ranks 0..U-1, the other lanes U..63
+                        const unsigned long long nm = ~um;
+                        const int other_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
+                        const int target = use ? my_rank : U + other_rank;
+                        rank_to_lane = __builtin_amdgcn_ds_permute(target << 2, lane_id);
+                    }
+                    float pwc[APD_K14_CHUNK], tcj[APD_K14_CHUNK];
+#pragma unroll
+                    for (int j = 0; j < APD_K14_CHUNK; ++j) {
+                        pwc[j] = (j < n) ? pw[c0 + j] : 1.0f;
+                        tcj[j] = 0.0f;
+                    }
+                    const int total = n * U;
+#pragma unroll 1
+                    for (int first = 0; first < total; first += 64) {
+                        const int idx = first + lane_id;
+                        const bool valid = idx < total;
+                        int j = 0;
+#pragma unroll
+                        for (int k = 1; k < APD_K14_CHUNK; ++k) {
+                            j += (k < n && k * U <= idx) ? 1 : 0;
+                        }
+                        const int owner = __shfl(rank_to_lane, valid ? idx - j * U : 0);
+                        const int j_lo = first / U, j_hi = (min(total, first + 64) - 1) / U;
+                        float w_item = 1.0f;
+#pragma unroll 1
+                        for (int jj = j_lo; jj <= j_hi; ++jj) {
+                            const float v_ = __shfl(pwc[jj], owner);
+                            if (j == jj) {
+                                w_item = v_;
+                            }
+                        }
+                        const float4 pl = make_float4(__shfl(origin.x, owner), __shfl(origin.y, owner), __shfl(origin.z, owner), w_item);
+                        RefPatchLds<kFwPitch> orp;
+                        orp.mean = __shfl(rp.mean, owner);
+                        orp.var = __shfl(rp.var, owner);
+                        const int olx = (wave_id & 1) * 8 + (owner & 7), oly = (wave_id >> 1) * 8 + (owner >> 3);
+                        orp.base = &tile[oly * kFwPitch + olx];
+                        const int opx = blockIdx.x * kFwTile + olx, opy = blockIdx.y * kFwTile + oly;
+                        float tc = 0.0f;
+                        if (valid) {
+                            float qx, qy, qz;
+                            plane_q(pl, qx, qy, qz);
+                            tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, orp, opx, opy, qx, qy, qz);
+                            if (fa.geom_consistency) {
+                                tc += fa.geom_factor * geom_cost(fa, vc, opx, opy, pl);
+                            }
+                        }
+                        // owners collect: pair (jj, my_rank) sits in slot (jj U + my_rank) / 64 at lane (jj U + my_rank) % 64
+#pragma unroll 1
+                        for (int jj = j_lo; jj <= j_hi; ++jj) {
+                            const int at = jj * U + my_rank;
+                            const float c = __shfl(tc, at & 63);
+                            if (use && (at >> 6) == (first >> 6)) {
+                                tcj[jj] = c;
+                            }
+                        }
+                    }
+                    if (use) {
+#pragma unroll
+                        for (int j = 0; j < APD_K14_CHUNK; ++j) {
+                            if (j < n) {
+                                pc[c0 + j] += tcj[j] * wv;
+                            }
+                        }
+                    }
+                } else {
+                    // pw[] and pc[] are indexed dynamically and live in scratch memory: the two reads of sample i + 1 are issued
+                    // before sample i is scored instead of stalling its start and its end
 #ifndef APD_K14_PREFETCH
 #define APD_K14_PREFETCH 1
 #endif
-                float pw_next = pw[c0], pc_next = pc[c0];
+                    float pw_next = pw[c0], pc_next = pc[c0];
 #pragma unroll 1
-                for (int i = c0; i < c1; ++i) {
-                    const float pw_i = APD_K14_PREFETCH ? pw_next : pw[i], pc_i = APD_K14_PREFETCH ? pc_next : 0.0f;
-                    if (APD_K14_PREFETCH && i + 1 < c1) {
-                        pw_next = pw[i + 1];
-                        pc_next = pc[i + 1];
-                    }
-                    if (use && ((in_range >> i) & 1ull)) {
-                        float4 pl = origin;
-                        pl.w = pw_i;
-                        float qx, qy, qz;
-                        plane_q(pl, qx, qy, qz);
-                        float tc = 0.0f;
-                        tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
-                        if (fa.geom_consistency) {
-                            tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
+                    for (int i = c0; i < c1; ++i) {
+                        const float pw_i = APD_K14_PREFETCH ? pw_next : pw[i], pc_i = APD_K14_PREFETCH ? pc_next : 0.0f;
+                        if (APD_K14_PREFETCH && i + 1 < c1) {
+                            pw_next = pw[i + 1];
+                            pc_next = pc[i + 1];
                         }
-                        if (APD_K14_PREFETCH) {
-                            pc[i] = pc_i + tc * wv;
-                        } else {
-                            pc[i] += tc * wv;
+                        if (use && ((in_range >> i) & 1ull)) {
+                            float4 pl = origin;
+                            pl.w = pw_i;
+                            float qx, qy, qz;
+                            plane_q(pl, qx, qy, qz);
+                            float tc = 0.0f;
+                            tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
+                            if (fa.geom_consistency) {
+                                tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
+                            }
+                            if (APD_K14_PREFETCH) {
+                                pc[i] = pc_i + tc * wv;
+                            } else {
+                                pc[i] += tc * wv;
+                            }
                         }
                     }
                 }
@@ -481,10 +586,17 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
 hipError_t launch_k14_windowed(const FrameArgs &fa, hipStream_t s)
 {
     const dim3 grid((fa.W + kFwTile - 1) / kFwTile, (fa.H + kFwTile - 1) / kFwTile);
+    const bool pairs = APD_K14_COMPACT && fa.num_src >= APD_K14_PAIRS_FROM_N;
     if (fa.use_quads) {
-        hipLaunchKernelGGL(k14w_depth_to_weak<true>, grid, dim3(256), 0, s, fa);
+        if (pairs) {
+            hipLaunchKernelGGL((k14w_depth_to_weak<true, true>), grid, dim3(256), 0, s, fa);
+        } else {
+            hipLaunchKernelGGL((k14w_depth_to_weak<true, false>), grid, dim3(256), 0, s, fa);
+        }
+    } else if (pairs) {
+        hipLaunchKernelGGL((k14w_depth_to_weak<false, true>), grid, dim3(256), 0, s, fa);
     } else {
-        hipLaunchKernelGGL(k14w_depth_to_weak<false>, grid, dim3(256), 0, s, fa);
+        hipLaunchKernelGGL((k14w_depth_to_weak<false, false>), grid, dim3(256), 0, s, fa);
     }
     return hipGetLastError();
 }

@@ -17,6 +17,8 @@ def run_case(case):
     rng = np.random.RandomState(1000 + case)
     W, H = int(rng.randint(36, 260)), int(rng.randint(30, 180))
     N = int(rng.randint(1, 10))
+    if rng.rand() < 0.25:  # ten and more sources: other kernel instantiations (NMAX = 12 / 16 / 32, K14 walking (sample, lane) pairs)
+        N = int(rng.randint(10, 19))
     tl = float(rng.choice([0.0, 0.15, 0.3]))
     iters = int(rng.randint(1, 4))
     float_images = bool(rng.rand() < 0.35)
