@@ -125,9 +125,6 @@ constexpr float kTrustedCost = APD_WIN_TRUST;
 #ifndef APD_K67W_WAVES
 #define APD_K67W_WAVES 4
 #endif
-#ifndef APD_K67_COMPACT_REFINE
-#define APD_K67_COMPACT_REFINE 1  // the refinement phase walks a compacted table of open (lane, hypothesis) pairs; 0: one NCC per hypothesis any lane has open
-#endif
 #ifndef APD_K67W_WAVES_F32
 #define APD_K67W_WAVES_F32 3  // float windows: three waves per SIMD also with the single-texel entries (4 waves, 128 VGPRs: 32.4 against 29.1 ms
                               // for the first iteration at 2048x1536, 16.0 against 14.6 later)
@@ -139,10 +136,8 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 {
     __shared__ float tile[kLdsH * kLdsPitch];
     __shared__ uint32_t windows[4][window_dwords(kQuad, kWinH)];
-#if APD_K67_COMPACT_REFINE
-    __shared__ uint16_t refine_items[4][5 * 64];  // per wave: (hypothesis << 6) | owner lane of every open (lane, hypothesis), hypothesis-major
+    __shared__ uint16_t refine_items[4][5 * 64];  // per wave: (hypothesis << 6) | owner lane of every open (lane, hypothesis)
     __shared__ float refine_cost[4][5][64];       // per wave: the cost a worker lane computed for (hypothesis, owner lane)
-#endif
     const TilePixel t = checkerboard_pixel(fa, colour);
     // stage the reference tile + 5 px halo (clamp-to-edge, as the texture unit would)
     for (int idx = threadIdx.x; idx < kLdsW * kLdsH; idx += 256) {
@@ -309,7 +304,6 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
     // skipped and the accept test below rejects it exactly as it would reject the full sum.  In converged iterations
     // that removes most NCCs of the two random-depth hypotheses, which are also the ones that miss the windows.
     const float lost = refinement_lost_bound(fa, cost_now, weight_norm);
-#if APD_K67_COMPACT_REFINE
     // Which (lane, hypothesis) pairs are still open differs from lane to lane -- a view a pixel did not select, a hypothesis
     // that has already lost -- and a wave runs an NCC whenever ANY of its lanes needs it: in converged iterations the lanes
     // need 11 refinement NCCs per pixel and the waves execute 25 (tools/win_stats.py).  So the open pairs of a view are
@@ -404,37 +398,6 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the table and the costs are rewritten for the next view
         __builtin_amdgcn_wave_barrier();
     }
-#else
-#pragma unroll 1
-    for (int v = 0; v < nsrc; ++v) {
-        const uint32_t wv = alive ? vw.get(v) : 0u;
-        unsigned open = 0;  // hypotheses of this lane that can still win
-        if (wv > 0) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                open |= (tc[k] >= lost) ? 0u : (1u << k);
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(open != 0) == 0) {
-            continue;  // nobody in the wave has anything left to score in this view
-        }
-        const ViewConst &vc = view_const(fa, v);
-        const SrcWindow w = stage_window<kQuad>(fa, vc, win, alive, px, py, plane_now, trusted, use_windows);
-        if (open != 0) {
-#pragma unroll 1
-            for (int k = 0; k < 5; ++k) {
-                if (!(open & (1u << k))) {
-                    continue;
-                }
-                float4 pl = ref_normals[k];
-                pl.w = ref_w[k];
-                float qx, qy, qz;
-                plane_q(pl, qx, qy, qz);
-                tc[k] += (float)wv * ncc_fixed_windowed<kQuad, kWinW, kTiled, kApprox>(fa, vc, w, rp, px, py, qx, qy, qz);
-            }
-        }
-    }
-#endif
 
     if (!alive) {
         return;
