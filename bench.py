@@ -362,6 +362,14 @@ def main():
             hbm_b = wp["hbm_bytes_per_launch"]
             weak_roofline.update({"achieved": round(acc, 1), "frac": round(acc / tag_peak, 4), "traffic": hbm_b,
                                   "tag_accesses_per_launch": wp["tcp_tag_accesses_per_launch"],
+                                  # the pipeline's rate depends on where the lanes of a gather go: 1.85 per clock when they share
+                                  # lines, 0.95 when every lane reads its own line (tools/tcp_mix.hip, profiles/r03/tcp_mix.txt:
+                                  # 32 accesses in 33.6 clocks; tcp_patterns 3, 7, 30 agree); `frac` is against the former
+                                  "tag_rate": {"achieved_per_clock_and_cu": round(acc / (256 * MAX_CLOCK_GHZ), 3),
+                                               "peak_lanes_sharing_lines": TCP_ACCESSES_PER_CLOCK, "peak_lanes_on_distinct_lines": 0.95,
+                                               "note": "more resident waves do not shorten the launch (profiles/r03/ab_k910_split.txt: 8 to 16 "
+                                                       "workgroups per CU, same time); L1 misses served by the L2 hide behind the tag "
+                                                       "accesses up to one miss per ~2.5 accesses (tcp_mix: 2.4 clocks per 128-byte line)"},
                                   "hbm": {"achieved": round(hbm_b / (wms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                           "frac": round(hbm_b / (wms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": hbm_b,
                                           "note": "2 x FETCH_SIZE + WRITE_SIZE per launch"},
