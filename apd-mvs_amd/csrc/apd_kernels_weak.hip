@@ -3,6 +3,7 @@
 // K9/K10 Black/RedPixelUpdateWeak, plus the depth/normal export used before the RCCL all-gather.
 #include "apd_device.h"
 #include "apd_sweep.h"
+#include "apd_window.h"
 
 #include <float.h>
 
@@ -498,9 +499,50 @@ struct WeakLdsT {
     int nb[8][64];            // x | y << 16, -1 = empty slot
     // reference texels of the 3x3 sub-patches: texel-quad mode three per dword (bytes), else nine floats
     typename std::conditional<kQuad, uint32_t[8][kSubN][64], float[8][kSubN * kSubN][64]>::type ref;
-    float mean[8][64];
-    float var[8][64];
+    // Moments of the sub-patches.  Float images: mean and variance as computed by weak_prepare_neighbours.  Texel-quad mode: every
+    // texel is an integer 0..255, so the sub-patch's texel sum S (< 2^12) and sum of squares Q (< 2^20) are exact integers in
+    // binary32 and mean = S * (1/9), var = fma(-mean, mean, Q * (1/9)) are formed again from them, with the same bits, where they
+    // are used: Q rides in the unused top bytes of the three row dwords (byte 3 of row i = bits 8i .. 8i+7), S is the byte sum of
+    // the nine texels (v_sad_u8).  4 KB less LDS per workgroup, which the centre-patch window (below) gets.
+    float mean[kQuad ? 1 : 8][kQuad ? 1 : 64];
+    float var[kQuad ? 1 : 8][kQuad ? 1 : 64];
     uint32_t centre[kQuad ? kPatchN * kPatchN / 4 : 1][64];  // texel-quad mode: the pixel's own 36 reference texels as bytes
+
+    // sum_r, sum_rr: texel sum and sum of squares of sub-patch k before the division by nine
+    __device__ __forceinline__ void store_sub(int k, int lane, const uint32_t (&rows)[kSubN], float sum_r, float sum_rr)
+    {
+        if constexpr (kQuad) {
+            const uint32_t q = (uint32_t)sum_rr;
+#pragma unroll
+            for (int i = 0; i < kSubN; ++i) {
+                ref[k][i][lane] = rows[i] | (((q >> (8 * i)) & 0xFFu) << 24);
+            }
+        } else {
+            const float inv_w = 1.0f / 9.0f;
+            sum_r *= inv_w;
+            sum_rr *= inv_w;
+            mean[k][lane] = sum_r;
+            var[k][lane] = fmaf(-sum_r, sum_r, sum_rr);
+        }
+    }
+    __device__ __forceinline__ void load_sub(int k, int lane, uint32_t (&rows)[kSubN], float &mean_r, float &var_r) const
+    {
+        if constexpr (kQuad) {
+            uint32_t s = 0, q = 0;
+#pragma unroll
+            for (int i = 0; i < kSubN; ++i) {
+                rows[i] = ref[k][i][lane];
+                s = __builtin_amdgcn_sad_u8(rows[i] & 0x00FFFFFFu, 0u, s);
+                q |= (rows[i] >> 24) << (8 * i);
+            }
+            const float inv_w = 1.0f / 9.0f;
+            mean_r = (float)s * inv_w;
+            var_r = fmaf(-mean_r, mean_r, (float)q * inv_w);
+        } else {
+            mean_r = mean[k][lane];
+            var_r = var[k][lane];
+        }
+    }
 };
 typedef WeakLdsT<true> WeakLds;
 
@@ -543,38 +585,38 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
             continue;
         }
         float sum_r = 0.0f, sum_rr = 0.0f;
+        uint32_t rows[kSubN] = {0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < kSubN; ++i) {
             float row_r = 0.0f, row_rr = 0.0f;
-            uint32_t packed = 0;
 #pragma unroll
             for (int j = 0; j < kSubN; ++j) {
                 const float r = fetch_texel(fa.ref_img, W, H, q.x + kSubStep * (i - 1), q.y + kSubStep * (j - 1));
                 row_r += r;
                 row_rr = fmaf(r, r, row_rr);
                 if constexpr (kQuad) {
-                    packed |= (uint32_t)r << (8 * j);
+                    rows[i] |= (uint32_t)r << (8 * j);
                 } else {
                     lds.ref[k][i * kSubN + j][lane] = r;
                 }
             }
             sum_r += row_r;
             sum_rr += row_rr;
-            if constexpr (kQuad) {
-                lds.ref[k][i][lane] = packed;
-            }
         }
-        const float inv_w = 1.0f / 9.0f;
-        sum_r *= inv_w;
-        sum_rr *= inv_w;
-        lds.mean[k][lane] = sum_r;
-        lds.var[k][lane] = fmaf(-sum_r, sum_r, sum_rr);
+        lds.store_sub(k, lane, rows, sum_r, sum_rr);
     }
 }
 
+#ifndef APD_K910_WINDOW
+#define APD_K910_WINDOW 1  // 0: no centre-patch window (A/B runs)
+#endif
+#ifndef APD_K910_WIN_DIVERGENT
+#define APD_K910_WIN_DIVERGENT 1  // 0: a wave with lanes outside the window takes the global path whole (A/B runs)
+#endif
+// w: this wave's window of view v for the centre patch (texel-quad mode; valid = 0: none staged)
 template <bool kQuad, typename Ref>
 __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLdsT<kQuad> &lds,
-                                              int lane, int px, int py, const float4 pl)
+                                              int lane, int px, int py, const float4 pl, const SrcWindow &w)
 {
     float qx, qy, qz;
     plane_q(pl, qx, qy, qz);
@@ -584,8 +626,14 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
     if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
         return 2.0f;
     }
-    // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above)
-    const float center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+    // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above).  Lanes whose 36 samples fall
+    // inside the wave's window read LDS, the others gather: only the latter cost L1 tag accesses, which bound this kernel.
+    float center_cost;
+    if constexpr (kQuad) {
+        center_cost = ncc_fixed_windowed_from_h<true, kWinW, false, false, APD_K910_WIN_DIVERGENT != 0>(fa, vc, w, rp, H, px, py);
+    } else {
+        center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+    }
     const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
     const unsigned qpitch = quad_row_pitch_bytes(fa.W);
     const unsigned fpitch = 16u * (unsigned)(fa.W + 1);
@@ -616,21 +664,20 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
         // one nine-sample body per wave and sub-patch: the IEEE division gives the bits of the fast reciprocal wherever that
         // one is valid, so if one lane needs it (a sign change or an extreme denominator under a random normal) all take it
         const bool fast = denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep));
+        uint32_t ref_rows[kSubN] = {0u, 0u, 0u};
+        float mean_r, var_r;
+        lds.load_sub(k, lane, ref_rows, mean_r, var_r);
         if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
             if constexpr (kQuad) {
-                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-                c = subpatch_cost_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+                c = subpatch_cost_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, mean_r, var_r);
             } else {
-                c = subpatch_cost_fquad<kRecipExact>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
-                                                     lds.var[k][lane]);
+                c = subpatch_cost_fquad<kRecipExact>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, mean_r, var_r);
             }
         } else {
             if constexpr (kQuad) {
-                const uint32_t ref_rows[kSubN] = {lds.ref[k][0][lane], lds.ref[k][1][lane], lds.ref[k][2][lane]};
-                c = subpatch_cost_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, lds.mean[k][lane], lds.var[k][lane]);
+                c = subpatch_cost_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, mean_r, var_r);
             } else {
-                c = subpatch_cost_fquad<kRecipIeee>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, lds.mean[k][lane],
-                                                    lds.var[k][lane]);
+                c = subpatch_cost_fquad<kRecipIeee>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, mean_r, var_r);
             }
         }
         strong_cost += c;
@@ -761,6 +808,37 @@ __device__ __forceinline__ float4 candidate_plane(const FrameArgs &fa, const sho
     return fa.planes[q.x + q.y * fa.W];
 }
 
+// Rows of fetch positions of K9/K10's centre-patch window: a wave's pixels come from one or two 16 x 8 px tiles, the patch adds
+// five rows either side, the rest is slack for hypotheses that move the patch along a slanted epipolar line.  With the packed
+// sub-patch moments the workgroup's LDS stays below 20 KB, i.e. eight workgroups per CU: the kernel loses 17 % with seven
+// (profiles/r03/ab_k910_occupancy.txt).
+#ifndef APD_K910_WIN_H
+#define APD_K910_WIN_H 28
+#endif
+constexpr int kK910WinH = APD_K910_WIN_H;
+
+// Window of view vc around where the wave's pixels land under their current planes.  Every lane of the wave calls this.
+__device__ __forceinline__ SrcWindow weak_stage_window(const FrameArgs &fa, const ViewConst &vc, uint32_t *win, int px, int py, const float4 plane)
+{
+    float qx, qy, qz;
+    plane_q(plane, qx, qy, qz);
+    const Homography H = make_homography(fa, vc, qx, qy, qz);
+    float cx, cy;
+    correspond(H, (float)px, (float)py, cx, cy);
+    const bool ok = cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf;  // false for NaN
+    return stage_window_around<true, kK910WinH>(fa, vc, win, ok, cx, cy);
+}
+
+__device__ __forceinline__ SrcWindow no_window()
+{
+    SrcWindow none;
+    none.valid = 0;
+    none.wx0 = none.wy0 = none.addr0 = 0;
+    none.lo_x = none.lo_y = 3.0e38f;
+    none.hi_x = none.hi_y = -3.0e38f;
+    return none;
+}
+
 // Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
 // plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
 #ifndef APD_K910_WAVES
@@ -777,11 +855,22 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
     constexpr bool kCompact = kQuad && APD_K910_COMPACT_REFINE != 0;
     __shared__ uint16_t refine_items[kCompact ? 5 * 64 : 1];
     __shared__ float refine_cost[kCompact ? 5 : 1][64];
+#ifdef APD_LAB_K910_LDS_PAD  // A/B runs: extra LDS bytes per workgroup, i.e. fewer workgroups per CU
+    __shared__ uint32_t lab_pad[APD_LAB_K910_LDS_PAD / 4];
+    if (count < 0) {
+        lab_pad[threadIdx.x] = 0;  // never taken: keeps the array
+    }
+#endif
+    // the wave's window of the current source view for the centre patches (texel-quad mode)
+    __shared__ uint32_t centre_window[kQuad ? window_dwords(true, kK910WinH) : 1];
     const int lane = threadIdx.x;
-    const int gid = weak_chunk_of_block(blockIdx.x, per_xcd) * 64 + lane;
-    if (gid >= count) {
+    const int first = weak_chunk_of_block(blockIdx.x, per_xcd) * 64;
+    if (first >= count) {
         return;
     }
+    // The window staging and the compacted stages are wave-wide operations: the lanes past the end of the list (last chunk only)
+    // repeat its last pixel -- same inputs, same stores of the same values -- instead of leaving the wave.
+    const int gid = min(first + lane, count - 1);
     const int W = fa.W;
     const int center = list[gid];
     const int py = center / W, px = center - py * W;
@@ -832,6 +921,10 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
 #pragma unroll 1
     for (int v = 0; v < nsrc; ++v) {
         const ViewConst &vc = view_const(fa, v);
+        SrcWindow w = no_window();
+        if constexpr (kQuad && APD_K910_WINDOW != 0) {
+            w = weak_stage_window(fa, vc, centre_window, px, py, plane_now);
+        }
 #pragma unroll 1
         for (int h = 0; h < 9; ++h) {
             if (h < 8 && !(flags & (1u << h))) {
@@ -844,7 +937,11 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             }
             APD_WEAK_COUNT(0, 1);
             APD_WEAK_COUNT_WAVE(1);
-            cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
+            cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl, w);
+        }
+        if constexpr (kQuad) {  // the window is rewritten for the next view
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -1007,6 +1104,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const ViewConst &vc = view_const(fa, v);
+                        const SrcWindow w = APD_K910_WINDOW != 0 ? weak_stage_window(fa, vc, centre_window, px, py, plane_now) : no_window();
 #ifdef APD_LAB_K910_IDENTITY  // diagnostic: every lane scores its own pairs, one hypothesis per slot (no cross-lane motion)
                         const int slot_step = 1, slot_end = 5;
 #else
@@ -1057,7 +1155,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                             if (valid) {
                                 APD_WEAK_COUNT(2, 1);
                                 APD_WEAK_COUNT_WAVE(3);
-                                float c = ncc_deformed<kQuad>(fa, vc, v, orp, lds, owner, opx, opy, hp);
+                                float c = ncc_deformed<kQuad>(fa, vc, v, orp, lds, owner, opx, opy, hp, w);
                                 if (fa.geom_consistency) {
                                     c = c + fa.geom_factor * geom_cost(fa, vc, opx, opy, hp);
                                 }
@@ -1119,7 +1217,7 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
             } else {
                 APD_WEAK_COUNT(2, 1);
                 APD_WEAK_COUNT_WAVE(3);
-                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl);
+                const float c = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl, no_window());
                 {
                     if (fa.geom_consistency) {
                         tc += (float)vw.get(v) * (c + fa.geom_factor * geom_cost(fa, vc, px, py, pl));
@@ -1400,4 +1498,5 @@ extern "C" int apd_debug_weak_stats(unsigned long long *out, int reset)
     }
     return (int)e;
 }
+APD_WIN_STATS_ACCESSOR(apd_debug_win_stats_weak)
 #endif

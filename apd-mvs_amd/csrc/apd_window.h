@@ -552,5 +552,82 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
     return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
 }
 
+// The same cost for an already projected centre (the caller has done the bounds test of APD.cu:546): K9/K10's centre patch.
+// (A function of its own rather than the tail of ncc_fixed_windowed: routing K6/K7 through it changes that kernel's block layout and
+// spills -- 512 -> 592 B of scratch per lane in one arrangement -- and K6/K7 is the headline kernel.)
+// kApprox: tolerance mode (bare v_rcp_f32 everywhere, no IEEE body); see quad_row_issue
+// kDivergent: lanes inside and lanes outside the window each take their own 36-sample body (a mixed wave runs both in turn).  The
+//   default is one body per wave and NCC -- right for the kernels the vector ALU bounds (K6/K7, K14, K15); K9/K10 is bound by the
+//   L1's tag accesses, which only the lanes on the global path make.
+template <bool kQuad, int kPitch = kWinW, bool kTiled = false, bool kApprox = false, bool kDivergent = false, typename Ref>
+__device__ __forceinline__ float ncc_fixed_windowed_from_h(const FrameArgs &fa, const ViewConst &vc, const SrcWindow &w, const Ref &rp,
+                                                           const Homography &H, int px, int py)
+{
+    const float kMinVar = 1e-5f;
+    if (rp.var < kMinVar) {
+        return 2.0f;
+    }
+    const float x0 = (float)(px - kPatchRadius), x1 = (float)(px + kPatchRadius);
+    const float y0 = (float)(py - kPatchRadius), y1 = (float)(py + kPatchRadius);
+    // tolerance mode: every denominator goes through v_rcp_f32; the corner test below still needs one sign
+    const bool fast_recip = denominators_fast(H, x0, x1, y0, y1);
+    bool in_window = false;
+    float cX[4], cY[4];  // only read when in_window, i.e. after the block below has written them
+    if (fast_recip && w.valid) {
+        // x/z and y/z are monotone along every row and every column of the sample grid while z keeps its sign, so the
+        // four corner samples bound all 36
+        corner_position<kApprox>(H, x0, y0, cX[0], cY[0]);
+        corner_position<kApprox>(H, x0, y1, cX[1], cY[1]);
+        corner_position<kApprox>(H, x1, y0, cX[2], cY[2]);
+        corner_position<kApprox>(H, x1, y1, cX[3], cY[3]);
+        const float xl = fminf(fminf(cX[0], cX[1]), fminf(cX[2], cX[3])), xh = fmaxf(fmaxf(cX[0], cX[1]), fmaxf(cX[2], cX[3]));
+        const float yl = fminf(fminf(cY[0], cY[1]), fminf(cY[2], cY[3])), yh = fmaxf(fmaxf(cY[0], cY[1]), fmaxf(cY[2], cY[3]));
+        in_window = xl >= w.lo_x && xh < w.hi_x && yl >= w.lo_y && yh < w.hi_y;
+    }
+#ifdef APD_LAB_WIN_STATS
+    {
+        const unsigned long long m_all = __builtin_amdgcn_ballot_w64(true), m_in = __builtin_amdgcn_ballot_w64(in_window);
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_all)) {
+            APD_WIN_COUNT(3, 1);
+            APD_WIN_COUNT(4, (m_in != 0 && m_in != m_all) ? 1 : 0);
+        }
+        APD_WIN_COUNT(in_window ? 0 : (fast_recip ? 1 : 2), 1);
+    }
+#endif
+#ifndef APD_WIN_DIVERGENT
+    if constexpr (!kDivergent) {
+        // one path per wave and NCC: lanes inside and outside the window would otherwise run both 36-sample bodies in turn
+        in_window = in_window && __builtin_amdgcn_ballot_w64(!in_window) == 0;
+    }
+#endif
+#ifndef APD_RECIP_DIVERGENT
+    // the same for the two global bodies: if one lane needs the IEEE division, every lane of the wave takes it (same bits)
+    const bool fast_body = __builtin_amdgcn_ballot_w64(!fast_recip) == 0;
+#else
+    const bool fast_body = fast_recip;
+#endif
+    float sum_s, sum_ss, sum_rs;
+    if (in_window) {
+        ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs, cX, cY);
+    } else if constexpr (kApprox) {
+        ncc_fixed_moments<kQuad, kRecipApprox, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+    } else if (__builtin_expect(fast_body, 1)) {
+        ncc_fixed_moments<kQuad, kRecipExact, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+    } else {
+        ncc_fixed_moments<kQuad, kRecipIeee, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+    }
+    const float inv_w = 1.0f / 36.0f;
+    sum_s *= inv_w;
+    sum_ss *= inv_w;
+    sum_rs *= inv_w;
+    const float var_s = fmaf(-sum_s, sum_s, sum_ss);
+    if (var_s < kMinVar) {
+        return 2.0f;
+    }
+    const float covar = fmaf(-rp.mean, sum_s, sum_rs);
+    const float denom = sqrtf(rp.var * var_s);
+    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+}
+
 }  // namespace apd
 

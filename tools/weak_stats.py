@@ -28,7 +28,9 @@ for k in (pkg.K1, pkg.K2, pkg.K3, pkg.K4, pkg.K5):
     h.run_kernel(k)
 L = pkg.lib()
 out = (C.c_ulonglong * 8)()
+win = (C.c_ulonglong * 8)()
 L.apd_debug_weak_stats(out, 1)
+L.apd_debug_win_stats_weak(win, 1)
 weak_px = h.weak_count
 for it in range(iters):
     h.run_sweeps(it, 1)
@@ -38,3 +40,8 @@ for it in range(iters):
           "hypotheses 9..14: %.1f needed, %.1f executed (%.3f); sub-patches %.1f needed, %.1f executed (%.3f)"
           % (it, weak_px, 100.0 * weak_px / (W * H), s[0] / weak_px, s[1] * 64 / weak_px, s[0] / max(s[1] * 64, 1), s[2] / weak_px,
              s[3] * 64 / weak_px, s[2] / max(s[3] * 64, 1), s[4] / weak_px, s[5] * 64 / weak_px, s[4] / max(s[5] * 64, 1)))
+    L.apd_debug_win_stats_weak(win, 1)
+    w = [float(v) for v in win]
+    lanes = max(w[0] + w[1] + w[2], 1.0)
+    print("        centre patches: %.1f %% of the lane-level NCCs through the window, %.1f %% global (wave-level: %.1f %% of the calls have lanes on "
+          "both paths); windows staged %d" % (100.0 * w[0] / lanes, 100.0 * (w[1] + w[2]) / lanes, 100.0 * w[4] / max(w[3], 1.0), int(w[5])))
