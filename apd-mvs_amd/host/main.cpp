@@ -1,11 +1,12 @@
 // main.cpp -- drop-in driver of the PatchMatch path.
 //
 //   APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]
-//       [--jacobi] [--no-rccl] [--rccl]
+//       [--jacobi] [--ranks N] [--no-rccl] [--rccl]
 //
 // One device index: the reference's driver.  A device LIST (or --jacobi): host/multi_device.cpp -- views sharded over the
 // devices, state resident on them, depth maps all-gathered after every pass (RCCL when there is more than one rank -- its set-up takes seconds
-// -- direct copies for a single rank; --rccl: RCCL even then; --no-rccl: direct copies only).
+// -- direct copies for a single rank; --rccl: RCCL even then; --no-rccl: direct copies only).  With --jacobi a single device runs
+// one to three scheduler ranks, by frame size (--ranks N: exactly N).
 //
 // Same command line, files and results as the reference driver (main.cpp:140-233), organised differently:
 //   * pair.txt is read as one token stream with diagnostics (the reference never notices a missing or short file,
@@ -62,6 +63,9 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.no_fusion = true;
         } else if (a == "--jacobi") {
             o.jacobi = true;
+        } else if (a == "--ranks") {
+            if (!value(v)) return false;
+            o.ranks_per_device = (int)v;
         } else if (a == "--no-rccl") {
             o.use_rccl = false;
         } else if (a == "--rccl") {
@@ -213,7 +217,7 @@ int main(int argc, char **argv)
 {
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
-        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--jacobi] [--no-rccl] [--rccl]\n");
+        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--jacobi] [--ranks N] [--no-rccl] [--rccl]\n");
         return EXIT_FAILURE;
     }
     if (opt.devices.empty()) {

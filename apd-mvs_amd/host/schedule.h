@@ -15,6 +15,7 @@ struct Options {
     int gpu_index = 0;
     std::vector<int> devices;   // "0,1,2,3": one scheduler rank per entry (an entry may repeat: two ranks on one device)
     bool jacobi = false;        // the in-memory scheduler of host/multi_device.cpp even with a single device
+    int ranks_per_device = 0;   // --ranks N: scheduler ranks on a single device (0: by frame size, host/multi_device.cpp)
     bool use_rccl = true;       // --no-rccl: exchange maps with direct copies
     bool force_rccl = false;    // --rccl: RCCL even for a single rank (which has nothing to exchange between devices and uses direct copies otherwise)
     uint64_t seed = 12345;

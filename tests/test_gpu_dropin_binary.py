@@ -218,7 +218,7 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     base.mkdir()
     _write_dense_folder(base, synth, W, H, nviews, jpeg=False)
     runs = {}
-    for name, dev, extra in (("one", "0", ["--jacobi", "--rccl"]), ("one_default", "0", ["--jacobi"]), ("one_copy", "0", ["--jacobi", "--no-rccl"]),
+    for name, dev, extra in (("one", "0", ["--jacobi", "--rccl"]), ("one_default", "0", ["--jacobi"]), ("one_copy", "0", ["--jacobi", "--no-rccl", "--ranks", "1"]),
                              ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", [])):
         d = tmp_path / name
         shutil.copytree(base, d)
@@ -226,6 +226,9 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
                            stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:]
         runs[name] = (d, r.stdout)
+    # ranks: --rccl keeps the single rank RCCL needs, a small frame on one device takes three (--ranks N: exactly N)
+    assert "processed on 1 rank(s)" in runs["one"][1] and "processed on 1 rank(s)" in runs["one_copy"][1]
+    assert "processed on 3 rank(s)" in runs["one_default"][1] and "processed on 2 rank(s)" in runs["two"][1]
     assert "Exchange of depth maps between passes: rccl\n" in runs["one"][1], runs["one"][1][-2000:]
     assert "through RCCL, 0 through direct copies" in runs["one"][1]
     # a single rank has nothing to exchange between devices: direct copies unless --rccl (RCCL's set-up takes seconds)
