@@ -4,9 +4,10 @@
 // state between pyramid levels on the device, and the all-gather of per-view maps across the devices of one process.
 //
 // The all-gather is RCCL's (ncclCommInitAll + one grouped ncclAllGather per call, every rank on its own stream), i.e. the
-// xGMI path.  librccl is opened at run time (dlopen): the library has no link-time dependency on it, and a device list that
-// names one device twice -- the way a one-GPU box exercises the multi-device scheduler -- or a missing librccl falls back to
-// direct copies (hipMemcpyPeerAsync), which give the same bytes.
+// xGMI path.  librccl is opened at run time (dlopen): the library has no link-time dependency on it, and a missing librccl falls
+// back to direct copies (hipMemcpyPeerAsync), which give the same bytes.  A device list that repeats itself ("0,1,2,3,0,1,2,3":
+// two scheduler ranks per device) runs RCCL between one leader rank per device and copies inside the devices; a list without that
+// structure ("0,0,1") uses direct copies.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -156,7 +157,11 @@ enum { kRcclOff = 0, kRcclPending = 1, kRcclReady = 2, kRcclFailed = 3 };
 struct apd_exchange {
     std::vector<int> devices;
     std::vector<hipStream_t> streams;
-    std::vector<void *> comms;  // ncclComm_t per rank; used only once rccl_state == kRcclReady
+    // Several ranks per device ("0,1,2,3,0,1,2,3": the list repeats its first `period` distinct entries): RCCL runs between
+    // one leader rank per device -- ranks 0 .. period - 1, one communicator entry each -- once per repetition, and the other ranks of
+    // a device copy the gathered blocks from their leader, inside the device.  period == number of ranks: the plain case.
+    int period = 0;
+    std::vector<void *> comms;  // ncclComm_t per leader rank; used only once rccl_state == kRcclReady
     std::atomic<int> rccl_state{kRcclOff};
     std::string rccl_error;
     int exchanges_rccl = 0, exchanges_copy = 0;
@@ -165,7 +170,7 @@ struct apd_exchange {
 
 static void rccl_initialise(apd_exchange *x)
 {
-    const int n = (int)x->devices.size();
+    const int n = x->period;  // one communicator entry per distinct device
     if (!g_rccl.load()) {
         x->rccl_error = "librccl not found";
         x->rccl_state.store(kRcclFailed);
@@ -274,14 +279,32 @@ int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, 
             return xfail(APD_ERR_HIP, "apd_exchange_create: cannot create a stream on device %d", devices[i]);
         }
     }
-    if (prefer_rccl && distinct) {  // one communicator per rank, all in this process
+    // the list's period: its first `period` entries are distinct and the rest repeats them in order
+    x->period = num_ranks;
+    if (!distinct) {
+        int first_repeat = num_ranks;
+        for (int i = 1; i < num_ranks && first_repeat == num_ranks; ++i) {
+            for (int j = 0; j < i; ++j) {
+                if (devices[i] == devices[j]) {
+                    first_repeat = i;
+                    break;
+                }
+            }
+        }
+        bool periodic = num_ranks % first_repeat == 0;
+        for (int i = first_repeat; i < num_ranks && periodic; ++i) {
+            periodic = devices[i] == devices[i % first_repeat];
+        }
+        x->period = periodic ? first_repeat : 0;  // 0: no structure RCCL could use, direct copies
+    }
+    if (prefer_rccl && x->period > 0) {  // one communicator entry per device, all in this process
         x->rccl_state.store(kRcclPending);
         rccl_initialise(x);
         if (x->rccl_state.load() == kRcclFailed) {
             fprintf(stderr, "apd_exchange_create: RCCL is not available (%s): using direct copies\n", x->rccl_error.c_str());
         }
     }
-    if (distinct && x->rccl_state.load() != kRcclReady) {  // direct copies between different devices: let them go over xGMI
+    if (x->rccl_state.load() != kRcclReady) {  // direct copies between different devices: let them go over xGMI
         for (int i = 0; i < num_ranks; ++i) {
             for (int j = 0; j < num_ranks; ++j) {
                 int can = 0;
@@ -339,14 +362,25 @@ int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *cons
     }
     if (x->rccl_state.load() == kRcclReady) {
         x->exchanges_rccl++;
+        // Repetition l of the device list is ranks l * period .. (l + 1) * period - 1, one per device in communicator order: its
+        // all-gather, run by the leaders (a send buffer only has to live on the leader's device), fills blocks l * period ..
+        // of every leader's result -- rank order.  One group for all repetitions.
+        const int period = x->period, reps = n / period;
         int rc = g_rccl.GroupStart();
-        for (int r = 0; r < n && rc == 0; ++r) {
-            rc = g_rccl.AllGather(send[r], recv[r], bytes_per_rank, kNcclInt8, x->comms[r], x->streams[r]);
+        for (int l = 0; l < reps && rc == 0; ++l) {
+            for (int d = 0; d < period && rc == 0; ++d) {
+                rc = g_rccl.AllGather(send[l * period + d], (char *)recv[d] + (size_t)l * period * bytes_per_rank, bytes_per_rank, kNcclInt8,
+                                      x->comms[d], x->streams[d]);
+            }
         }
         const int rc_end = g_rccl.GroupEnd();
         rc = rc ? rc : rc_end;
         if (rc != 0) {
             return xfail(APD_ERR_HIP, "ncclAllGather failed: %s", g_rccl.GetErrorString(rc));
+        }
+        for (int r = period; r < n; ++r) {  // the other ranks of a device: a copy of their leader's result, ordered behind the gather
+            X_TRY(hipSetDevice(x->devices[r]));
+            X_TRY(hipMemcpyAsync(recv[r], recv[r % period], (size_t)n * bytes_per_rank, hipMemcpyDeviceToDevice, x->streams[r % period]));
         }
     } else {
         x->exchanges_copy++;

@@ -164,16 +164,30 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
     ms_load = stage.lap();
     const int W0 = full[0].cols, H0 = full[0].rows;
     const size_t pix0 = (size_t)W0 * H0;
-    // A single device takes several scheduler ranks when the frames are small: one view's launches leave a 256-CU device partly
-    // idle (a 960 x 540 level is 1.3 rounds of workgroups), two or three views in flight fill it -- 12 % less wall time on a
-    // 12-view 1080p folder, 2 % at 6200 x 4130 (profiles/r03/e2e_timing.txt), same bytes (Jacobi over views).  --ranks N overrides;
-    // a device LIST keeps one rank per entry as given (RCCL wants distinct devices).
-    if (devices.size() == 1 && !(opt.force_rccl && opt.ranks_per_device <= 0)) {  // --rccl: one rank per communicator device
+    // A device takes several scheduler ranks when the frames are small: one view's launches leave a 256-CU device partly idle (a
+    // 960 x 540 level is 1.3 rounds of workgroups), two or three views in flight fill it -- 12 % less wall time on a 12-view 1080p
+    // folder, 2 % at 6200 x 4130 (profiles/r03/e2e_timing.txt), same bytes (Jacobi over views).  --ranks N: exactly N per device.
+    // The device list is repeated as a whole ("0,1,2,3" -> "0,1,2,3,0,1,2,3"): views stay round-robin over the devices, and the
+    // exchange runs RCCL between one leader rank per device and copies inside the devices (csrc/apd_exchange.hip).  A list that
+    // already names a device twice is taken as given.
+    {
+        bool distinct = true;
+        for (size_t i = 0; i < devices.size(); ++i) {
+            for (size_t j = 0; j < i; ++j) {
+                distinct = distinct && devices[i] != devices[j];
+            }
+        }
         int k = opt.ranks_per_device;
         if (k <= 0) {
             k = pix0 <= ((size_t)4 << 20) ? 3 : (pix0 <= ((size_t)12 << 20) ? 2 : 1);
         }
-        devices.assign((size_t)std::max(1, std::min(k, V)), devices[0]);
+        k = std::max(1, std::min(k, V / (int)devices.size()));
+        if (distinct && k > 1) {
+            const std::vector<int> once = devices;
+            for (int rep = 1; rep < k; ++rep) {
+                devices.insert(devices.end(), once.begin(), once.end());
+            }
+        }
     }
     const int G = (int)devices.size();
     const int round_num = opt.single_level ? 1 : RoundNum(W0, H0);
@@ -210,8 +224,17 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
     const long long ms_alloc = stage.lap();
     apd_exchange_t exchange = nullptr;
     // RCCL's set-up costs seconds (5.6 s for one device on the MI355X box, against 4.0 s for all eight passes of a 12-view 1080p
-    // folder) and cannot be overlapped with the passes: a single rank, which exchanges with itself, does without unless --rccl
-    Check(apd_exchange_create(&exchange, G, devices.data(), (opt.use_rccl && (G > 1 || opt.force_rccl)) ? 1 : 0), "apd_exchange_create");
+    // folder) and cannot be overlapped with the passes: ranks that share one device have nothing to send through xGMI and do without
+    // unless --rccl
+    int physical = 0;  // distinct devices of the list
+    for (int i = 0; i < G; ++i) {
+        bool seen = false;
+        for (int j = 0; j < i; ++j) {
+            seen = seen || devices[j] == devices[i];
+        }
+        physical += seen ? 0 : 1;
+    }
+    Check(apd_exchange_create(&exchange, G, devices.data(), (opt.use_rccl && (physical > 1 || opt.force_rccl)) ? 1 : 0), "apd_exchange_create");
     printf("Device buffers: %lld ms, exchange set-up: %lld ms\n", ms_alloc, stage.lap());
     printf("Exchange of depth maps between passes: %s\n", apd_exchange_backend(exchange));
 

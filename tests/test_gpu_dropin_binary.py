@@ -218,7 +218,8 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     base.mkdir()
     _write_dense_folder(base, synth, W, H, nviews, jpeg=False)
     runs = {}
-    for name, dev, extra in (("one", "0", ["--jacobi", "--rccl"]), ("one_default", "0", ["--jacobi"]), ("one_copy", "0", ["--jacobi", "--no-rccl", "--ranks", "1"]),
+    for name, dev, extra in (("one", "0", ["--jacobi", "--rccl", "--ranks", "1"]), ("one_default", "0", ["--jacobi"]),
+                             ("one_copy", "0", ["--jacobi", "--no-rccl", "--ranks", "1"]), ("three_rccl", "0", ["--jacobi", "--rccl"]),
                              ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", [])):
         d = tmp_path / name
         shutil.copytree(base, d)
@@ -226,9 +227,13 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
                            stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:]
         runs[name] = (d, r.stdout)
-    # ranks: --rccl keeps the single rank RCCL needs, a small frame on one device takes three (--ranks N: exactly N)
+    # ranks: a small frame takes three per device (--ranks N: exactly N); with RCCL the leader rank of the device runs the
+    # collective (here with itself) and the two others copy its result
     assert "processed on 1 rank(s)" in runs["one"][1] and "processed on 1 rank(s)" in runs["one_copy"][1]
     assert "processed on 3 rank(s)" in runs["one_default"][1] and "processed on 2 rank(s)" in runs["two"][1]
+    assert "processed on 3 rank(s)" in runs["three_rccl"][1]
+    assert "Exchange of depth maps between passes: rccl\n" in runs["three_rccl"][1], runs["three_rccl"][1][-2000:]
+    assert "through RCCL, 0 through direct copies" in runs["three_rccl"][1]
     assert "Exchange of depth maps between passes: rccl\n" in runs["one"][1], runs["one"][1][-2000:]
     assert "through RCCL, 0 through direct copies" in runs["one"][1]
     # a single rank has nothing to exchange between devices: direct copies unless --rccl (RCCL's set-up takes seconds)
@@ -238,7 +243,7 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     assert "Exchange of depth maps between passes: peer-copy" in runs["three"][1]   # one device named three times: RCCL needs distinct devices
     assert "Round nums: 2" in runs["one"][1] and "rank 2 (device 0)" in runs["three"][1]
     ref = runs["one"][0]
-    for name in ("one_default", "one_copy", "three", "two"):
+    for name in ("one_default", "one_copy", "three", "two", "three_rccl"):
         d = runs[name][0]
         for idx in range(nviews):
             for f in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):

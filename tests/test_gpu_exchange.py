@@ -1,6 +1,6 @@
 """The multi-device helpers of the C ABI (include/apd_mi355x.h: apd_device_*, apd_rescale_nearest_device, apd_exchange_*) called
-directly, on the one GPU of the box: device lists that repeat a device exchange by direct copies, a one-device list through
-RCCL.  host/multi_device.cpp is the user of these entry points (tests/test_gpu_dropin_binary.py runs it end to end); the
+directly, on the one GPU of the box: a one-device list through RCCL, lists that repeat the device through the two-level
+exchange (RCCL between the leader ranks -- here one, with itself -- and copies inside the device) or by direct copies.  host/multi_device.cpp is the user of these entry points (tests/test_gpu_dropin_binary.py runs it end to end); the
 all-gather there replaces the reference's exchange of depth maps through depths.dmb files (APD.cpp:497-500)."""
 import ctypes as C
 
@@ -37,8 +37,8 @@ def _host_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-@pytest.mark.parametrize("devices,prefer_rccl,backend", [([0], 1, b"rccl"), ([0], 0, b"peer-copy"), ([0, 0], 1, b"peer-copy"),
-                                                          ([0, 0, 0], 0, b"peer-copy")])
+@pytest.mark.parametrize("devices,prefer_rccl,backend", [([0], 1, b"rccl"), ([0], 0, b"peer-copy"), ([0, 0], 1, b"rccl"),
+                                                          ([0, 0, 0], 1, b"rccl"), ([0, 0, 0], 0, b"peer-copy")])
 def test_allgather_waits_for_the_copies_that_fill_its_send_buffers(gpu_pkg, devices, prefer_rccl, backend):
     """The regression behind the synchronisation in apd_exchange_allgather: the send buffers are packed with device-to-device
     copies on the null stream right before the exchange, whose own streams are non-blocking.  At 3100 x 2065 the planes of the
