@@ -1,12 +1,14 @@
 // main.cpp -- drop-in driver of the PatchMatch path.
 //
 //   APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]
-//       [--jacobi] [--ranks N] [--no-rccl] [--rccl]
+//       [--in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl]
 //
 // One device index: the reference's driver.  A device LIST (or --jacobi): host/multi_device.cpp -- views sharded over the
 // devices, state resident on them, depth maps all-gathered after every pass (RCCL when there is more than one rank -- its set-up takes seconds
 // -- direct copies for a single rank; --rccl: RCCL even then; --no-rccl: direct copies only).  With --jacobi a single device runs
-// one to three scheduler ranks, by frame size (--ranks N: exactly N).
+// one to three scheduler ranks, by frame size (--ranks N: exactly N).  --in-memory: the same scheduler with one rank in the
+// reference's own order (a view of a geometric pass sees the depth maps its sources have at that moment): the bytes of the
+// file-based driver without the files.
 //
 // Same command line, files and results as the reference driver (main.cpp:140-233), organised differently:
 //   * pair.txt is read as one token stream with diagnostics (the reference never notices a missing or short file,
@@ -63,6 +65,8 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.no_fusion = true;
         } else if (a == "--jacobi") {
             o.jacobi = true;
+        } else if (a == "--in-memory") {
+            o.in_memory = true;
         } else if (a == "--ranks") {
             if (!value(v)) return false;
             o.ranks_per_device = (int)v;
@@ -217,7 +221,7 @@ int main(int argc, char **argv)
 {
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
-        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--jacobi] [--ranks N] [--no-rccl] [--rccl]\n");
+        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl]\n");
         return EXIT_FAILURE;
     }
     if (opt.devices.empty()) {
@@ -262,7 +266,11 @@ int main(int argc, char **argv)
         }
     }
     PrefetchGrayImages(opt.dense_folder / "images", ids);  // decoded once, on several host threads
-    if (opt.devices.size() > 1 || opt.jacobi) {
+    if (opt.in_memory && (opt.devices.size() > 1 || opt.jacobi)) {
+        fprintf(stderr, "--in-memory keeps the reference's order of views: one device, one rank (no device list, no --jacobi)\n");
+        return EXIT_FAILURE;
+    }
+    if (opt.devices.size() > 1 || opt.jacobi || opt.in_memory) {
         return RunMultiDevice(opt, problems);  // host/multi_device.cpp: in memory, views sharded over the device list
     }
     int width = 0, height = 0;

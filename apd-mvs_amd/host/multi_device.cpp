@@ -170,7 +170,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
     // The device list is repeated as a whole ("0,1,2,3" -> "0,1,2,3,0,1,2,3"): views stay round-robin over the devices, and the
     // exchange runs RCCL between one leader rank per device and copies inside the devices (csrc/apd_exchange.hip).  A list that
     // already names a device twice is taken as given.
-    {
+    if (!opt.in_memory) {
         bool distinct = true;
         for (size_t i = 0; i < devices.size(); ++i) {
             for (size_t j = 0; j < i; ++j) {
@@ -364,6 +364,13 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                     s.W = LW;
                     s.H = LH;
                     s.valid = true;
+                    if (opt.in_memory) {
+                        // the reference's order (Gauss-Seidel over views): ProcessProblem writes depths.dmb before the next view of
+                        // the pass reads its sources' (main.cpp:117-124, APD.cpp:497-500) -- the view's new map replaces the
+                        // gathered one at once (one rank: G == 1, slot == v)
+                        Check(apd_device_memcpy(k.device, block_of_view(k, v, pix), k.send.as<float>() + slot * pix, pix * sizeof(float)),
+                              "publish depth");
+                    }
                     printf("pass %d (round %d, scale %d) view %08d done on rank %d (device %d)\n", pass.iteration, pass.level, pass.scale_size,
                            problem.ref_image_id, r, k.device);
                 }

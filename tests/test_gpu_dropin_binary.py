@@ -220,7 +220,7 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     runs = {}
     for name, dev, extra in (("one", "0", ["--jacobi", "--rccl", "--ranks", "1"]), ("one_default", "0", ["--jacobi"]),
                              ("one_copy", "0", ["--jacobi", "--no-rccl", "--ranks", "1"]), ("three_rccl", "0", ["--jacobi", "--rccl"]),
-                             ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", [])):
+                             ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", []), ("in_memory", "0", ["--in-memory"])):
         d = tmp_path / name
         shutil.copytree(base, d)
         r = subprocess.run([APD_BIN, str(d), dev, "--seed", str(seed), "--iters", "1", "--keep-maps"] + extra, stdout=subprocess.PIPE,
@@ -250,9 +250,15 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
                 assert (ref / "APD" / ("%08d" % idx) / f).read_bytes() == (d / "APD" / ("%08d" % idx) / f).read_bytes(), (name, idx, f)
         assert (ref / "APD" / "APD.ply").read_bytes() == (d / "APD" / "APD.ply").read_bytes(), name
     assert len(_read_ply(ref / "APD" / "APD.ply")[0]) > 0.3 * W * H
+    # --in-memory: the same scheduler in the reference's order of views gives the bytes of the file-based driver
+    fd, md = runs["files"][0], runs["in_memory"][0]
+    assert "processed on 1 rank(s)" in runs["in_memory"][1]
+    for idx in range(nviews):
+        for f in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
+            assert (fd / "APD" / ("%08d" % idx) / f).read_bytes() == (md / "APD" / ("%08d" % idx) / f).read_bytes(), ("in_memory", idx, f)
+    assert (fd / "APD" / "APD.ply").read_bytes() == (md / "APD" / "APD.ply").read_bytes()
     # Jacobi vs the reference's Gauss-Seidel order: view 0 of the first geometric pass sees the same inputs; in the end the
     # maps are close, not equal
-    fd = runs["files"][0]
     close = []
     for idx in range(nviews):
         a = _read_dmb(ref / "APD" / ("%08d" % idx) / "depths.dmb")
