@@ -230,6 +230,20 @@ int apd_device_memset(int device, void *dst, int value, size_t bytes)
     return APD_OK;
 }
 
+int apd_device_memory(int device, size_t *free_bytes, size_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) {
+        *free_bytes = f;
+    }
+    if (total_bytes) {
+        *total_bytes = t;
+    }
+    return APD_OK;
+}
+
 int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes)
 {
     if (!src || !dst || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0) {

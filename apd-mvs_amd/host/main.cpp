@@ -1,7 +1,7 @@
 // main.cpp -- drop-in driver of the PatchMatch path.
 //
 //   APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion]
-//       [--in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl]
+//       [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl]
 //
 // One device index: the reference's driver.  A device LIST (or --jacobi): host/multi_device.cpp -- views sharded over the
 // devices, state resident on them, depth maps all-gathered after every pass (RCCL when there is more than one rank -- its set-up takes seconds
@@ -16,8 +16,10 @@
 //   * the passes are rows of one table (BuildSchedule) -- the same table apd-mvs_amd/pipeline.py::pass_schedule builds,
 //     so the file-based and the in-memory scheduler cannot drift apart;
 //   * every image is decoded once per process instead of once per (view, pass).
-// State moves between passes through depths.dmb / normals.dmb / weak.bin / selected_views.bin in <dense>/APD/<%08d>/,
+// --files: state moves between passes through depths.dmb / normals.dmb / weak.bin / selected_views.bin in <dense>/APD/<%08d>/,
 // as in the reference; RunFusion then writes APD/APD.ply and the four state files are removed (--keep-maps keeps them).
+// Default for one device: the same order of views and the same bytes with the state resident on the device (host/multi_device.cpp,
+// --in-memory) when the folder fits it -- the files of the last pass are written with --keep-maps.
 // Not built: the debug JPEGs of show_medium_result.
 #include <algorithm>
 #include <chrono>
@@ -67,6 +69,8 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.jacobi = true;
         } else if (a == "--in-memory") {
             o.in_memory = true;
+        } else if (a == "--files") {
+            o.files = true;
         } else if (a == "--ranks") {
             if (!value(v)) return false;
             o.ranks_per_device = (int)v;
@@ -221,7 +225,7 @@ int main(int argc, char **argv)
 {
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
-        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl]\n");
+        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl]\n");
         return EXIT_FAILURE;
     }
     if (opt.devices.empty()) {
@@ -266,6 +270,25 @@ int main(int argc, char **argv)
         }
     }
     PrefetchGrayImages(opt.dense_folder / "images", ids);  // decoded once, on several host threads
+    if (opt.files && (opt.in_memory || opt.jacobi || opt.devices.size() > 1)) {
+        fprintf(stderr, "--files is the single-device driver (no device list, --jacobi or --in-memory)\n");
+        return EXIT_FAILURE;
+    }
+    // `APD dense_folder [gpu]`, the reference's command line: its order of views and its bytes, in memory when the folder fits the
+    // device (every level image, every view's state and two sets of depth maps resident: 4 N + 33 V + 25 bytes per pixel), through the
+    // files otherwise or with --files.
+    if (!opt.files && !opt.in_memory && !opt.jacobi && opt.devices.size() == 1) {
+        int w = 0, h = 0;
+        size_t free_bytes = 0, total_bytes = 0;
+        if (CheckImages(problems, w, h) && apd_device_memory(opt.gpu_index, &free_bytes, &total_bytes) == APD_OK) {
+            const double need = (double)w * h * (4.0 * ids.size() + 33.0 * problems.size() + 25.0);
+            opt.in_memory = need < 0.6 * (double)free_bytes;
+            if (!opt.in_memory) {
+                printf("%.1f GB of resident state against %.1f GB free on device %d: passing state through files\n", need / 1e9,
+                       free_bytes / 1e9, opt.gpu_index);
+            }
+        }
+    }
     if (opt.in_memory && (opt.devices.size() > 1 || opt.jacobi)) {
         fprintf(stderr, "--in-memory keeps the reference's order of views: one device, one rank (no device list, no --jacobi)\n");
         return EXIT_FAILURE;

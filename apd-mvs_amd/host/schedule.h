@@ -16,6 +16,7 @@ struct Options {
     std::vector<int> devices;   // "0,1,2,3": one scheduler rank per entry (an entry may repeat: two ranks on one device)
     bool jacobi = false;        // the in-memory scheduler of host/multi_device.cpp even with a single device
     int ranks_per_device = 0;   // --ranks N: scheduler ranks on a single device (0: by frame size, host/multi_device.cpp)
+    bool files = false;         // --files: state moves between passes through the four files per view, as in the reference
     bool in_memory = false;     // --in-memory: the in-memory scheduler on one device in the reference's own order (one rank, a view reads the
                                 // depth maps its sources have at that moment): the file-based driver's bytes without the files
     bool use_rccl = true;       // --no-rccl: exchange maps with direct copies

@@ -185,6 +185,7 @@ int apd_device_malloc(int device, size_t bytes, void **out);
 int apd_device_free(int device, void *p);
 int apd_device_memcpy(int device, void *dst, const void *src, size_t bytes);   /* host or device pointers on either side */
 int apd_device_memset(int device, void *dst, int value, size_t bytes);
+int apd_device_memory(int device, size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo: does an in-memory run fit? */
 int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes /* 1, 4, 16 */);
 
 /* All-gather across `num_ranks` ranks of this process, rank r on devices[r]: after apd_exchange_allgather every recv[r]

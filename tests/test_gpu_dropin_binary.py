@@ -79,15 +79,19 @@ def _read_image(tmp, i, jpeg):
     return np.frombuffer(data, np.uint8).reshape(h, w).astype(np.float32)
 
 
+@pytest.mark.parametrize("mode", [[], ["--files"]], ids=["in-memory", "files"])
 @pytest.mark.parametrize("jpeg", [False, True])
-def test_binary_matches_c_abi_schedule(gpu_pkg, synth, tmp_path, jpeg):
+def test_binary_matches_c_abi_schedule(gpu_pkg, synth, tmp_path, jpeg, mode):
+    """`APD dense_folder 0` against the same schedule driven through the C ABI from here, in the reference's order of views: the
+    default (state resident on the device between passes) and --files (the reference's four files per view and pass)."""
     assert os.path.exists(APD_BIN), "run __graft_entry__.build() first"
     W, H, nviews, seed, iters = 80, 60, 3, 77, 2
     _write_dense_folder(tmp_path, synth, W, H, nviews, jpeg=jpeg)
-    r = subprocess.run([APD_BIN, str(tmp_path), "0", "--seed", str(seed), "--iters", str(iters), "--keep-maps"], stdout=subprocess.PIPE,
+    r = subprocess.run([APD_BIN, str(tmp_path), "0", "--seed", str(seed), "--iters", str(iters), "--keep-maps"] + mode, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "Round nums: 1" in r.stdout  # max(W,H) <= 1000 -> one pyramid level (main.cpp:83-86)
+    assert ("Processing image: 00000000" in r.stdout) == (mode == ["--files"])   # the file-based driver's log lines
 
     pkg = gpu_pkg
     cams = [_read_cam(tmp_path / "cams" / ("%08d_cam.txt" % i), pkg, W, H) for i in range(nviews)]
@@ -220,7 +224,7 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     runs = {}
     for name, dev, extra in (("one", "0", ["--jacobi", "--rccl", "--ranks", "1"]), ("one_default", "0", ["--jacobi"]),
                              ("one_copy", "0", ["--jacobi", "--no-rccl", "--ranks", "1"]), ("three_rccl", "0", ["--jacobi", "--rccl"]),
-                             ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", []), ("in_memory", "0", ["--in-memory"])):
+                             ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", ["--files"]), ("in_memory", "0", [])):
         d = tmp_path / name
         shutil.copytree(base, d)
         r = subprocess.run([APD_BIN, str(d), dev, "--seed", str(seed), "--iters", "1", "--keep-maps"] + extra, stdout=subprocess.PIPE,
@@ -282,7 +286,7 @@ def test_multi_device_scheduler_at_a_size_where_copies_take_time(gpu_pkg, synth,
     base.mkdir()
     _write_dense_folder(base, synth, W, H, nviews, jpeg=False)
     runs = {}
-    for name, dev, extra in (("jacobi", "0", ["--jacobi"]), ("two", "0,0", []), ("files", "0", [])):
+    for name, dev, extra in (("jacobi", "0", ["--jacobi"]), ("two", "0,0", []), ("files", "0", ["--files"])):
         d = tmp_path / name
         shutil.copytree(base, d)
         r = subprocess.run([APD_BIN, str(d), dev, "--seed", str(seed), "--iters", "1", "--keep-maps"] + extra, stdout=subprocess.PIPE,

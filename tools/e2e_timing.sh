@@ -12,7 +12,7 @@ run_case() {  # name width height views src
   local t0=$(date +%s%N)
   python tools/mvs_pipeline.py $d --seed 12345 > /tmp/e2e_pipe.log 2>&1 || tail -5 /tmp/e2e_pipe.log
   local t1=$(date +%s%N)
-  apd-mvs_amd/_build/APD ${d}_b 0 --seed 12345 > /tmp/e2e_bin.log 2>&1 || tail -5 /tmp/e2e_bin.log
+  apd-mvs_amd/_build/APD ${d}_b 0 --files --seed 12345 > /tmp/e2e_bin.log 2>&1 || tail -5 /tmp/e2e_bin.log
   local t2=$(date +%s%N)
   # the C++ multi-device scheduler with one rank (host/multi_device.cpp: state resident, depth maps exchanged in memory;
   # Jacobi over views, so its cloud differs slightly from the two Gauss-Seidel runs above by construction)
@@ -23,12 +23,12 @@ run_case() {  # name width height views src
   # ... and in the reference's own order (--in-memory): the bytes of the file-based run
   rm -rf ${d}_d; cp -r ${d}_b ${d}_d; rm -rf ${d}_d/APD
   local t5=$(date +%s%N)
-  apd-mvs_amd/_build/APD ${d}_d 0 --in-memory --seed 12345 > /tmp/e2e_gs.log 2>&1 || tail -5 /tmp/e2e_gs.log
+  apd-mvs_amd/_build/APD ${d}_d 0 --seed 12345 > /tmp/e2e_gs.log 2>&1 || tail -5 /tmp/e2e_gs.log
   local t6=$(date +%s%N)
-  echo "== $1: drop-in binary, in memory, reference order (APD folder 0 --in-memory) $(( (t6 - t5) / 1000000 )) ms"
+  echo "== $1: drop-in binary as the reference calls it (APD folder 0: in memory, reference order) $(( (t6 - t5) / 1000000 )) ms"
   grep -iE "stages" /tmp/e2e_gs.log | tail -1
   md5sum ${d}_d/APD/APD.ply
-  echo "== $1: $4 views of $2x$3, $5 sources: in-memory pipeline $(( (t1 - t0) / 1000000 )) ms (python start-up included), drop-in binary $(( (t2 - t1) / 1000000 )) ms, drop-in binary with the in-memory scheduler (APD folder 0 --jacobi) $(( (t4 - t3) / 1000000 )) ms"
+  echo "== $1: $4 views of $2x$3, $5 sources: in-memory pipeline $(( (t1 - t0) / 1000000 )) ms (python start-up included), drop-in binary through the files (APD folder 0 --files) $(( (t2 - t1) / 1000000 )) ms, drop-in binary with the in-memory scheduler (APD folder 0 --jacobi) $(( (t4 - t3) / 1000000 )) ms"
   grep -iE "fusion|points|total|pass" /tmp/e2e_pipe.log | tail -4
   grep -iE "fus|points|total|exchange|gather" /tmp/e2e_mem.log | tail -6
   md5sum $d/APD/APD.ply ${d}_b/APD/APD.ply
