@@ -1,5 +1,5 @@
 """Double entry for the control-flow-heavy stages of the path.  The reference ships no tests or vectors and cannot be built
-here, so the oracle (oracle/apd_oracle.c) is pinned by inspection only.  This file is a SECOND restatement of four stages,
+here, so the oracle (oracle/apd_oracle.c) is pinned by inspection only.  This file is a SECOND restatement of nine stages,
 written from the reference's text (APD.cu line numbers below) and not from the oracle's: plain Python over numpy binary32
 scalars, one statement per statement.  It shares with the oracle only leaf functions that have their own independent checks --
 the NCC / geometric cost of one (pixel, view, plane) (tests/test_oracle_float64.py), the XORWOW stream (tests/test_rng.py,
@@ -8,7 +8,13 @@ pinned to rocRAND) and the polynomial exp of the arithmetic contract -- and must
   * adaptive checkerboard arm search + multi-hypothesis joint view selection of CheckerboardPropagationStrong
     (APD.cu:1012-1259): the view weights of every pixel of a colour;
   * GenNeighbours, K3 (APD.cu:1750-1969): neighbour table, reliability flags and the random state it leaves behind;
-  * the peak classifier of DepthToWeak, K14 (APD.cu:1990-2143): the weak map.
+  * the peak classifier of DepthToWeak, K14 (APD.cu:1990-2143): the weak map;
+  * RANSACToGetFitPlane, K8 (APD.cu:2272-2384): the fit planes and the random state it leaves behind;
+  * LocalRefine, K15 (APD.cu:2146-2232): the depths it adopts;
+  * FindNearestStrongPoint, K2 (APD.cu:2234-2270), and GetDepthandNormal + the two median-filter launches, K11-K13
+    (APD.cu:1587-1748) with the HALF launch geometry of RunPatchMatch (:2400-2407) on a frame of odd height;
+  * the rest of CheckerboardPropagationStrong (APD.cu:1260-1321) with PlaneHypothesisRefinementStrong and its random and
+    perturbed hypotheses (:211-273, :837-890): planes, costs, selected views and random streams after K6 / K7.
 
 Two independent transcriptions that agree on every bit do not prove either right, but a slip in one of them (a swapped arm,
 a `<` for a `<=`, a draw out of order) shows up here."""
@@ -161,6 +167,11 @@ def arm_search(costs, W, H, px, py):
 
 
 def view_weights_of_pixel(ob, o, snap, W, H, nsrc, px, py, it):
+    return view_selection_of_pixel(ob, o, snap, W, H, nsrc, px, py, it)[0]
+
+
+def view_selection_of_pixel(ob, o, snap, W, H, nsrc, px, py, it):
+    """(view weights, arm positions, arm flags, the 8 x 32 cost table, the pixel's random stream after its 15 draws)"""
     costs, planes, sel, rng_words = snap
     pos, flag = arm_search(costs, W, H, px, py)
     cost_array = np.zeros((8, 32), np.float32)
@@ -211,7 +222,7 @@ def view_weights_of_pixel(ob, o, snap, W, H, nsrc, px, py, it):
             if probs[v] > rand_prob:
                 weights[v] += 1
                 break
-    return weights
+    return weights, pos, flag, cost_array, rng
 
 
 def test_arm_search_and_view_selection(synth, ob):
@@ -560,4 +571,482 @@ def test_depth_to_weak_classifier(synth, ob):
                 assert int(got[py, px]) == want, (geom, px, py, int(got[py, px]), want)
                 counts[want] += 1
         assert min(counts) > 0, counts   # all three classes occur
+        o.close()
+
+
+# ---- stage 4: RANSACToGetFitPlane, K8 (APD.cu:2272-2384) --------------------------------------------------------------------
+
+def depth_from_plane(K, pl, px, py):  # ComputeDepthfromPlaneHypothesis, :206-209
+    num = f32(f32(-pl[3]) * K[0])
+    a = f32(f32(f32(px) - K[2]) * pl[0])
+    b = f32(f32(f32(K[0] / K[4]) * f32(f32(py) - K[5])) * pl[1])
+    c = f32(K[0] * pl[2])
+    return f32(num / f32(f32(a + b) + c))
+
+
+def view_direction(K, px, py, depth):  # GetViewDirection, :174-184
+    X = get_3d_point(K, px, py, depth)
+    norm = np.sqrt(f32(f32(f32(X[0] * X[0]) + f32(X[1] * X[1])) + f32(X[2] * X[2])))
+    return f32(X[0] / norm), f32(X[1] / norm), f32(X[2] / norm)
+
+
+def ransac_fit_plane_pixel(ob, W, K, weak, planes, neighbours_row, rng_words, px, py):
+    """One pixel of K8: returns (fit plane as 4 binary32, random state afterwards)."""
+    pl_c = tuple(f32(v) for v in planes[py, px])
+    if weak[py, px] != WEAK:  # :2283-2286
+        return pl_c, np.array(rng_words, np.uint32)
+    rng = Rng(ob, rng_words)
+    pts, pts3 = [], []
+    for i in range(1, 9):  # :2296-2311, NEIGHBOUR_NUM = 9
+        qx, qy = int(neighbours_row[i][0]), int(neighbours_row[i][1])
+        if qx == -1 or qy == -1:
+            continue
+        pts.append((qx, qy))
+        d = depth_from_plane(K, tuple(f32(v) for v in planes[qy, qx]), qx, qy)
+        pts3.append(get_3d_point(K, qx, qy, d))
+    n = len(pts)
+    if n < 3:  # :2312-2315
+        return pl_c, rng.words()
+    min_cost, best = FLT_MAX, None
+    for _ in range(50):  # :2317-2370, `while (iteration--)`
+        a = rng.next() % n   # unsigned remainder (curand returns unsigned int, the int operand is converted)
+        b = rng.next() % n
+        c = rng.next() % n
+        if a == b or b == c or a == c:
+            continue
+        if not point_in_triangle(pts[a], pts[b], pts[c], (px, py)):
+            continue
+        A, B, Cp = pts3[a], pts3[b], pts3[c]
+        ac = (f32(A[0] - Cp[0]), f32(A[1] - Cp[1]), f32(A[2] - Cp[2]))
+        bc = (f32(B[0] - Cp[0]), f32(B[1] - Cp[1]), f32(B[2] - Cp[2]))
+        cx = f32(f32(ac[1] * bc[2]) - f32(bc[1] * ac[2]))
+        cy = f32(-f32(f32(ac[0] * bc[2]) - f32(bc[0] * ac[2])))
+        cz = f32(f32(ac[0] * bc[1]) - f32(bc[0] * ac[1]))
+        if (cx == 0 and cy == 0 and cz == 0) or math.isnan(cx) or math.isnan(cy) or math.isnan(cz):
+            continue
+        inv = f32(f32(1.0) / np.sqrt(f32(f32(f32(cx * cx) + f32(cy * cy)) + f32(cz * cz))))  # NormalizeVec3, rsqrtf := 1 / sqrtf (C4)
+        cx, cy, cz = f32(cx * inv), f32(cy * inv), f32(cz * inv)
+        cw = f32(-f32(f32(f32(cx * A[0]) + f32(cy * A[1])) + f32(cz * A[2])))
+        cost = f32(0.0)
+        for k in range(n):
+            if k in (a, b, c):
+                continue
+            t = pts3[k]
+            cost = f32(cost + f32(abs(f32(f32(f32(f32(cx * t[0]) + f32(cy * t[1])) + f32(cz * t[2])) + cw))))
+        if cost < min_cost:
+            min_cost, best = cost, (cx, cy, cz, cw)
+        if min_cost == 0:
+            break
+    if best is None:  # :2381-2383
+        return (f32(0), f32(0), f32(0), f32(0)), rng.words()
+    d = depth_from_plane(K, pl_c, px, py)  # :2372-2379: flip to face the camera
+    vd = view_direction(K, px, py, d)
+    dot = f32(f32(f32(best[0] * vd[0]) + f32(best[1] * vd[1])) + f32(best[2] * vd[2]))
+    if dot > 0:
+        best = (f32(-best[0]), f32(-best[1]), f32(-best[2]), f32(-best[3]))
+    return best, rng.words()
+
+
+def test_ransac_fit_plane(synth, ob):
+    W, H, N = 128, 96, 3
+    sc, p1, o = _apd_oracle(synth, ob, W, H, N, seed=12)
+    for kid in (1, 2, 3, 4, 5, 6, 7):   # RunPatchMatch's order up to the first K8 (:2407-2451)
+        o.run_kernel(kid, 0)
+    weak, planes, rng0 = o.weak_info.copy(), o.planes.copy(), o.rng.copy()
+    nmap, nb = o.neighbours_map.copy(), o.neighbours.copy()
+    o.run_kernel(8, 0)
+    fit, rng1 = o.fit_planes, o.rng
+    K = [f32(v) for v in sc.K[0].reshape(-1)]
+    fitted = zeroed = 0
+    with np.errstate(all="ignore"):
+        for py in range(H):
+            for px in range(W):
+                want, want_rng = ransac_fit_plane_pixel(ob, W, K, weak, planes, nb[nmap[py, px]], rng0[py, px], px, py)
+                got = fit[py, px]
+                assert np.array_equal(np.array(want, np.float32).view(np.uint32), got.view(np.uint32)), (px, py, want, got.tolist())
+                assert np.array_equal(rng1[py, px], want_rng), (px, py)
+                if weak[py, px] == WEAK:
+                    zero = not np.any(got.view(np.uint32) & 0x7FFFFFFF)
+                    zeroed += int(zero)
+                    fitted += int(not zero and not np.array_equal(got.view(np.uint32), planes[py, px].view(np.uint32)))
+    assert fitted > 20 and zeroed > 0, (fitted, zeroed)   # both outcomes of the RANSAC loop occur
+    o.close()
+
+
+# ---- stage 5: LocalRefine, K15 (APD.cu:2146-2232) ---------------------------------------------------------------------------
+
+def local_refine_pixel(o, cams_c, K, R, params, planes, sel, vweight, nsrc, px, py, geom):
+    """One pixel of K15: the w component its plane has afterwards (binary32)."""
+    origin = normal_to_ref_cam(R, planes[py, px])
+    origin_depth = origin[3]
+    if origin_depth == 0:
+        return f32(planes[py, px][3])
+    s = int(sel[py, px])
+    vw = vweight[py, px]
+    gf = f32(params["geom_factor"])
+    cost_now, base_line, valid, weight_normal = f32(0), f32(0), 0, f32(0)
+    for v in range(nsrc):  # :2170-2190
+        if is_set(s, v):
+            pl = np.array([origin[0], origin[1], origin[2], distance_to_origin(K, px, py, origin_depth, origin)], np.float32)
+            t = f32(o.ncc_old(px, py, v + 1, pl))
+            if geom:
+                t = f32(t + f32(gf * f32(o.geom_cost(px, py, v + 1, pl))))
+            cost_now = f32(cost_now + f32(t * f32(vw[v])))
+            weight_normal = f32(weight_normal + f32(vw[v]))
+            cd = [f32(cams_c[0][k] - cams_c[v + 1][k]) for k in range(3)]
+            tv = float(f32(f32(f32(cd[0] * cd[0]) + f32(cd[1] * cd[1])) + f32(cd[2] * cd[2])))  # float expression into a double
+            base_line = f32(base_line + f32(np.sqrt(f32(tv))))
+            valid += 1
+    if weight_normal == 0 or valid == 0:
+        return f32(planes[py, px][3])
+    cost_now = f32(cost_now / weight_normal)
+    base_line = f32(base_line / f32(valid))
+    disp = f32(f32(K[0] * base_line) / origin_depth)
+    min_cost, best_depth = f32(2.0), origin_depth
+    for p_disp in range(-5, 6):  # :2201-2226
+        p_depth = f32(f32(K[0] * base_line) / f32(disp + f32(p_disp)))
+        if p_depth < f32(params["depth_min"]) or p_depth > f32(params["depth_max"]):
+            continue
+        pl = np.array([origin[0], origin[1], origin[2], distance_to_origin(K, px, py, p_depth, origin)], np.float32)
+        t = f32(0)
+        for v in range(nsrc):
+            if is_set(s, v):
+                t = f32(t + f32(f32(o.ncc_old(px, py, v + 1, pl)) * f32(vw[v])))
+                if geom:
+                    t = f32(t + f32(f32(gf * f32(o.geom_cost(px, py, v + 1, pl))) * f32(vw[v])))
+        t = f32(t / weight_normal)
+        if t < min_cost:
+            min_cost, best_depth = t, p_depth
+    if float(f32(cost_now - min_cost)) > 0.1:  # :2229, a float difference against a double constant
+        return best_depth
+    return f32(planes[py, px][3])
+
+
+def test_local_refine(synth, ob):
+    W, H, N = 56, 40, 3
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=14, textureless=0.25)
+    for geom in (0, 1):
+        kw = dict(seed=9, max_iterations=1, weak_peak_radius=4 if geom else 6)   # one iteration: planes far enough from converged to move
+        depths = None
+        prior = None
+        if geom:
+            kw.update(state=2, geom_consistency=1)
+            depths = common.fake_depth_maps(W, H, N + 1)
+            o0 = common.make_oracle(ob, sc, imgs, N, common.base_params(sc, N, seed=3, max_iterations=2, weak_peak_radius=6))
+            o0.run()
+            p0 = common.base_params(sc, N)
+            prior = common.postprocess(o0.planes.copy(), o0.weak_info.copy(), o0.selected_views.copy(), f32(p0["depth_min"]), f32(p0["depth_max"]))
+            o0.close()
+        params = common.base_params(sc, N, **kw)
+        params["geom_factor"] = ob.default_params(**params).geom_factor
+        o = common.make_oracle(ob, sc, imgs, N, params, depths=depths, prior=prior)
+        for kid in (1, 2, 5):
+            o.run_kernel(kid)
+        o.run_sweeps(0, 1)
+        for kid in (11, 12, 13, 14):   # the post-loop kernels in RunPatchMatch's order (:2459-2490)
+            o.run_kernel(kid)
+        planes, sel, vw = o.planes.copy(), o.selected_views.copy(), o.view_weight.copy()
+        o.run_kernel(15)
+        got = o.planes
+        K = [f32(v) for v in sc.K[0].reshape(-1)]
+        R = [f32(v) for v in sc.R[0].reshape(-1)]
+        cams_c = [[f32(v) for v in ob.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max).c] for i in range(N + 1)]
+        moved = 0
+        with np.errstate(all="ignore"):
+            for py in range(H):
+                for px in range(W):
+                    want = local_refine_pixel(o, cams_c, K, R, params, planes, sel, vw, N, px, py, geom)
+                    assert np.array_equal(got[py, px, :3].view(np.uint32), planes[py, px, :3].view(np.uint32)), (geom, px, py)  # only w is written
+                    assert np.float32(want).view(np.uint32) == got[py, px, 3].view(np.uint32), (geom, px, py, float(want), float(got[py, px, 3]))
+                    moved += int(got[py, px, 3].view(np.uint32) != planes[py, px, 3].view(np.uint32))
+        assert moved > 5, (geom, moved)   # some depths are adopted
+        o.close()
+
+
+# ---- stage 6: FindNearestStrongPoint, K2 (APD.cu:2234-2270) -----------------------------------------------------------------
+
+def nearest_strong_pixel(weak, W, H, px, py):
+    if weak[py, px] != WEAK:
+        return (-1, -1)
+    best, min_dist = (-1, -1), f32(255.0)
+    for x in range(-100, 101):          # x is the OUTER loop (:2252-2253): ties go to the first hit in that order
+        for y in range(-100, 101):
+            qx, qy = px + x, py + y
+            if qx < 0 or qy < 0 or qx >= W or qy >= H:
+                continue
+            if weak[qy, qx] == STRONG:
+                dist = np.sqrt(f32(x * x + y * y))   # integer expression converted to float, then sqrtf
+                if dist < min_dist:
+                    min_dist, best = dist, (qx, qy)
+    return best
+
+
+def test_find_nearest_strong_point(synth, ob):
+    W, H, N = 128, 96, 2
+    sc, p1, o = _apd_oracle(synth, ob, W, H, N, seed=12)
+    o.run_kernel(1)
+    weak = o.weak_info.copy()
+    # a hand-made WEAK block wider than the search radius, with UNKNOWN pixels on part of its border: pixels without any STRONG
+    # pixel within 100, ties between equidistant candidates, candidates hidden behind non-STRONG ones
+    weak[:, :] = STRONG
+    weak[10:90, 4:124] = WEAK
+    weak[9, 30:60] = UNKNOWN
+    weak[40:44, 3] = UNKNOWN
+    weak[50, 60] = STRONG
+    o.weak_info[:, :] = weak
+    o.run_kernel(2)
+    got = o.nearest_strong
+    ys, xs = np.nonzero(weak == WEAK)
+    pick = np.random.RandomState(0).choice(len(ys), 350, replace=False)
+    none = 0
+    for py, px in [(int(ys[i]), int(xs[i])) for i in pick] + [(0, 0), (9, 40), (50, 60), (49, 60), (50, 59)]:
+        want = nearest_strong_pixel(weak, W, H, px, py)
+        assert (int(got[py, px][0]), int(got[py, px][1])) == want, (px, py, got[py, px].tolist(), want)
+        none += int(want == (-1, -1) and weak[py, px] == WEAK)
+    o.close()
+
+
+# ---- stage 7: GetDepthandNormal, Black/RedPixelFilterStrong, K11-K13 (APD.cu:1587-1748) -------------------------------------
+
+def normal_to_world(R, p):  # TransformNormal, :374-381: R^T n
+    return (f32(f32(f32(R[0] * p[0]) + f32(R[3] * p[1])) + f32(R[6] * p[2])),
+            f32(f32(f32(R[1] * p[0]) + f32(R[4] * p[1])) + f32(R[7] * p[2])),
+            f32(f32(f32(R[2] * p[0]) + f32(R[5] * p[1])) + f32(R[8] * p[2])), f32(p[3]))
+
+
+def filter_strong_pixel(planes, costs, weak, W, H, px, py):
+    """CheckerboardFilterStrong (:1602-1714) on pixel (px, py): the depth it leaves in planes[py, px][3]."""
+    w = planes[..., 3]
+    vals = [f32(w[py, px])]
+    if costs[py, px] < f32(0.001):
+        return f32(w[py, px])
+
+    def take(cond, dx, dy):
+        if cond and weak[py + dy, px + dx] == STRONG:
+            vals.append(f32(w[py + dy, px + dx]))
+
+    take(py > 0, 0, -1)
+    take(py > 2, 0, -3)
+    take(py > 4, 0, -5)
+    take(py < H - 1, 0, 1)
+    take(py < H - 3, 0, 3)
+    take(py < H - 5, 0, 5)
+    take(px > 0, -1, 0)
+    take(px > 2, -3, 0)
+    take(px > 4, -5, 0)
+    take(px < W - 1, 1, 0)
+    take(px < W - 3, 3, 0)
+    take(px < W - 5, 5, 0)
+    take(py > 0 and px < W - 2, 2, -1)
+    take(py < H - 1 and px < W - 2, 2, 1)
+    take(py > 0 and px > 1, -2, -1)
+    take(py < H - 1 and px > 1, -2, 1)
+    take(px > 0 and py > 2, -1, -2)
+    take(px < W - 1 and py > 2, 1, -2)
+    take(px > 0 and py < H - 2, -1, 2)
+    take(px < W - 1 and py < H - 2, 1, 2)
+    d = list(vals)   # sort_small (:3-12): insertion sort, strict `<`
+    for i in range(1, len(d)):
+        tmp, j = d[i], i
+        while j >= 1 and tmp < d[j - 1]:
+            d[j] = d[j - 1]
+            j -= 1
+        d[j] = tmp
+    m = len(d) // 2
+    if len(d) % 2 == 0:
+        return f32(f32(d[m - 1] + d[m]) / f32(2))
+    return d[m]
+
+
+def test_depth_normal_and_median_filter(synth, ob):
+    W, H, N = 89, 65, 3   # odd height: grid_size_half.y = ((65 / 2) + 15) / 16 = 2 blocks of 16 row pairs -> row 64 is never filtered
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=21, textureless=0.3)
+    o0 = common.make_oracle(ob, sc, imgs, N, common.base_params(sc, N, seed=3, max_iterations=2, weak_peak_radius=6))
+    o0.run()
+    p0 = common.base_params(sc, N)
+    prior = common.postprocess(o0.planes.copy(), o0.weak_info.copy(), o0.selected_views.copy(), f32(p0["depth_min"]), f32(p0["depth_max"]))
+    o0.close()
+    params = common.base_params(sc, N, seed=9, max_iterations=1, state=1, use_APD=1, weak_peak_radius=6, rotate_time=2, ransac_threshold=0.00875)
+    o = common.make_oracle(ob, sc, imgs, N, params, prior=prior)
+    for kid in (1, 2, 3, 4, 5):
+        o.run_kernel(kid)
+    o.run_sweeps(0, 1)
+    before, costs, weak = o.planes.copy(), o.costs.copy(), o.weak_info.copy()
+    assert (weak == WEAK).sum() > 20 and (weak == STRONG).sum() > 200
+    K = [f32(v) for v in sc.K[0].reshape(-1)]
+    R = [f32(v) for v in sc.R[0].reshape(-1)]
+    # K11, :1587-1600: depth first, then the normal to the world frame (w keeps the depth)
+    o.run_kernel(11)
+    want = np.empty_like(before)
+    for py in range(H):
+        for px in range(W):
+            pl = [f32(v) for v in before[py, px]]
+            pl[3] = depth_from_plane(K, pl, px, py)
+            want[py, px] = normal_to_world(R, pl)
+    assert np.array_equal(o.planes.view(np.uint32), want.view(np.uint32))
+    # K12 then K13: HALF launches of 32 x 16 threads, p.y = 2 * p.y (+ 1) by the parity of threadIdx.x (:1716-1748)
+    rows = 2 * (((H // 2) + 15) // 16) * 16
+    changed = 0
+    for colour in (0, 1):
+        o.run_kernel(12 + colour)
+        snap = want.copy()
+        for py in range(min(rows, H)):
+            for px in range(W):
+                black = (py % 2) == (px % 2)   # threadIdx.x even <-> px even (block width 32): black rows are even there
+                if black != (colour == 0) or weak[py, px] == WEAK:
+                    continue
+                v = filter_strong_pixel(snap, costs, weak, W, H, px, py)
+                changed += int(np.float32(v).view(np.uint32) != snap[py, px, 3].view(np.uint32))
+                want[py, px, 3] = v
+        assert np.array_equal(o.planes.view(np.uint32), want.view(np.uint32)), colour
+    assert changed > 50, changed
+    assert rows == H - 1   # the last row of the odd-height frame stays as K11 left it
+    o.close()
+
+
+# ---- stage 8: the tail of CheckerboardPropagationStrong (APD.cu:1260-1321) + PlaneHypothesisRefinementStrong (:837-890) -----
+
+def sinf(ob, x):
+    return f32(ob.lib().orc_sinf(C.c_float(float(x))))
+
+
+def cosf(ob, x):
+    return f32(ob.lib().orc_cosf(C.c_float(float(x))))
+
+
+def random_normal(K, px, py, rng, depth):  # GenerateRandomNormal, :211-237
+    q1, q2, s = f32(1), f32(1), f32(2)
+    while s >= f32(1):
+        q1 = f32(f32(f32(2) * rng.uniform()) - f32(1))
+        q2 = f32(f32(f32(2) * rng.uniform()) - f32(1))
+        s = f32(f32(q1 * q1) + f32(q2 * q2))
+    sq = np.sqrt(f32(f32(1) - s))
+    n = [f32(f32(f32(2) * q1) * sq), f32(f32(f32(2) * q2) * sq), f32(f32(1) - f32(f32(2) * s))]
+    vd = view_direction(K, px, py, depth)
+    if f32(f32(f32(n[0] * vd[0]) + f32(n[1] * vd[1])) + f32(n[2] * vd[2])) > 0:
+        n = [f32(-n[0]), f32(-n[1]), f32(-n[2])]
+    return normalize3(*n)
+
+
+def perturbed_normal(ob, K, px, py, normal, rng, perturbation):  # GeneratePerturbedNormal, :239-273
+    vd = view_direction(K, px, py, f32(1))
+    a1 = f32(f32(rng.uniform() - f32(0.5)) * perturbation)
+    a2 = f32(f32(rng.uniform() - f32(0.5)) * perturbation)
+    a3 = f32(f32(rng.uniform() - f32(0.5)) * perturbation)
+    s1, s2, s3 = sinf(ob, a1), sinf(ob, a2), sinf(ob, a3)
+    c1, c2, c3 = cosf(ob, a1), cosf(ob, a2), cosf(ob, a3)
+    R = [f32(c2 * c3),
+         f32(f32(f32(c3 * s1) * s2) - f32(c1 * s3)),
+         f32(f32(s1 * s3) + f32(f32(c1 * c3) * s2)),
+         f32(c2 * s3),
+         f32(f32(c1 * c3) + f32(f32(s1 * s2) * s3)),
+         f32(f32(f32(c1 * s2) * s3) - f32(c3 * s1)),
+         f32(-s2),
+         f32(c2 * s1),
+         f32(c1 * c2)]
+    p = [f32(f32(f32(R[3 * r] * normal[0]) + f32(R[3 * r + 1] * normal[1])) + f32(R[3 * r + 2] * normal[2])) for r in range(3)]
+    if f32(f32(f32(p[0] * vd[0]) + f32(p[1] * vd[1])) + f32(p[2] * vd[2])) >= 0:
+        p = [f32(normal[0]), f32(normal[1]), f32(normal[2])]
+    return normalize3(*p)
+
+
+def strong_update_pixel(ob, o, snap, W, H, nsrc, params, K, px, py, it):
+    """(plane, cost, selected views, random state) of pixel (px, py) after its K6 / K7 update."""
+    costs, planes, sel, rng_words = snap
+    weights, pos, flag, cost_array, rng = view_selection_of_pixel(ob, o, snap, W, H, nsrc, px, py, it)
+    flat_planes = planes.reshape(-1, 4)
+    center = py * W + px
+    dmin, dmax = f32(params["depth_min"]), f32(params["depth_max"])
+    temp_sel, weight_norm = 0, f32(0)
+    for i in range(nsrc):  # :1260-1270
+        if weights[i] > 0:
+            temp_sel |= 1 << i
+            weight_norm = f32(weight_norm + f32(weights[i]))
+    with np.errstate(all="ignore"):
+        final = []
+        for i in range(8):  # :1272-1282
+            acc = f32(0)
+            for j in range(nsrc):
+                if weights[j] > 0:
+                    acc = f32(acc + f32(f32(weights[j]) * cost_array[i, j]))
+            final.append(f32(acc / weight_norm))
+        best = 0   # FindMinCostIndex, :29-40: `<=`, the last minimum wins
+        cmin = final[0]
+        for i in range(1, 8):
+            if final[i] <= cmin:
+                cmin, best = final[i], i
+        plane_c = np.array(flat_planes[center], np.float32)
+        cost_now = f32(0)
+        for i in range(nsrc):  # :1286-1293: every view, selected or not
+            cost_now = f32(cost_now + f32(f32(weights[i]) * f32(o.ncc_old(px, py, i + 1, plane_c))))
+        cost_now = f32(cost_now / weight_norm)
+        committed = cost_now   # costs[center] = cost_now (:1294)
+        depth_now = depth_from_plane(K, plane_c, px, py)
+        plane_now = plane_c.copy()
+        new_sel = int(sel[py, px])
+        if flag[best]:  # :1298-1307
+            cand = np.array(flat_planes[pos[best]], np.float32)
+            d = depth_from_plane(K, cand, px, py)
+            if d >= dmin and d <= dmax and final[best] < cost_now:
+                depth_now, plane_now, cost_now, new_sel = d, cand.copy(), final[best], temp_sel
+        # PlaneHypothesisRefinementStrong, :837-890
+        depth_rand = f32(f32(rng.uniform() * f32(dmax - dmin)) + dmin)
+        n_rand = random_normal(K, px, py, rng, depth_now)
+        lo, hi = f32(f32(f32(1) - f32(0.02)) * depth_now), f32(f32(f32(1) + f32(0.02)) * depth_now)
+        depth_pert = f32(f32(rng.uniform() * f32(hi - lo)) + lo)   # `do ... while (a < min && a > max)` runs once
+        n_pert = perturbed_normal(ob, K, px, py, plane_now, rng, f32(float(f32(0.02)) * math.pi))
+        depths = [depth_rand, depth_now, depth_rand, depth_now, depth_pert]
+        normals = [tuple(plane_now[:3]), n_rand, n_rand, n_pert, tuple(plane_now[:3])]
+        for dk, nk in zip(depths, normals):
+            pl = np.array([nk[0], nk[1], nk[2], distance_to_origin(K, px, py, dk, nk)], np.float32)
+            t = f32(0)
+            for j in range(nsrc):
+                if weights[j] > 0:
+                    t = f32(t + f32(f32(weights[j]) * f32(o.ncc_old(px, py, j + 1, pl))))
+            t = f32(t / weight_norm)
+            d = depth_from_plane(K, pl, px, py)
+            if d >= dmin and d <= dmax and t < cost_now:
+                depth_now, plane_now, cost_now = d, pl.copy(), t
+        if params.get("state", 0) == 1:  # REFINE_INIT, :1311-1316: float < float - double
+            if float(cost_now) < float(committed) - 0.1:
+                return plane_now, cost_now, new_sel, rng.words()
+            return plane_c, committed, new_sel, rng.words()
+        return plane_now, cost_now, new_sel, rng.words()
+
+
+def test_strong_update(synth, ob):
+    W, H, N = 36, 28, 3
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=23)
+    for state in (0, 1):
+        prior = None
+        params = common.base_params(sc, N, seed=41 + state, max_iterations=2, state=state)
+        if state == 1:
+            o0 = common.make_oracle(ob, sc, imgs, N, common.base_params(sc, N, seed=3, max_iterations=1, weak_peak_radius=6))
+            o0.run()
+            p0 = common.base_params(sc, N)
+            prior = common.postprocess(o0.planes.copy(), o0.weak_info.copy(), o0.selected_views.copy(), f32(p0["depth_min"]), f32(p0["depth_max"]))
+            o0.close()
+        o = common.make_oracle(ob, sc, imgs, N, params, prior=prior)
+        for kid in (1, 2, 5):
+            o.run_kernel(kid)
+        K = [f32(v) for v in sc.K[0].reshape(-1)]
+        adopted = refined = 0
+        for it in (0, 1):
+            for colour, kid in ((0, 6), (1, 7)):
+                snap = (o.costs.copy(), o.planes.copy(), o.selected_views.copy(), o.rng.copy())
+                weak = o.weak_info.copy()
+                o.run_kernel(kid, it)
+                planes, costs, sel, rng = o.planes, o.costs, o.selected_views, o.rng
+                for py in range(H):
+                    for px in range(W):
+                        if (px + py) % 2 != colour or weak[py, px] == WEAK:
+                            continue
+                        wp, wc, ws, wr = strong_update_pixel(ob, o, snap, W, H, N, params, K, px, py, it)
+                        assert np.array_equal(np.asarray(wp, np.float32).view(np.uint32), planes[py, px].view(np.uint32)), (state, it, colour, px, py)
+                        assert np.float32(wc).view(np.uint32) == costs[py, px].view(np.uint32), (state, it, colour, px, py)
+                        assert int(sel[py, px]) == ws and np.array_equal(rng[py, px], wr), (state, it, colour, px, py)
+                        adopted += int(ws != int(snap[2][py, px]))
+                        refined += int(not np.array_equal(planes[py, px].view(np.uint32), snap[1][py, px].view(np.uint32)))
+        # REFINE_INIT only commits an improvement of more than 0.1 (:1312): few pixels move, both branches occur
+        assert (adopted > 20 and refined > 100) if state == 0 else (adopted > 3 and refined > 20), (state, adopted, refined)
         o.close()
