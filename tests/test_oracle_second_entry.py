@@ -1,5 +1,5 @@
 """Double entry for the control-flow-heavy stages of the path.  The reference ships no tests or vectors and cannot be built
-here, so the oracle (oracle/apd_oracle.c) is pinned by inspection only.  This file is a SECOND restatement of nine stages,
+here, so the oracle (oracle/apd_oracle.c) is pinned by inspection only.  This file is a SECOND restatement of eleven stages,
 written from the reference's text (APD.cu line numbers below) and not from the oracle's: plain Python over numpy binary32
 scalars, one statement per statement.  It shares with the oracle only leaf functions that have their own independent checks --
 the NCC / geometric cost of one (pixel, view, plane) (tests/test_oracle_float64.py), the XORWOW stream (tests/test_rng.py,
@@ -7,14 +7,19 @@ pinned to rocRAND) and the polynomial exp of the arithmetic contract -- and must
 
   * adaptive checkerboard arm search + multi-hypothesis joint view selection of CheckerboardPropagationStrong
     (APD.cu:1012-1259): the view weights of every pixel of a colour;
-  * GenNeighbours, K3 (APD.cu:1750-1969): neighbour table, reliability flags and the random state it leaves behind;
+  * GenNeighbours, K3 (APD.cu:1750-1969): neighbour table, reliability flags and the random state it leaves behind, and
+    NeigbourUpdate, K4 (:1971-1987);
   * the peak classifier of DepthToWeak, K14 (APD.cu:1990-2143): the weak map;
   * RANSACToGetFitPlane, K8 (APD.cu:2272-2384): the fit planes and the random state it leaves behind;
   * LocalRefine, K15 (APD.cu:2146-2232): the depths it adopts;
   * FindNearestStrongPoint, K2 (APD.cu:2234-2270), and GetDepthandNormal + the two median-filter launches, K11-K13
     (APD.cu:1587-1748) with the HALF launch geometry of RunPatchMatch (:2400-2407) on a frame of odd height;
   * the rest of CheckerboardPropagationStrong (APD.cu:1260-1321) with PlaneHypothesisRefinementStrong and its random and
-    perturbed hypotheses (:211-273, :837-890): planes, costs, selected views and random streams after K6 / K7.
+    perturbed hypotheses (:211-273, :837-890): planes, costs, selected views and random streams after K6 / K7;
+  * RandomInitialization, K5 (APD.cu:807-835) with both initial-cost functions (:616-693; `unSetBit` clears the bit and
+    everything below it, :46-49);
+  * CheckerboardPropagationWeak with PlaneHypothesisRefinementWeak, K9 / K10 (APD.cu:1323-1508, :892-980), photometric and with
+    the geometric term: planes, costs, view weights, selected views and random streams of the WEAK pixels.
 
 Two independent transcriptions that agree on every bit do not prove either right, but a slip in one of them (a swapped arm,
 a `<` for a `<=`, a draw out of order) shows up here."""
@@ -428,6 +433,13 @@ def test_gen_neighbours(synth, ob):
             assert np.array_equal(rng_after[py, px], want_rng), (px, py)
             n_reliable += want_rel
     assert n_reliable > 10, "some pixels must get a full neighbour set, or the RANSAC half is not exercised"
+    # NeigbourUpdate, K4 (:1971-1987): a WEAK pixel that K3 did not mark reliable becomes UNKNOWN
+    ys, xs = np.nonzero(weak == WEAK)
+    o.weak_reliable[ys[::3], xs[::3]] = 0   # every pixel of this scene found its neighbours: make a third of them unreliable
+    rel = o.weak_reliable.copy()
+    o.run_kernel(4)
+    want_weak = np.where((weak == WEAK) & (rel != 1), UNKNOWN, weak).astype(np.uint8)
+    assert np.array_equal(o.weak_info, want_weak) and (want_weak != weak).any()
     o.close()
 
 
@@ -1050,3 +1062,253 @@ def test_strong_update(synth, ob):
         # REFINE_INIT only commits an improvement of more than 0.1 (:1312): few pixels move, both branches occur
         assert (adopted > 20 and refined > 100) if state == 0 else (adopted > 3 and refined > 20), (state, adopted, refined)
         o.close()
+
+
+# ---- stage 9: RandomInitialization, K5 (APD.cu:807-835, :275-282, :616-693) -------------------------------------------------
+
+def random_initialization_pixel(ob, o, K, R, params, planes, sel, rng_words, nsrc, px, py):
+    """(plane, cost, selected views, random state) of pixel (px, py) after K5."""
+    dmin, dmax = f32(params["depth_min"]), f32(params["depth_max"])
+    if params.get("state", 0) == 0:  # FIRST_INIT
+        rng = Rng(ob, rng_words)
+        depth = f32(f32(rng.uniform() * f32(dmax - dmin)) + dmin)   # GenerateRandomPlaneHypothesis, :275-282
+        n = random_normal(K, px, py, rng, depth)
+        pl = np.array([n[0], n[1], n[2], distance_to_origin(K, px, py, depth, n)], np.float32)
+        # ComputeMultiViewInitialCostandSelectedViews, :616-662
+        cost_vector = [f32(o.ncc_old(px, py, i + 1, pl)) for i in range(nsrc)]
+        copy = list(cost_vector)
+        valid = sum(1 for c in cost_vector if c < f32(2.0))
+        d = list(cost_vector)   # sort_small over cost_count entries
+        for i in range(1, len(d)):
+            tmp, j = d[i], i
+            while j >= 1 and tmp < d[j - 1]:
+                d[j] = d[j - 1]
+                j -= 1
+            d[j] = tmp
+        top_k = min(valid, int(params.get("top_k", 4)))
+        new_sel = 0
+        if top_k > 0:
+            cost = f32(0)
+            for i in range(top_k):
+                cost = f32(cost + d[i])
+            thr = d[top_k - 1]
+            for i in range(nsrc):
+                if copy[i] <= thr:
+                    new_sel |= 1 << i
+            return pl, f32(cost / f32(top_k)), new_sel, rng.words()
+        return pl, f32(2.0), new_sel, rng.words()
+    # REFINE_*: the prior plane (world normal, depth) back into the camera frame (:823-833); no draw
+    q = normal_to_ref_cam(R, planes[py, px])
+    pl = np.array([q[0], q[1], q[2], distance_to_origin(K, px, py, q[3], q)], np.float32)
+    s, count, cost = int(sel[py, px]), 0, f32(0)
+    for i in range(nsrc):  # ComputeMultiViewInitialCost, :664-693
+        if is_set(s, i):
+            c = f32(o.ncc_old(px, py, i + 1, pl))
+            if c < f32(2.0):
+                count += 1
+                cost = f32(cost + c)
+            else:
+                s &= (0xFFFFFFFE << i) & 0xFFFFFFFF   # unSetBit (:46-49): bit i AND every bit below it
+    return pl, (f32(2.0) if count == 0 else f32(cost / f32(count))), s, np.array(rng_words, np.uint32)
+
+
+def test_random_initialization(synth, ob):
+    W, H, N = 48, 36, 5
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=31, textureless=0.2)
+    K = [f32(v) for v in sc.K[0].reshape(-1)]
+    R = [f32(v) for v in sc.R[0].reshape(-1)]
+    prior = None
+    for state in (0, 2):
+        params = common.base_params(sc, N, seed=51 + state, max_iterations=1, state=state, weak_peak_radius=6)
+        if "top_k" not in params:
+            params["top_k"] = ob.default_params(**params).top_k
+        o = common.make_oracle(ob, sc, imgs, N, params, prior=prior)
+        for kid in (1, 2):
+            o.run_kernel(kid)
+        planes, sel, rng0 = o.planes.copy(), o.selected_views.copy(), o.rng.copy()
+        o.run_kernel(5)
+        cleared = 0
+        with np.errstate(all="ignore"):
+            for py in range(H):
+                for px in range(W):
+                    wp, wc, ws, wr = random_initialization_pixel(ob, o, K, R, params, planes, sel, rng0[py, px], N, px, py)
+                    assert np.array_equal(np.asarray(wp, np.float32).view(np.uint32), o.planes[py, px].view(np.uint32)), (state, px, py)
+                    assert np.float32(wc).view(np.uint32) == o.costs[py, px].view(np.uint32), (state, px, py)
+                    assert int(o.selected_views[py, px]) == ws, (state, px, py, int(o.selected_views[py, px]), ws)
+                    assert np.array_equal(o.rng[py, px], wr), (state, px, py)
+                    cleared += int(state != 0 and ws != int(sel[py, px]))
+        if state == 0:
+            o.run()   # the FIRST_INIT pass gives the prior of the second round
+            p0 = common.base_params(sc, N)
+            prior = common.postprocess(o.planes.copy(), o.weak_info.copy(), o.selected_views.copy(), f32(p0["depth_min"]), f32(p0["depth_max"]))
+        else:
+            assert cleared > 0, "no view failed: the unSetBit path is not exercised"
+        o.close()
+
+
+# ---- stage 10: CheckerboardPropagationWeak + PlaneHypothesisRefinementWeak, K9 / K10 (APD.cu:1323-1508, :892-980) -----------
+
+def weak_update_pixel(ob, o, snap, nb_row, fit_plane, W, H, nsrc, params, K, px, py, it, geom):
+    """(plane, cost, view weights, selected views, random state) of WEAK pixel (px, py) after its K9 / K10 update."""
+    planes, sel, weak, rng_words = snap
+    dmin, dmax = f32(params["depth_min"]), f32(params["depth_max"])
+    gf = f32(params["geom_factor"])
+    cost_array = np.zeros((8, 32), np.float32)
+    cost_array[0, 0] = f32(2.0)   # `= { 2.0f }` (:1345)
+    flag, cand = [False] * 8, [None] * 8
+    for i in range(8):  # :1352-1363
+        qx, qy = int(nb_row[i + 1][0]), int(nb_row[i + 1][1])
+        if qx == -1 or qy == -1 or weak[qy, qx] != STRONG:
+            continue
+        flag[i] = True
+        cand[i] = np.array(planes[qy, qx], np.float32)
+        for v in range(nsrc):
+            cost_array[i, v] = f32(o.ncc_new(px, py, v + 1, cand[i]))
+    priors = np.zeros(32, np.float32)
+    for i in range(8):  # :1371-1385: every neighbour that exists, STRONG or not
+        qx, qy = int(nb_row[i + 1][0]), int(nb_row[i + 1][1])
+        if qx == -1 or qy == -1:
+            continue
+        for j in range(nsrc):
+            priors[j] = f32(priors[j] + (f32(0.9) if is_set(sel[qy, qx], j) == 1 else f32(0.1)))
+    probs = np.zeros(32, np.float32)
+    thr = f32(0.8 * float(expf(ob, f32(it * it) / f32(-90.0))))
+    for i in range(nsrc):
+        count, count_false, tmpw = f32(0), 0, f32(0)
+        for j in range(8):
+            cij = cost_array[j, i]
+            if cij < thr:
+                tmpw = f32(tmpw + expf(ob, f32(f32(cij * cij) / f32(-0.18))))
+                count = f32(count + f32(1))
+            if cij > f32(1.2):
+                count_false += 1
+        if count > 2 and count_false < 3:
+            probs[i] = f32(tmpw / count)
+        elif count_false < 3:
+            probs[i] = expf(ob, f32(f32(thr * thr) / f32(-0.32)))
+        probs[i] = f32(probs[i] * priors[i])
+    s = f32(0)
+    for i in range(nsrc):
+        s = f32(s + probs[i])
+    inv = f32(1.0) / s
+    cum = f32(0)
+    for i in range(nsrc):
+        cum = f32(cum + f32(probs[i] * inv))
+        probs[i] = cum
+    rng = Rng(ob, rng_words[py, px])
+    weights = np.zeros(32, np.uint8)
+    for _ in range(15):
+        rand_prob = f32(rng.uniform() - FLT_EPSILON)
+        for v in range(nsrc):
+            if probs[v] > rand_prob:
+                weights[v] += 1
+                break
+    temp_sel, weight_norm = 0, f32(0)
+    for i in range(nsrc):
+        if weights[i] > 0:
+            temp_sel |= 1 << i
+            weight_norm = f32(weight_norm + f32(weights[i]))
+
+    def weighted(plane, cost_of_view, only_selected):
+        """sum_j w_j * (cost_j [+ geom_factor * geometric cost_j]) in view order"""
+        acc = f32(0)
+        for j in range(nsrc):
+            if only_selected and not weights[j] > 0:
+                continue
+            c = cost_of_view(j)
+            if geom:
+                c = f32(c + f32(gf * (f32(o.geom_cost(px, py, j + 1, plane)) if plane is not None else f32(3.0))))
+            acc = f32(acc + f32(f32(weights[j]) * c))
+        return acc
+
+    final = []
+    for i in range(8):  # :1441-1460
+        acc = weighted(cand[i] if flag[i] else None, lambda j, i=i: cost_array[i, j], True)
+        final.append(f32(acc / weight_norm))
+    best, cmin = 0, final[0]
+    for i in range(1, 8):
+        if final[i] <= cmin:
+            cmin, best = final[i], i
+    plane_c = np.array(planes[py, px], np.float32)
+    cost_now = f32(weighted(plane_c, lambda j: f32(o.ncc_new(px, py, j + 1, plane_c)), False) / weight_norm)  # :1464-1476, every view
+    committed = cost_now
+    depth_now, plane_now, new_sel = depth_from_plane(K, plane_c, px, py), plane_c.copy(), int(sel[py, px])
+    if flag[best]:  # :1480-1488
+        d = depth_from_plane(K, cand[best], px, py)
+        if d >= dmin and d <= dmax and final[best] < cost_now:
+            depth_now, plane_now, cost_now, new_sel = d, cand[best].copy(), final[best], temp_sel
+
+    def try_plane(pl):
+        nonlocal depth_now, plane_now, cost_now
+        t = f32(weighted(pl, lambda j: f32(o.ncc_new(px, py, j + 1, pl)), True) / weight_norm)
+        d = depth_from_plane(K, pl, px, py)
+        if d >= dmin and d <= dmax and t < cost_now:
+            depth_now, plane_now, cost_now = d, pl.copy(), t
+
+    fit = np.array(fit_plane, np.float32)
+    if not (fit[0] == 0 and fit[1] == 0 and fit[2] == 0):  # PlaneHypothesisRefinementWeak, :910-980; no fit plane: no refinement at all
+        try_plane(fit)
+        depth_rand = f32(f32(rng.uniform() * f32(dmax - dmin)) + dmin)
+        n_rand = random_normal(K, px, py, rng, depth_now)
+        lo, hi = f32(f32(f32(1) - f32(0.02)) * depth_now), f32(f32(f32(1) + f32(0.02)) * depth_now)
+        depth_pert = f32(f32(rng.uniform() * f32(hi - lo)) + lo)
+        n_pert = perturbed_normal(ob, K, px, py, plane_now, rng, f32(float(f32(0.02)) * math.pi))
+        depths = [depth_rand, depth_now, depth_rand, depth_now, depth_pert]
+        normals = [tuple(plane_now[:3]), n_rand, n_rand, n_pert, tuple(plane_now[:3])]
+        for dk, nk in zip(depths, normals):
+            try_plane(np.array([nk[0], nk[1], nk[2], distance_to_origin(K, px, py, dk, nk)], np.float32))
+    if params.get("state", 0) == 1:  # REFINE_INIT, :1490-1495
+        plane_final = plane_now if float(cost_now) < float(committed) - 0.1 else plane_c
+    else:
+        plane_final = plane_now
+    rescore = f32(0)  # :1499-1507: the stored cost is the fixed-patch cost of the committed plane over every view
+    for i in range(nsrc):
+        rescore = f32(rescore + f32(f32(weights[i]) * f32(o.ncc_old(px, py, i + 1, plane_final))))
+    return plane_final, f32(rescore / weight_norm), weights, new_sel, rng.words()
+
+
+def test_weak_update(synth, ob):
+    W, H, N = 96, 72, 3
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=12, textureless=0.3)
+    o0 = common.make_oracle(ob, sc, imgs, N, common.base_params(sc, N, seed=5, max_iterations=2, weak_peak_radius=6))
+    o0.run()
+    p0 = common.base_params(sc, N)
+    prior = common.postprocess(o0.planes.copy(), o0.weak_info.copy(), o0.selected_views.copy(), f32(p0["depth_min"]), f32(p0["depth_max"]))
+    o0.close()
+    K = [f32(v) for v in sc.K[0].reshape(-1)]
+    nofit_total = 0
+    for state, geom in ((1, 0), (2, 1)):
+        params = common.base_params(sc, N, seed=60 + state, max_iterations=1, state=state, use_APD=1, weak_peak_radius=6, rotate_time=2,
+                                    ransac_threshold=0.00875, geom_consistency=geom)
+        params["geom_factor"] = ob.default_params(**params).geom_factor
+        depths = common.fake_depth_maps(W, H, N + 1) if geom else None
+        o = common.make_oracle(ob, sc, imgs, N, params, depths=depths, prior=prior)
+        for kid in (1, 2, 3, 4, 5, 6, 7, 8):   # RunPatchMatch's order up to the first weak launch
+            o.run_kernel(kid, 0)
+        nmap, nb, fit = o.neighbours_map.copy(), o.neighbours.copy(), o.fit_planes.copy()
+        moved = refined = nofit = 0
+        for colour, kid in ((0, 9), (1, 10)):
+            snap = (o.planes.copy(), o.selected_views.copy(), o.weak_info.copy(), o.rng.copy())
+            o.run_kernel(kid, 0)
+            with np.errstate(all="ignore"):
+                for py in range(H):
+                    for px in range(W):
+                        if snap[2][py, px] != WEAK:
+                            continue
+                        if (px + py) % 2 != colour:
+                            continue
+                        wp, wc, ww, ws, wr = weak_update_pixel(ob, o, snap, nb[nmap[py, px]], fit[py, px], W, H, N, params, K, px, py, 0, geom)
+                        where = (state, colour, px, py)
+                        assert np.array_equal(np.asarray(wp, np.float32).view(np.uint32), o.planes[py, px].view(np.uint32)), where
+                        assert np.float32(wc).view(np.uint32) == o.costs[py, px].view(np.uint32), where
+                        assert np.array_equal(o.view_weight[py, px], ww), where
+                        assert int(o.selected_views[py, px]) == ws and np.array_equal(o.rng[py, px], wr), where
+                        moved += int(ws != int(snap[1][py, px]))
+                        refined += int(not np.array_equal(o.planes[py, px].view(np.uint32), snap[0][py, px].view(np.uint32)))
+                        nofit += int(not np.any(fit[py, px, :3]))
+        checked = int((snap[2] == WEAK).sum())
+        # REFINE_INIT only commits an improvement of more than 0.1: few planes move there
+        assert checked > 150 and refined > (3 if state == 1 else 20), (state, checked, moved, refined, nofit)
+        nofit_total += nofit
+        o.close()
+    assert nofit_total > 0, "no WEAK pixel without a fit plane: the early return of the refinement is not exercised"
