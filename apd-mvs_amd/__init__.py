@@ -90,6 +90,10 @@ def lib():
     L.apd_destroy.argtypes = [H]
     L.apd_reset.argtypes = [H, C.POINTER(Params)]
     L.apd_upload_views.argtypes = [H, C.c_int, C.POINTER(Camera), fpp, fpp]
+    L.apd_upload_views_split.argtypes = [H, C.c_int, C.POINTER(Camera), fpp]
+    L.apd_upload_depths.argtypes = [H, C.c_int, fpp]
+    L.apd_run_before_depths.argtypes = [H]
+    L.apd_run_after_depths.argtypes = [H]
     L.apd_upload_prior.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
     L.apd_run.argtypes = [H]
     L.apd_run_kernel.argtypes = [H, C.c_int, C.c_int]
@@ -218,6 +222,28 @@ class Handle:
         dp = None if deps is None else (C.c_void_p * n)(*[_ptr(a) for a in deps])
         _check(lib().apd_upload_views(self._h, n, cam_arr, ip, dp))
         self.params.num_images = n
+
+    def upload_views_split(self, cameras, images):
+        """apd_upload_views_split: a geometric pass whose depth maps follow with upload_depths."""
+        n = len(cameras)
+        imgs = [self._as_f32(im) for im in images]
+        self._keep = [imgs, None]
+        cam_arr = (Camera * n)(*cameras)
+        ip = (C.c_void_p * n)(*[_ptr(a) for a in imgs])
+        _check(lib().apd_upload_views_split(self._h, n, cam_arr, ip))
+        self.params.num_images = n
+
+    def upload_depths(self, depths):
+        deps = [self._as_f32(d) for d in depths]
+        dp = (C.c_void_p * len(deps))(*[_ptr(a) for a in deps])
+        _check(lib().apd_upload_depths(self._h, len(deps), dp))
+
+    def run_before_depths(self):
+        _check(lib().apd_run_before_depths(self._h))
+
+    def run_after_depths(self):
+        _check(lib().apd_run_after_depths(self._h))
+        self.synchronize()
 
     def _as_f32(self, a):
         if hasattr(a, "data_ptr"):

@@ -59,6 +59,7 @@ struct apd_context {
     apd_params params{};
     int num_images = 0;
     bool views_uploaded = false;
+    bool depths_pending = false;   // apd_upload_views_split on a geometric pass: the depth maps follow with apd_upload_depths
     bool prior_uploaded = false;
     int weak_count = 0;
     hipStream_t stream = nullptr;
@@ -86,6 +87,10 @@ struct apd_context {
     int weak_list_count[2] = {0, 0};
     bool weak_lists_valid = false;
     bool weak_lists_all_rows = false;  // the valid lists were built for K3 (every row) / for K9, K10 (rows of the HALF launches)
+    // weak_info was rewritten (K14, apd_upload_state) after the upload that sized `neighbours`, the index map and the lists: the
+    // kernels that walk them (K3, K8, K9, K10) are refused until apd_upload_prior / apd_reset -- the reference builds all three
+    // once per object from the map it loads (APD.cpp:526-537) and never runs a second pass on it
+    bool weak_map_stale = false;
     int options[APD_OPT_COUNT] = {0, 1, 1, 1, 1, 1};  // defaults of include/apd_mi355x.h
     int *neighbours_map = nullptr;
     size_t neighbours_cap = 0;
@@ -363,9 +368,11 @@ int apd_reset(apd_handle c, const apd_params *params)
     HIP_TRY(hipSetDevice(c->device));
     c->params = *params;
     c->views_uploaded = false;
+    c->depths_pending = false;
     c->prior_uploaded = false;
     c->weak_count = 0;
     c->weak_lists_valid = false;
+    c->weak_map_stale = false;
     const int st = initial_state(c);
     if (st != APD_OK) {
         return st;
@@ -441,37 +448,28 @@ int apd_set_stream(apd_handle c, void *hip_stream)
     return APD_OK;
 }
 
-int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, const float *const *images, const float *const *depths)
+// Image / camera upload shared by apd_upload_views and apd_upload_views_split.  defer_depths: a geometric pass whose depth
+// maps arrive later (apd_upload_depths): their buffers are allocated here, so that the per-view constants can point at them.
+static int upload_views_impl(apd_context *c, int num_images, const apd_camera *cameras, const float *const *images, const float *const *depths,
+                             bool defer_depths)
 {
-    if (!c || !cameras || !images || num_images < 2) {
-        return fail(APD_ERR_INVALID, "apd_upload_views: bad argument");
-    }
-    if (num_images > APD_MAX_IMAGES) {
-        return fail(APD_ERR_TOO_MANY, "Can't process so much images: %d", num_images);  // APD.cpp:428-431
-    }
-    if (c->params.geom_consistency && !depths) {
-        return fail(APD_ERR_INVALID, "apd_upload_views: geom_consistency needs depth maps");
-    }
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)c->W * c->H;
-    // a recycled handle (apd_reset) keeps its buffers: per-image float planes are reused, the derived texel-quad /
-    // float-quad images are rebuilt below and change kind with the input, so they are released here
-    auto release = [](auto &vec, size_t keep) {
-        for (size_t i = keep; i < vec.size(); ++i) {
-            hipFree(vec[i]);
+    const bool want_depths = depths != nullptr || defer_depths;
+    // A recycled handle (apd_reset) keeps every buffer it ever allocated -- image planes, depth planes and the derived
+    // texel-pair / tiled / float-quad copies, all of one size per handle -- and only allocates what it lacks: hipFree
+    // synchronises the whole device, i.e. every other handle's stream too, and a scheduler with several views in flight on
+    // one device (host/multi_device.cpp) calls this once per (view, pass).  Which copies are valid is decided per upload.
+    auto grow = [](auto &vec, size_t count) {
+        if (vec.size() < count) {
+            vec.resize(count, nullptr);
         }
-        vec.resize(keep);
     };
-    release(c->images, std::min(c->images.size(), (size_t)num_images));
-    release(c->depths, depths ? std::min(c->depths.size(), (size_t)num_images) : 0);
-    release(c->quads, 0);
-    release(c->quads_tiled, 0);
-    release(c->fquads, 0);
-    c->images.resize(num_images, nullptr);
-    c->depths.resize(num_images, nullptr);
-    c->quads.assign(num_images, nullptr);
-    c->quads_tiled.assign(num_images, nullptr);
-    c->fquads.assign(num_images, nullptr);
+    grow(c->images, (size_t)num_images);
+    grow(c->depths, (size_t)num_images);
+    grow(c->quads, (size_t)num_images);
+    grow(c->quads_tiled, (size_t)num_images);
+    grow(c->fquads, (size_t)num_images);
     for (int i = 0; i < num_images; ++i) {
         if (cameras[i].width != c->W || cameras[i].height != c->H) {
             return fail(APD_ERR_INVALID, "apd_upload_views: camera %d is %dx%d, handle is %dx%d", i, cameras[i].width, cameras[i].height,
@@ -481,11 +479,13 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
             HIP_TRY(hipMalloc(&c->images[i], n * sizeof(float)));
         }
         HIP_TRY(hipMemcpyAsync(c->images[i], images[i], n * sizeof(float), hipMemcpyDefault, c->stream));
-        if (depths) {
+        if (want_depths) {
             if (!c->depths[i]) {
                 HIP_TRY(hipMalloc(&c->depths[i], n * sizeof(float)));
             }
-            HIP_TRY(hipMemcpyAsync(c->depths[i], depths[i], n * sizeof(float), hipMemcpyDefault, c->stream));
+            if (depths) {
+                HIP_TRY(hipMemcpyAsync(c->depths[i], depths[i], n * sizeof(float), hipMemcpyDefault, c->stream));
+            }
         }
     }
     // 8-bit input (integers 0..255 in every view)?  Then also keep the source views as texel quads.
@@ -507,7 +507,9 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     if (!c->use_quads) {  // float grey values (e.g. a resampled pyramid level): float texel quads of the source views
         const size_t fn = (size_t)(c->W + 1) * (c->H + 1);
         for (int i = 1; i < num_images; ++i) {
-            HIP_TRY(hipMalloc(&c->fquads[i], fn * sizeof(apd::fquad_t)));
+            if (!c->fquads[i]) {
+                HIP_TRY(hipMalloc(&c->fquads[i], fn * sizeof(apd::fquad_t)));
+            }
             hipError_t e = apd::launch_pack_fquads(c->images[i], c->W, c->H, c->fquads[i], c->stream);
             if (e != hipSuccess) {
                 return fail(APD_ERR_HIP, "k_pack_fquads failed: %s", hipGetErrorString(e));
@@ -517,7 +519,9 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
     if (c->use_quads) {
         const size_t qbytes = apd::quad_image_bytes(c->W, c->H);
         for (int i = 1; i < num_images; ++i) {
-            HIP_TRY(hipMalloc(&c->quads[i], qbytes));
+            if (!c->quads[i]) {
+                HIP_TRY(hipMalloc(&c->quads[i], qbytes));
+            }
             hipError_t e = apd::launch_pack_quads(c->images[i], c->W, c->H, c->quads[i], c->stream);
             if (e != hipSuccess) {
                 return fail(APD_ERR_HIP, "k_pack_quads failed: %s", hipGetErrorString(e));
@@ -530,7 +534,9 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         if (c->have_tiled) {
             const size_t tbytes = apd::quad_tiled_bytes(c->W, c->H);
             for (int i = 1; i < num_images; ++i) {
-                HIP_TRY(hipMalloc(&c->quads_tiled[i], tbytes));
+                if (!c->quads_tiled[i]) {
+                    HIP_TRY(hipMalloc(&c->quads_tiled[i], tbytes));
+                }
                 hipError_t e = apd::launch_pack_quads_tiled(c->images[i], c->W, c->H, c->quads_tiled[i], c->stream);
                 if (e != hipSuccess) {
                     return fail(APD_ERR_HIP, "k_pack_quads_tiled failed: %s", hipGetErrorString(e));
@@ -568,15 +574,69 @@ int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, co
         memcpy(vc.t, src.t, sizeof(vc.t));
         memcpy(vc.c, src.c, sizeof(vc.c));
         vc.img = c->images[v + 1];
-        vc.depth = c->depths[v + 1];
-        vc.quad = c->quads[v + 1];
-        vc.quad_tiled = c->quads_tiled[v + 1];
-        vc.fquad = c->fquads[v + 1];
+        vc.depth = want_depths ? c->depths[v + 1] : nullptr;
+        vc.quad = c->use_quads ? c->quads[v + 1] : nullptr;
+        vc.quad_tiled = c->have_tiled ? c->quads_tiled[v + 1] : nullptr;
+        vc.fquad = c->use_quads ? nullptr : c->fquads[v + 1];
     }
     HIP_TRY(hipMemcpyAsync(c->views_dev, vcs.data(), vcs.size() * sizeof(ViewConst), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->views_uploaded = true;
+    c->depths_pending = defer_depths;
     refresh_frame_args(c);
+    return APD_OK;
+}
+
+static int check_upload_args(apd_context *c, int num_images, const apd_camera *cameras, const float *const *images, const char *who)
+{
+    if (!c || !cameras || !images || num_images < 2) {
+        return fail(APD_ERR_INVALID, "%s: bad argument", who);
+    }
+    if (num_images > APD_MAX_IMAGES) {
+        return fail(APD_ERR_TOO_MANY, "Can't process so much images: %d", num_images);  // APD.cpp:428-431
+    }
+    return APD_OK;
+}
+
+int apd_upload_views(apd_handle c, int num_images, const apd_camera *cameras, const float *const *images, const float *const *depths)
+{
+    const int rc = check_upload_args(c, num_images, cameras, images, "apd_upload_views");
+    if (rc) {
+        return rc;
+    }
+    if (c->params.geom_consistency && !depths) {
+        return fail(APD_ERR_INVALID, "apd_upload_views: geom_consistency needs depth maps");
+    }
+    return upload_views_impl(c, num_images, cameras, images, depths, false);
+}
+
+int apd_upload_views_split(apd_handle c, int num_images, const apd_camera *cameras, const float *const *images)
+{
+    const int rc = check_upload_args(c, num_images, cameras, images, "apd_upload_views_split");
+    if (rc) {
+        return rc;
+    }
+    return upload_views_impl(c, num_images, cameras, images, nullptr, c->params.geom_consistency != 0);
+}
+
+int apd_upload_depths(apd_handle c, int num_images, const float *const *depths)
+{
+    if (!c || !depths) {
+        return fail(APD_ERR_INVALID, "apd_upload_depths: bad argument");
+    }
+    if (!c->views_uploaded || !c->depths_pending) {
+        return fail(APD_ERR_STATE, "apd_upload_depths: no apd_upload_views_split of a geometric pass is waiting for depth maps");
+    }
+    if (num_images != c->num_images) {
+        return fail(APD_ERR_INVALID, "apd_upload_depths: %d depth maps for %d views", num_images, c->num_images);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->W * c->H;
+    for (int i = 0; i < num_images; ++i) {  // on the handle's stream: ordered after the kernels already launched, before the next ones
+        HIP_TRY(hipMemcpyAsync(c->depths[i], depths[i], n * sizeof(float), hipMemcpyDefault, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the sources may be overwritten by their owners as soon as this returns
+    c->depths_pending = false;
     return APD_OK;
 }
 
@@ -612,7 +672,8 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
         HIP_TRY(hipMemsetAsync(c->weak_info, APD_STRONG, n, c->stream));
         HIP_TRY(hipMemsetAsync(c->neighbours_map, 0, n * sizeof(int), c->stream));
     }
-    const size_t need = (size_t)(c->weak_count > 0 ? c->weak_count : 1);
+    // + 1: a pixel behind the last WEAK one maps to index weak_count, and K8 forms (never follows) that address
+    const size_t need = (size_t)c->weak_count + 1;
     if (need > c->neighbours_cap) {
         hipFree(c->neighbours);
         c->neighbours = nullptr;  // a failing re-allocation must not leave a dangling pointer for apd_destroy
@@ -622,7 +683,8 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
     }
     HIP_TRY(hipMemsetAsync(c->neighbours, 0, c->neighbours_cap * APD_NEIGHBOUR_NUM * sizeof(short2), c->stream));
     c->weak_lists_valid = false;
-    if (need > c->weak_list_cap) {  // one colour holds at most every WEAK pixel
+    c->weak_map_stale = false;
+    if (need > c->weak_list_cap) {  // one colour holds at most every WEAK pixel of the map uploaded above (K4 only removes some)
         for (int k = 0; k < 2; ++k) {
             hipFree(c->weak_list[k]);
             c->weak_list[k] = nullptr;
@@ -679,6 +741,15 @@ static int launch_one(apd_context *c, int kernel_id, int iter)
         HIP_TRY(hipEventRecord(pe.start, c->stream));
     }
     hipError_t e;
+    if (c->weak_map_stale && (kernel_id == APD_K3_GEN_NEIGHBOURS || kernel_id == APD_K8_RANSAC_FIT_PLANE ||
+                              kernel_id == APD_K9_BLACK_UPDATE_WEAK || kernel_id == APD_K10_RED_UPDATE_WEAK)) {
+        return fail(APD_ERR_STATE, "kernel %d walks the WEAK lists / neighbour table of the last apd_upload_prior, but weak_info has been "
+                                   "rewritten since (K14 or apd_upload_state): call apd_upload_prior or apd_reset first", kernel_id);
+    }
+    if (c->depths_pending && (kernel_id == APD_K9_BLACK_UPDATE_WEAK || kernel_id == APD_K10_RED_UPDATE_WEAK ||
+                              kernel_id == APD_K14_DEPTH_TO_WEAK || kernel_id == APD_K15_LOCAL_REFINE)) {
+        return fail(APD_ERR_STATE, "kernel %d reads the sources' depth maps (geometric term): call apd_upload_depths first", kernel_id);
+    }
     switch (kernel_id) {
     case APD_K3_GEN_NEIGHBOURS:
     case APD_K9_BLACK_UPDATE_WEAK:
@@ -701,8 +772,9 @@ static int launch_one(apd_context *c, int kernel_id, int iter)
     case APD_K8_RANSAC_FIT_PLANE:
         e = apd::launch_weak_kernel(c->fa, kernel_id, iter, c->stream, nullptr, nullptr);
         break;
-    case APD_K14_DEPTH_TO_WEAK:  // rewrites weak_info
+    case APD_K14_DEPTH_TO_WEAK:  // rewrites weak_info, usually with MORE WEAK pixels than the lists and the table have room for
         c->weak_lists_valid = false;
+        c->weak_map_stale = true;
         e = apd::launch_kernel(c->fa, kernel_id, iter, c->stream);
         break;
     default:
@@ -766,27 +838,96 @@ int apd_run_sweeps(apd_handle c, int first_iter, int iters)
     return APD_OK;
 }
 
-int apd_run(apd_handle c)
+// The schedule of APD::RunPatchMatch (APD.cu:2409-2471) in two halves around the first kernel that reads a source's depth map.
+// The geometric term (ComputeGeomConsistencyCost, APD.cu:752) is only evaluated by the weak update (K9/K10), K14 and K15: the
+// strong sweep, K8 and everything before the loop never touch a depth map.  `first`: K1..K5, iteration 0 of K6..K8 and, while
+// no WEAK pixel exists (no K9/K10), the remaining iterations and K11..K13; `second`: the rest.  Without the geometric term
+// the first half is the whole pass.
+static int run_schedule(apd_context *c, bool first, bool second)
 {
-    int rc = check_ready(c, "apd_run");
+    int rc;
+    const bool geom = c->params.geom_consistency != 0;
+    const bool weak = c->weak_count > 0;
+    const int iters = c->params.max_iterations;
+    // position of the split: number of complete iterations the first half may run, and whether it reaches past K13
+    const int split_iter = !geom ? iters : (weak ? 0 : iters);      // first half runs iterations [0, split_iter) completely
+    const bool head_of_split = geom && weak && iters > 0;             // ... and K6..K8 of iteration split_iter
+    if (first) {
+        if ((rc = launch_one(c, APD_K1_INIT_RANDOM_STATES, 0))) return rc;
+        if ((rc = launch_one(c, APD_K2_FIND_NEAREST_STRONG, 0))) return rc;
+        if (weak) {
+            if ((rc = launch_one(c, APD_K3_GEN_NEIGHBOURS, 0))) return rc;
+            if ((rc = launch_one(c, APD_K4_NEIGHBOUR_UPDATE, 0))) return rc;
+        }
+        if ((rc = launch_one(c, APD_K5_RANDOM_INITIALIZATION, 0))) return rc;
+        if ((rc = apd_run_sweeps(c, 0, split_iter))) return rc;
+        if (head_of_split) {
+            if ((rc = launch_one(c, APD_K6_BLACK_UPDATE_STRONG, split_iter))) return rc;
+            if ((rc = launch_one(c, APD_K7_RED_UPDATE_STRONG, split_iter))) return rc;
+            if ((rc = launch_one(c, APD_K8_RANSAC_FIT_PLANE, split_iter))) return rc;
+        }
+    }
+    if (first && (!geom || !weak)) {  // no depth map is read before K14
+        if ((rc = launch_one(c, APD_K11_GET_DEPTH_NORMAL, 0))) return rc;
+        if ((rc = launch_one(c, APD_K12_BLACK_FILTER, 0))) return rc;
+        if ((rc = launch_one(c, APD_K13_RED_FILTER, 0))) return rc;
+        if (!geom) {
+            if ((rc = launch_one(c, APD_K14_DEPTH_TO_WEAK, 0))) return rc;
+            if ((rc = launch_one(c, APD_K15_LOCAL_REFINE, 0))) return rc;
+        }
+    }
+    if (second && geom) {
+        if (weak) {
+            if (head_of_split) {
+                if ((rc = launch_one(c, APD_K9_BLACK_UPDATE_WEAK, split_iter))) return rc;
+                if ((rc = launch_one(c, APD_K10_RED_UPDATE_WEAK, split_iter))) return rc;
+                if ((rc = apd_run_sweeps(c, split_iter + 1, iters - split_iter - 1))) return rc;
+            }
+            if ((rc = launch_one(c, APD_K11_GET_DEPTH_NORMAL, 0))) return rc;
+            if ((rc = launch_one(c, APD_K12_BLACK_FILTER, 0))) return rc;
+            if ((rc = launch_one(c, APD_K13_RED_FILTER, 0))) return rc;
+        }
+        if ((rc = launch_one(c, APD_K14_DEPTH_TO_WEAK, 0))) return rc;
+        if ((rc = launch_one(c, APD_K15_LOCAL_REFINE, 0))) return rc;
+    }
+    return APD_OK;
+}
+
+static int check_run(apd_context *c, const char *who)
+{
+    int rc = check_ready(c, who);
     if (rc) {
         return rc;
     }
-    // schedule of APD::RunPatchMatch, APD.cu:2409-2471
-    if ((rc = launch_one(c, APD_K1_INIT_RANDOM_STATES, 0))) return rc;
-    if ((rc = launch_one(c, APD_K2_FIND_NEAREST_STRONG, 0))) return rc;
-    if (c->weak_count > 0) {
-        if ((rc = launch_one(c, APD_K3_GEN_NEIGHBOURS, 0))) return rc;
-        if ((rc = launch_one(c, APD_K4_NEIGHBOUR_UPDATE, 0))) return rc;
+    if (c->weak_map_stale) {
+        return fail(APD_ERR_STATE, "%s: this handle already ran a pass (K14 rewrote weak_info): one handle is one (view, pass) like "
+                                   "one APD object; call apd_reset or apd_upload_prior first", who);
     }
-    if ((rc = launch_one(c, APD_K5_RANDOM_INITIALIZATION, 0))) return rc;
-    if ((rc = apd_run_sweeps(c, 0, c->params.max_iterations))) return rc;
-    if ((rc = launch_one(c, APD_K11_GET_DEPTH_NORMAL, 0))) return rc;
-    if ((rc = launch_one(c, APD_K12_BLACK_FILTER, 0))) return rc;
-    if ((rc = launch_one(c, APD_K13_RED_FILTER, 0))) return rc;
-    if ((rc = launch_one(c, APD_K14_DEPTH_TO_WEAK, 0))) return rc;
-    if ((rc = launch_one(c, APD_K15_LOCAL_REFINE, 0))) return rc;
     return APD_OK;
+}
+
+int apd_run(apd_handle c)
+{
+    const int rc = check_run(c, "apd_run");
+    return rc ? rc : run_schedule(c, true, true);
+}
+
+int apd_run_before_depths(apd_handle c)
+{
+    const int rc = check_run(c, "apd_run_before_depths");
+    return rc ? rc : run_schedule(c, true, false);
+}
+
+int apd_run_after_depths(apd_handle c)
+{
+    int rc = check_ready(c, "apd_run_after_depths");
+    if (rc) {
+        return rc;
+    }
+    if (c->depths_pending) {
+        return fail(APD_ERR_STATE, "apd_run_after_depths: the depth maps of this geometric pass have not been uploaded (apd_upload_depths)");
+    }
+    return run_schedule(c, false, true);
 }
 
 int apd_synchronize(apd_handle c)
@@ -882,6 +1023,7 @@ int apd_upload_state(apd_handle c, int which, const void *src, size_t bytes)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (which == APD_STATE_WEAK_INFO) {
         c->weak_lists_valid = false;
+        c->weak_map_stale = true;
     }
     return APD_OK;
 }
@@ -935,6 +1077,15 @@ int apd_get_option(apd_handle c, int option, int *value)
         return fail(APD_ERR_INVALID, "apd_get_option: bad argument");
     }
     *value = c->options[option];
+    return APD_OK;
+}
+
+int apd_get_stream(apd_handle c, void **hip_stream)
+{
+    if (!c || !hip_stream) {
+        return fail(APD_ERR_INVALID, "apd_get_stream: bad argument");
+    }
+    *hip_stream = (void *)c->stream;
     return APD_OK;
 }
 

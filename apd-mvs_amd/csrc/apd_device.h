@@ -607,6 +607,7 @@ struct RefPatch {
     float mean;                  // sum_ref / 36
     float var;                   // sum_ref_ref/36 - mean^2
     __device__ __forceinline__ float at(int i, int j) const { return v[i * kPatchN + j]; }
+    static constexpr bool kRuntimeIndex = false;  // a register array: indices must be compile-time constants
 };
 
 // Same interface with the 36 texels left in the workgroup's LDS tile (clamp-to-edge already applied when the
@@ -616,6 +617,7 @@ struct RefPatchLds {
     const float *base;  // &tile[(ly)*kPitch + lx], i.e. the texel at offset (-radius, -radius)
     float mean, var;
     __device__ __forceinline__ float at(int i, int j) const { return base[(kPatchStep * j) * kPitch + kPatchStep * i]; }
+    static constexpr bool kRuntimeIndex = true;   // LDS: any index
 };
 
 __device__ __forceinline__ void ref_patch_finish(RefPatch &rp)
@@ -967,6 +969,72 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     }
 }
 
+// The kRecipIeee body again, one sample at a time in two rolled loops: the same instructions on the same operands in the same
+// per-lane order (row partial sums, then the total), hence the same bits, for a fraction of the registers and of the code.  The
+// lock-step body keeps six IEEE division sequences in flight -- the register peak of every kernel that inlines it, which the
+// allocator pays for with spills around the (rare) path; this one is slower per call and is only taken when a denominator of the
+// patch leaves the range of the exact fast reciprocal.  Needs a reference patch that can be indexed at run time (LDS).
+#ifndef APD_IEEE_COMPACT
+#define APD_IEEE_COMPACT 1
+#endif
+template <bool kQuad, bool kTiled, typename Ref>
+__device__ __forceinline__ void ncc_fixed_moments_ieee_rolled(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H,
+                                                              int px, int py, float &sum_s, float &sum_ss, float &sum_rs)
+{
+    const global_quad_ptr srcq = (global_quad_ptr)(kTiled ? vc.quad_tiled : vc.quad);
+    const int W = fa.W, Hh = fa.H;
+    const unsigned qpitch = kTiled ? quad_tiles_x(W) : quad_row_pitch_bytes(W);
+    const unsigned fpitch = 16u * (unsigned)(W + 1);
+    const global_fquad_ptr srcf = (global_fquad_ptr)vc.fquad;
+    const int wm1 = W - 1, hm1 = Hh - 1;
+    sum_s = 0.0f;
+    sum_ss = 0.0f;
+    sum_rs = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < kPatchN; ++i) {
+        const float xf = (float)(px + kPatchStep * i - kPatchRadius);
+        const float bx = fmaf(H.h[0], xf, H.h[2]), by = fmaf(H.h[3], xf, H.h[5]), bz = fmaf(H.h[6], xf, H.h[8]);
+        float row_s = 0.0f, row_ss = 0.0f, row_rs = 0.0f;
+#pragma unroll 1
+        for (int j = 0; j < kPatchN; ++j) {
+            const float yf = (float)(py + kPatchStep * j - kPatchRadius);
+            const float z = fmaf(H.h[7], yf, bz);
+            const float r = 1.0f / z;
+            const float X = fmaf(H.h[1], yf, bx) * r, Y = fmaf(H.h[4], yf, by) * r;
+            const float a = __builtin_amdgcn_fractf(X), b = __builtin_amdgcn_fractf(Y);
+            const int qx = med3_i32(cvt_floor_i32(X), -1, wm1), qy = med3_i32(cvt_floor_i32(Y), -1, hm1);
+            float v;
+            if constexpr (kQuad) {
+                const unsigned off = kTiled ? quad_tiled_byte_offset(qx, qy, qpitch) : quad_byte_offset(qx, qy, (int)qpitch, (int)(qpitch + kRowEntryBytes));
+                v = quad_lerp(quad_fetch(srcq, off), a, b);
+            } else {
+                const fquad_t t = fquad_fetch(srcf, fquad_byte_offset(qx, qy, (int)fpitch, (int)(fpitch + 16u)));
+                const float top = fmaf(a, t.y, t.x), bot = fmaf(a, t.w, t.z);
+                v = fmaf(b, bot - top, top);
+            }
+            const float ref = rp.at(i, j);
+            row_s += v;
+            row_ss = fmaf(v, v, row_ss);
+            row_rs = fmaf(ref, v, row_rs);
+        }
+        sum_s += row_s;
+        sum_ss += row_ss;
+        sum_rs += row_rs;
+    }
+}
+
+// The IEEE-division body a kernel should inline: rolled where the reference patch allows it.
+template <bool kQuad, bool kTiled, typename Ref>
+__device__ __forceinline__ void ncc_fixed_moments_ieee(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H, int px,
+                                                       int py, float &sum_s, float &sum_ss, float &sum_rs)
+{
+    if constexpr (APD_IEEE_COMPACT != 0 && Ref::kRuntimeIndex) {
+        ncc_fixed_moments_ieee_rolled<kQuad, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+    } else {
+        ncc_fixed_moments<kQuad, kRecipIeee, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+    }
+}
+
 // True when h6*x + h7*y + h8 is, for every (x, y) of the grid [x0, x1] x [y0, y1], in the range where
 // recip_fast is the correctly rounded reciprocal.  The denominator is evaluated with monotone (rounded)
 // fma, so over the grid it stays between its values at the four corners: if those share a sign and lie
@@ -1001,7 +1069,7 @@ __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const Vie
     if (__builtin_expect(fast_recip, 1)) {
         ncc_fixed_moments<kQuad, kRecipExact, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else {
-        ncc_fixed_moments<kQuad, kRecipIeee, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
+        ncc_fixed_moments_ieee<kQuad, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     }
     const float inv_w = 1.0f / 36.0f;
     sum_s *= inv_w;

@@ -244,26 +244,100 @@ int apd_device_memory(int device, size_t *free_bytes, size_t *total_bytes)
     return APD_OK;
 }
 
-int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes)
+static int rescale_nearest_on(hipStream_t st, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes, const char *who)
 {
     if (!src || !dst || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0) {
-        return xfail(APD_ERR_INVALID, "apd_rescale_nearest_device: bad argument");
+        return xfail(APD_ERR_INVALID, "%s: bad argument", who);
     }
-    X_TRY(hipSetDevice(device));
     if (src_w == dst_w && src_h == dst_h) {  // the reference returns before touching dst (APD.cpp:754-756); callers want the copy
-        X_TRY(hipMemcpy(dst, src, (size_t)src_w * src_h * elem_bytes, hipMemcpyDeviceToDevice));
-        X_TRY(hipStreamSynchronize(nullptr));
+        X_TRY(hipMemcpyAsync(dst, src, (size_t)src_w * src_h * elem_bytes, hipMemcpyDeviceToDevice, st));
         return APD_OK;
     }
     const dim3 grid((dst_w + 255) / 256, dst_h);
     switch (elem_bytes) {
-    case 1: hipLaunchKernelGGL(apd::k_rescale_nearest<uint8_t>, grid, dim3(256), 0, 0, (const uint8_t *)src, src_w, src_h, (uint8_t *)dst, dst_w, dst_h); break;
-    case 4: hipLaunchKernelGGL(apd::k_rescale_nearest<uint32_t>, grid, dim3(256), 0, 0, (const uint32_t *)src, src_w, src_h, (uint32_t *)dst, dst_w, dst_h); break;
-    case 16: hipLaunchKernelGGL(apd::k_rescale_nearest<apd::Bytes16>, grid, dim3(256), 0, 0, (const apd::Bytes16 *)src, src_w, src_h, (apd::Bytes16 *)dst, dst_w, dst_h); break;
-    default: return xfail(APD_ERR_INVALID, "apd_rescale_nearest_device: element size %d (1, 4 or 16 bytes)", elem_bytes);
+    case 1: hipLaunchKernelGGL(apd::k_rescale_nearest<uint8_t>, grid, dim3(256), 0, st, (const uint8_t *)src, src_w, src_h, (uint8_t *)dst, dst_w, dst_h); break;
+    case 4: hipLaunchKernelGGL(apd::k_rescale_nearest<uint32_t>, grid, dim3(256), 0, st, (const uint32_t *)src, src_w, src_h, (uint32_t *)dst, dst_w, dst_h); break;
+    case 16: hipLaunchKernelGGL(apd::k_rescale_nearest<apd::Bytes16>, grid, dim3(256), 0, st, (const apd::Bytes16 *)src, src_w, src_h, (apd::Bytes16 *)dst, dst_w, dst_h); break;
+    default: return xfail(APD_ERR_INVALID, "%s: element size %d (1, 4 or 16 bytes)", who, elem_bytes);
     }
     X_TRY(hipGetLastError());
+    return APD_OK;
+}
+
+int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes)
+{
+    X_TRY(hipSetDevice(device));
+    const int rc = rescale_nearest_on(nullptr, src, src_w, src_h, dst, dst_w, dst_h, elem_bytes, "apd_rescale_nearest_device");
+    if (rc != APD_OK) {
+        return rc;
+    }
     X_TRY(hipDeviceSynchronize());
+    return APD_OK;
+}
+
+int apd_rescale_nearest_async(int device, void *hip_stream, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes)
+{
+    X_TRY(hipSetDevice(device));
+    return rescale_nearest_on((hipStream_t)hip_stream, src, src_w, src_h, dst, dst_w, dst_h, elem_bytes, "apd_rescale_nearest_async");
+}
+
+int apd_device_memcpy_async(int device, void *hip_stream, void *dst, const void *src, size_t bytes)
+{
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)hip_stream));
+    return APD_OK;
+}
+
+int apd_stream_synchronize(int device, void *hip_stream)
+{
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    return APD_OK;
+}
+
+namespace apd {
+__global__ __launch_bounds__(256) void k_split_planes(const float4 *__restrict__ planes, size_t n, float *__restrict__ depth, float *__restrict__ normal)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float4 p = planes[i];
+        depth[i] = p.w;
+        normal[3 * i] = p.x;
+        normal[3 * i + 1] = p.y;
+        normal[3 * i + 2] = p.z;
+    }
+}
+}  // namespace apd
+
+int apd_split_planes_async(int device, void *hip_stream, const float *planes4, size_t pixels, float *depth, float *normal3)
+{
+    if (!planes4 || !depth || !normal3) {
+        return xfail(APD_ERR_INVALID, "apd_split_planes_async: null pointer");
+    }
+    X_TRY(hipSetDevice(device));
+    if (pixels > 0) {
+        hipLaunchKernelGGL(apd::k_split_planes, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                           reinterpret_cast<const float4 *>(planes4), pixels, depth, normal3);
+        X_TRY(hipGetLastError());
+    }
+    return APD_OK;
+}
+
+int apd_host_register(void *p, size_t bytes)
+{
+    if (!p || bytes == 0) {
+        return xfail(APD_ERR_INVALID, "apd_host_register: bad argument");
+    }
+    X_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return APD_OK;
+}
+
+int apd_host_unregister(void *p)
+{
+    if (!p) {
+        return APD_OK;
+    }
+    X_TRY(hipHostUnregister(p));
     return APD_OK;
 }
 

@@ -241,9 +241,11 @@ __global__ __launch_bounds__(1024) void k_fusion_scan(int *__restrict__ counts, 
     }
 }
 
+// Packs the accepted points of a view in raster order as the 15-byte records of the PLY body (x y z float, diffuse_blue /
+// green / red uchar, APD.cpp:214-254): one download per view straight into the file image, no per-point loop on the host.
 __global__ __launch_bounds__(256) void k_fusion_compact(RefTask task, int n, const float *__restrict__ xyz_sparse,
                                                          const uint8_t *__restrict__ bgr_sparse, const int *__restrict__ block_offsets,
-                                                         float *__restrict__ xyz_out, uint8_t *__restrict__ bgr_out)
+                                                         uint8_t *__restrict__ records)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const bool acc = p < n && task.state[p] == kAccepted;
@@ -259,12 +261,17 @@ __global__ __launch_bounds__(256) void k_fusion_compact(RefTask task, int n, con
         for (int w = 0; w < wave; ++w) {
             pos += wave_counts[w];
         }
-        xyz_out[3 * (size_t)pos + 0] = xyz_sparse[3 * (size_t)p + 0];
-        xyz_out[3 * (size_t)pos + 1] = xyz_sparse[3 * (size_t)p + 1];
-        xyz_out[3 * (size_t)pos + 2] = xyz_sparse[3 * (size_t)p + 2];
-        bgr_out[3 * (size_t)pos + 0] = bgr_sparse[3 * (size_t)p + 0];
-        bgr_out[3 * (size_t)pos + 1] = bgr_sparse[3 * (size_t)p + 1];
-        bgr_out[3 * (size_t)pos + 2] = bgr_sparse[3 * (size_t)p + 2];
+        uint8_t *rec = records + (size_t)pos * 15;
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t bits = __float_as_uint(xyz_sparse[3 * (size_t)p + k]);  // little endian, as the host's memcpy wrote them
+            rec[4 * k + 0] = (uint8_t)(bits & 0xFFu);
+            rec[4 * k + 1] = (uint8_t)((bits >> 8) & 0xFFu);
+            rec[4 * k + 2] = (uint8_t)((bits >> 16) & 0xFFu);
+            rec[4 * k + 3] = (uint8_t)(bits >> 24);
+        }
+        rec[12] = bgr_sparse[3 * (size_t)p + 0];
+        rec[13] = bgr_sparse[3 * (size_t)p + 1];
+        rec[14] = bgr_sparse[3 * (size_t)p + 2];
     }
 }
 
@@ -402,7 +409,7 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
         max_src = std::max(max_src, pair_offsets[i + 1] - pair_offsets[i]);
     }
     const int max_blocks = (int)((max_px + 255) / 256);
-    void *vote_idx, *vote_w, *state, *flags, *xyz_sparse, *grey_sparse, *block_counts, *total, *xyz_out, *grey_out;
+    void *vote_idx, *vote_w, *state, *flags, *xyz_sparse, *grey_sparse, *block_counts, *total, *records;
     FUS_TRY(dev_alloc(max_px * max_src * 4, &vote_idx));
     FUS_TRY(dev_alloc(max_px * max_src * 4, &vote_w));
     FUS_TRY(dev_alloc(max_px, &state));
@@ -411,12 +418,9 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
     FUS_TRY(dev_alloc(max_px * 3, &grey_sparse));
     FUS_TRY(dev_alloc((size_t)max_blocks * 4, &block_counts));
     FUS_TRY(dev_alloc(sizeof(int), &total));
-    FUS_TRY(dev_alloc(max_px * 12, &xyz_out));
-    FUS_TRY(dev_alloc(max_px * 3, &grey_out));
+    FUS_TRY(dev_alloc(max_px * 15, &records));
 
     std::vector<uint8_t> body;  // PLY records: x y z float + diffuse_blue/green/red uchar (APD.cpp:214-254)
-    std::vector<float> hxyz;
-    std::vector<uint8_t> hgrey;
     long long count = 0;
     unsigned epoch = 0;
     for (int i = 0; i < num_views; ++i) {
@@ -461,23 +465,15 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
                            (int *)block_counts);
         hipLaunchKernelGGL(k_fusion_scan, dim3(1), dim3(1024), 0, 0, (int *)block_counts, blocks, (int *)total);
         hipLaunchKernelGGL(k_fusion_compact, dim3(blocks), dim3(256), 0, 0, task, n, (const float *)xyz_sparse,
-                           (const uint8_t *)grey_sparse, (const int *)block_counts, (float *)xyz_out, (uint8_t *)grey_out);
+                           (const uint8_t *)grey_sparse, (const int *)block_counts, (uint8_t *)records);
         FUS_TRY(hipGetLastError());
         int npts = 0;
         FUS_TRY(hipMemcpy(&npts, total, sizeof(int), hipMemcpyDeviceToHost));
         (void)rounds;
         if (npts > 0) {
-            hxyz.resize((size_t)npts * 3);
-            hgrey.resize((size_t)npts * 3);
-            FUS_TRY(hipMemcpy(hxyz.data(), xyz_out, (size_t)npts * 12, hipMemcpyDeviceToHost));
-            FUS_TRY(hipMemcpy(hgrey.data(), grey_out, (size_t)npts * 3, hipMemcpyDeviceToHost));
             const size_t base = body.size();
             body.resize(base + (size_t)npts * 15);
-            for (int k = 0; k < npts; ++k) {
-                uint8_t *rec = body.data() + base + (size_t)k * 15;
-                memcpy(rec, &hxyz[3 * (size_t)k], 12);
-                memcpy(rec + 12, &hgrey[3 * (size_t)k], 3);  // diffuse_blue, diffuse_green, diffuse_red
-            }
+            FUS_TRY(hipMemcpy(body.data() + base, records, (size_t)npts * 15, hipMemcpyDeviceToHost));
             count += npts;
         }
     }

@@ -186,11 +186,19 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
             // cost_now of :2022-2051 is computed by the reference but never used by K14's classification
             base_line /= (float)valid;
             const float disp = fa.K[0] * base_line / origin.w;
+            // Samples 0 and NP - 1 are never read: the peak search covers i = 2 .. NP - 3 and looks at i - 1 and i + 1 (:2104-2115),
+            // and pc[min_peak] of :2120 can only be pc[0] when no peak was found, where abs(0 - 30) > weak_peak_radius has already
+            // decided (for every radius below 30; with a larger one the two samples are scored like the rest).  Two of 61 NCC
+            // rounds per selected view less, no state bit changes.
+            const bool skip_ends = fa.early_out && fa.weak_peak_radius < RADIUS;
 #pragma unroll 1
             for (int i = 0; i < NP; ++i) {
                 const float p_depth = fa.K[0] * base_line / (disp + (float)(i - RADIUS));
                 pc[i] = 0.0f;
                 pw[i] = 1.0f;
+                if (skip_ends && (i == 0 || i == NP - 1)) {
+                    continue;
+                }
                 if (!(p_depth < fa.depth_min || p_depth > fa.depth_max)) {
                     in_range |= 1ull << i;
                     pw[i] = distance_to_origin(fa, px, py, p_depth, origin.x, origin.y, origin.z);

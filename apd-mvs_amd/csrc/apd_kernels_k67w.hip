@@ -172,13 +172,11 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 
     const int nsrc = fa.num_src;
     Rng rng = Rng{0, 0, 0, 0, 0, 0};
-    float cost_array[9][NMAX];  // [8] = current plane
-    for (int h = 0; h < 9; ++h) {
-        for (int v = 0; v < NMAX; ++v) {
-            cost_array[h][v] = 0.0f;
-        }
-    }
-    cost_array[0][0] = 2.0f;  // "= { 2.0f }" sets only the first element (APD.cu:1004)
+    // [8] = current plane.  The reference's "= { 2.0f }" (APD.cu:1004) sets element [0][0] to 2 and the rest to 0, and an arm that
+    // falls outside the image keeps those values: the loop below writes them where it skips the NCC instead of clearing the
+    // whole table first -- it lives in scratch memory, and the 9 x NMAX clearing stores per pixel were a third of the launch's
+    // write-back (3.7 of 11.3 GB on configs[1]); columns >= nsrc are never read.
+    float cost_array[9][NMAX];
     int positions[8];
     unsigned flags = 0;
     ViewWeights<NMAX> vw;
@@ -221,6 +219,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K67W_WAVES : APD_K67W_WAVES_F32) v
 #pragma unroll 1
             for (int h = 0; h < 9; ++h) {
                 if (h < 8 && !(flags & (1u << h))) {
+                    cost_array[h][v] = (h == 0 && v == 0) ? 2.0f : 0.0f;
                     continue;
                 }
                 const float4 pl = (h < 8) ? fa.planes[positions[h]] : plane_now;

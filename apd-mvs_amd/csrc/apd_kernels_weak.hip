@@ -556,6 +556,7 @@ struct RefPatchBytes {
         const int idx = i * kPatchN + j;
         return (float)((base[(idx >> 2) * 64] >> (8 * (idx & 3))) & 0xFFu);
     }
+    static constexpr bool kRuntimeIndex = true;
 };
 
 __device__ __forceinline__ RefPatchBytes ref_patch_to_lds(const RefPatch &rp, WeakLds &lds, int lane)

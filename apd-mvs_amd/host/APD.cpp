@@ -12,6 +12,7 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 
 bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height);
 bool DecodeJpegBGR(const uint8_t *data, size_t size, std::vector<uint8_t> &bgr, int &width, int &height);
@@ -186,7 +187,15 @@ static bool read_pgm(const std::vector<uint8_t> &b, Mat &out)
 // disk while the program runs.
 static bool read_gray_image_uncached(const path &stem, Mat &image_float);
 
-bool ReadGrayImage(const path &stem, Mat &image_float)
+static bool read_gray_image_cached(const path &stem, Mat &image_float, bool share);
+
+bool ReadGrayImage(const path &stem, Mat &image_float) { return read_gray_image_cached(stem, image_float, false); }
+
+// The cached matrix itself, not a copy, for callers that only read it (the in-memory scheduler keeps every full-resolution
+// image for the whole run and CheckImages only looks at the size): saves one 4 B/px copy per image and caller.
+bool ReadGrayImageShared(const path &stem, Mat &image_float) { return read_gray_image_cached(stem, image_float, true); }
+
+static bool read_gray_image_cached(const path &stem, Mat &image_float, bool share)
 {
     static std::unordered_map<std::string, Mat> cache;
     static size_t cached_bytes = 0;
@@ -200,7 +209,7 @@ bool ReadGrayImage(const path &stem, Mat &image_float)
         std::lock_guard<std::mutex> lock(cache_mutex);
         auto it = cache.find(key);
         if (it != cache.end()) {
-            image_float = it->second.clone();
+            image_float = share ? it->second : it->second.clone();
             return true;
         }
     }
@@ -210,7 +219,7 @@ bool ReadGrayImage(const path &stem, Mat &image_float)
     const size_t bytes = (size_t)image_float.rows * image_float.step();
     std::lock_guard<std::mutex> lock(cache_mutex);
     if (cached_bytes + bytes <= cap_bytes && cache.find(key) == cache.end()) {
-        cache.emplace(key, image_float.clone());
+        cache.emplace(key, share ? image_float : image_float.clone());
         cached_bytes += bytes;
     }
     return true;
@@ -414,6 +423,15 @@ void ResizeLinear(const Mat &src, Mat &dst, int new_cols, int new_rows)
 static int g_device = -1;
 void APD::SetDevice(int device) { g_device = device; }
 
+static std::unordered_set<int> g_reconstructed;
+static bool g_have_reconstructed = false;
+void APD::SetReconstructedViews(const std::vector<int> &ref_image_ids)
+{
+    g_reconstructed.clear();
+    g_reconstructed.insert(ref_image_ids.begin(), ref_image_ids.end());
+    g_have_reconstructed = true;
+}
+
 static void ApdSafeCall(int rc, const char *what)
 {
     if (rc != APD_OK) {  // reference: CudaSafeCall -> print + exit (APD.cpp:315-323)
@@ -547,12 +565,16 @@ void APD::LoadGeometricDepths()
     if (!params_host.geom_consistency) {
         return;
     }
-    auto load = [&](const path &folder, bool must_exist) {
+    auto load = [&](const path &folder, bool reconstructed) {
         Mat depth;
-        if (!must_exist && !std::filesystem::exists(folder)) {
-            // A source that is not reconstructed itself (no pair.txt entry, hence no result folder): the reference reads a
-            // file that is not there and goes on with an unspecified matrix (APD.cpp:497-506); here the view has no
-            // estimate anywhere (depth 0), which the geometric term prices like any pixel without a depth.
+        if (!reconstructed) {
+            // A source that is not reconstructed itself (no pair.txt entry of its own): the reference reads a file that is not
+            // there and goes on with an unspecified matrix (APD.cpp:497-506); here the view has no estimate anywhere (depth 0),
+            // which the geometric term prices like any pixel without a depth.  Decided by membership in the set of
+            // reference views (SetReconstructedViews), never by what an earlier run left on the disk: main() creates a
+            // result folder for every problem, so a stale folder -- or, after --keep-maps, a stale depths.dmb -- of a
+            // previous, larger run must not turn a source-only view into one with a depth map (the in-memory scheduler
+            // and pipeline.py decide by membership too, and all three must write the same bytes).
             depth.create(height, width, MAT_32FC1);  // zero-filled
             return depth;
         }
@@ -572,7 +594,9 @@ void APD::LoadGeometricDepths()
     };
     depths.push_back(load(problem.result_folder, true));
     for (int src_idx : problem.src_image_ids) {
-        depths.push_back(load(problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx)), false));
+        // without a set (a caller that drives the class directly) every source is expected to have a map, as in the reference
+        const bool reconstructed = !g_have_reconstructed || g_reconstructed.count(src_idx) != 0;
+        depths.push_back(load(problem.dense_folder / path("APD") / path(ToFormatIndex(src_idx)), reconstructed));
     }
 }
 

@@ -131,6 +131,7 @@ template <typename TYPE> void RescaleMatToTargetSize(const Mat &src, Mat &dst, i
 
 // image input: `images/%08d.jpg` decoded to 8-bit grey (APD.cpp:410-413); `.pgm` / `.pfm` accepted too
 bool ReadGrayImage(const path &image_path_without_ext, Mat &image_float);
+bool ReadGrayImageShared(const path &image_path_without_ext, Mat &image_float);  // the process cache's own matrix: read only
 // the same file as cv::imread(IMREAD_COLOR) returns it (fusion colours, APD.cpp:859): MAT_32FC3, blue first
 bool ReadColorImage(const path &image_path_without_ext, Mat &image_bgr);
 // host-side helpers of the drop-in (not in the reference): a small thread pool and a parallel warm-up of the image cache
@@ -162,6 +163,9 @@ public:
 
     // additive: which HIP device this object uses (reference: process-global cudaSetDevice, main.cpp:153)
     static void SetDevice(int device);
+    // additive: the ids of the views this run reconstructs (the reference ids of pair.txt).  A source outside the set is a
+    // source-only view: the geometric term gets a zero depth map for it, whatever an earlier run left in <dense>/APD/.
+    static void SetReconstructedViews(const std::vector<int> &ref_image_ids);
 
 private:
     // the steps of InuputInitialization

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <thread>
 #include <unordered_map>
 
 #include "APD.h"
@@ -78,12 +79,17 @@ void SetFusionDevice(int device) { g_fusion_device = device; }
 // Reads every view's final maps from <dense>/APD/<id>/ and fuses them into APD/APD.ply (APD.cpp:826-977).
 void RunFusion(const path &dense_folder, const std::vector<Problem> &problems) { RunFusionWithMaps(dense_folder, problems, nullptr); }
 
-// The same with the final maps already in memory (host/multi_device.cpp gathers them from the devices): maps[i] belongs to
-// problems[i]; nullptr reads the files.
-void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps)
+// Inputs of the fusion besides the maps: colour image, camera, optional block mask of every view, resampled to the size of
+// the maps when that differs from the image's (RescaleImageAndCamera, APD.cpp:729-750), and the sources of every view as view
+// indices.  maps: host maps (RunFusionWithMaps) or nullptr with map_cols x map_rows > 0 (the maps are on the device) or
+// nullptr with 0 x 0 (read the files).
+namespace {
+
+bool prepare_fusion_inputs(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps, int map_cols,
+                           int map_rows, std::vector<FusionView> &views, std::vector<std::vector<int>> &sources)
 {
-    const auto t_inputs = std::chrono::steady_clock::now();
-    std::vector<FusionView> views(problems.size());
+    const bool on_device = !maps && map_cols > 0 && map_rows > 0;
+    views.assign(problems.size(), FusionView());
     std::unordered_map<int, int> index_of_id;
     const path block_folder = dense_folder / path("blocks");
     const bool use_block = std::filesystem::exists(block_folder);  // APD.cpp:849-853
@@ -102,31 +108,36 @@ void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &pro
         }
         memset(&v.cam, 0, sizeof(v.cam));
         ReadCamera(dense_folder / path("cams") / path(ToFormatIndex(problem.ref_image_id) + "_cam.txt"), v.cam);
-        if (maps) {
-            v.depth = (*maps)[i].depth;
-            v.normal = (*maps)[i].normal;
-            v.weak = (*maps)[i].weak.clone();  // resampled in place below
-        } else {
-            ReadBinMat(problem.result_folder / path("depths.dmb"), v.depth);
-            ReadBinMat(problem.result_folder / path("normals.dmb"), v.normal);
-            ReadBinMat(problem.result_folder / path("weak.bin"), v.weak);
+        int cols = map_cols, rows = map_rows;
+        if (!on_device) {
+            if (maps) {
+                v.depth = (*maps)[i].depth;
+                v.normal = (*maps)[i].normal;
+                v.weak = (*maps)[i].weak.clone();  // resampled in place below
+            } else {
+                ReadBinMat(problem.result_folder / path("depths.dmb"), v.depth);
+                ReadBinMat(problem.result_folder / path("normals.dmb"), v.normal);
+                ReadBinMat(problem.result_folder / path("weak.bin"), v.weak);
+            }
+            if (v.depth.empty() || v.normal.empty() || v.weak.empty()) {
+                std::cerr << "Missing maps of view " << problem.ref_image_id << " in " << problem.result_folder << std::endl;
+                failed[i] = 1;
+                return;
+            }
+            cols = v.depth.cols;
+            rows = v.depth.rows;
         }
-        if (v.depth.empty() || v.normal.empty() || v.weak.empty()) {
-            std::cerr << "Missing maps of view " << problem.ref_image_id << " in " << problem.result_folder << std::endl;
-            failed[i] = 1;
-            return;
-        }
-        if (v.depth.cols != v.image.cols || v.depth.rows != v.image.rows) {  // RescaleImageAndCamera, APD.cpp:729-750
-            const float scale_x = v.depth.cols / static_cast<float>(v.image.cols);
-            const float scale_y = v.depth.rows / static_cast<float>(v.image.rows);
+        if (cols != v.image.cols || rows != v.image.rows) {  // RescaleImageAndCamera, APD.cpp:729-750
+            const float scale_x = cols / static_cast<float>(v.image.cols);
+            const float scale_y = rows / static_cast<float>(v.image.rows);
             // the reference resizes the 8-bit colour image: each channel resampled, then rounded back to 8 bit
-            const size_t n_in = (size_t)v.image.rows * v.image.cols, n_out = (size_t)v.depth.rows * v.depth.cols;
-            Mat out(v.depth.rows, v.depth.cols, MAT_32FC3), plane(v.image.rows, v.image.cols, MAT_32FC1), scaled;
+            const size_t n_in = (size_t)v.image.rows * v.image.cols, n_out = (size_t)rows * cols;
+            Mat out(rows, cols, MAT_32FC3), plane(v.image.rows, v.image.cols, MAT_32FC1), scaled;
             for (int ch = 0; ch < 3; ++ch) {
                 for (size_t k = 0; k < n_in; ++k) {
                     plane.ptr<float>()[k] = v.image.ptr<float>()[3 * k + ch];
                 }
-                ResizeLinear(plane, scaled, v.depth.cols, v.depth.rows);
+                ResizeLinear(plane, scaled, cols, rows);
                 for (size_t k = 0; k < n_out; ++k) {
                     out.ptr<float>()[3 * k + ch] = std::nearbyint(scaled.ptr<float>()[k]);
                 }
@@ -137,13 +148,14 @@ void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &pro
             v.cam.K[4] *= scale_y;
             v.cam.K[5] *= scale_y;
         }
-        v.cam.width = v.depth.cols;
-        v.cam.height = v.depth.rows;
-        RescaleMatToTargetSize<uint8_t>(v.weak, v.weak, v.depth.cols, v.depth.rows);
+        v.cam.width = cols;
+        v.cam.height = rows;
+        if (!on_device) {  // device maps: the weak map already has the size of the depth map
+            RescaleMatToTargetSize<uint8_t>(v.weak, v.weak, cols, rows);
+        }
         if (use_block) {  // blocks/mask_<id>.jpg, read as grey (APD.cpp:871-875); must have the size of the depth map
             Mat grey;
-            if (ReadGrayImage(block_folder / path("mask_" + std::to_string(problem.ref_image_id)), grey) && grey.rows == v.depth.rows &&
-                grey.cols == v.depth.cols) {
+            if (ReadGrayImage(block_folder / path("mask_" + std::to_string(problem.ref_image_id)), grey) && grey.rows == rows && grey.cols == cols) {
                 v.block.create(grey.rows, grey.cols, MAT_8UC1);
                 for (size_t k = 0; k < (size_t)grey.rows * grey.cols; ++k) {
                     v.block.ptr<uint8_t>()[k] = (uint8_t)grey.ptr<float>()[k];
@@ -153,10 +165,10 @@ void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &pro
     }, 0);
     for (int f : failed) {
         if (f) {
-            exit(EXIT_FAILURE);
+            return false;
         }
     }
-    std::vector<std::vector<int>> sources(problems.size());
+    sources.assign(problems.size(), std::vector<int>());
     for (size_t i = 0; i < problems.size(); ++i) {
         std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
         for (int id : problems[i].src_image_ids) {
@@ -168,6 +180,20 @@ void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &pro
             }
         }
     }
+    return true;
+}
+
+}  // namespace
+
+// The same with the final maps already in memory (maps[i] belongs to problems[i]; nullptr reads the files).
+void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps)
+{
+    const auto t_inputs = std::chrono::steady_clock::now();
+    std::vector<FusionView> views;
+    std::vector<std::vector<int>> sources;
+    if (!prepare_fusion_inputs(dense_folder, problems, maps, 0, 0, views, sources)) {
+        exit(EXIT_FAILURE);
+    }
     const path ply_path = dense_folder / path("APD") / path("APD.ply");
     const auto t_fuse = std::chrono::steady_clock::now();
     std::cout << "Fusion inputs ready: " << std::chrono::duration_cast<std::chrono::milliseconds>(t_fuse - t_inputs).count() << " ms" << std::endl;
@@ -177,6 +203,126 @@ void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &pro
         exit(EXIT_FAILURE);  // like every other device error of the reference (CudaSafeCall, APD.cpp:315-323)
     }
     std::cout << "Fused " << n << " points into " << ply_path << std::endl;
+}
+
+// The final maps are on `device` already (host/multi_device.cpp keeps every view's state there and gathers the other devices'
+// into it): only the colour images (and block masks) go up; nothing comes down but the points.  The inputs that do not depend
+// on the passes -- colour decode (cv::imread(IMREAD_COLOR), APD.cpp:859), cameras, masks, their upload -- are prepared on a
+// background thread WHILE the passes run (StartFusionInputs right after the grey images are loaded): at 152 views of 1920 x 1080
+// they take 4 s, as long as half of an 8-device run's passes.
+struct FusionPrefetch {
+    std::thread worker;
+    path dense_folder;
+    std::vector<Problem> problems;
+    int device = 0, cols = 0, rows = 0;
+    std::vector<FusionView> views;
+    std::vector<std::vector<int>> sources;
+    std::vector<void *> owned;
+    std::vector<const float *> imgs;
+    std::vector<const uint8_t *> blocks;
+    bool any_block = false, ok = false;
+    int channels = 3;
+    long long prepare_ms = 0;
+    std::string error;
+};
+
+FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Problem> &problems, int device, int cols, int rows)
+{
+    FusionPrefetch *f = new FusionPrefetch();
+    f->dense_folder = dense_folder;
+    f->problems = problems;
+    f->device = device;
+    f->cols = cols;
+    f->rows = rows;
+    f->worker = std::thread([f]() {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!prepare_fusion_inputs(f->dense_folder, f->problems, nullptr, f->cols, f->rows, f->views, f->sources)) {
+            f->error = "fusion inputs could not be read";
+            return;
+        }
+        const int V = (int)f->views.size();
+        const size_t n = (size_t)f->rows * f->cols;
+        f->channels = (V > 0 && f->views[0].image.type == MAT_32FC3) ? 3 : 1;
+        f->imgs.assign(V, nullptr);
+        f->blocks.assign(V, nullptr);
+        auto upload = [&](const void *host, size_t bytes) -> void * {
+            void *p = nullptr;
+            if (apd_device_malloc(f->device, bytes, &p) != APD_OK || apd_device_memcpy(f->device, p, host, bytes) != APD_OK) {
+                f->error = std::string("fusion: device upload failed: ") + apd_exchange_last_error();
+                return nullptr;
+            }
+            f->owned.push_back(p);
+            return p;
+        };
+        for (int i = 0; i < V; ++i) {
+            f->imgs[i] = (const float *)upload(f->views[i].image.data(), n * 4 * (size_t)f->channels);
+            f->views[i].image = Mat();  // the host copy is done with
+            if (!f->imgs[i]) {
+                return;
+            }
+            if (!f->views[i].block.empty()) {
+                f->blocks[i] = (const uint8_t *)upload(f->views[i].block.data(), n);
+                if (!f->blocks[i]) {
+                    return;
+                }
+                f->any_block = true;
+            }
+        }
+        f->prepare_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        f->ok = true;
+    });
+    return f;
+}
+
+void CancelFusionInputs(FusionPrefetch *f)
+{
+    if (!f) {
+        return;
+    }
+    if (f->worker.joinable()) {
+        f->worker.join();
+    }
+    for (void *p : f->owned) {
+        apd_device_free(f->device, p);
+    }
+    delete f;
+}
+
+void RunFusionOnDevice(FusionPrefetch *f, const std::vector<const float *> &depths, const std::vector<const float *> &normals,
+                       const std::vector<const uint8_t *> &weaks)
+{
+    const auto t_wait = std::chrono::steady_clock::now();
+    f->worker.join();
+    if (!f->ok) {
+        std::cerr << f->error << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    const int V = (int)f->views.size();
+    std::vector<apd_camera> cams(V);
+    std::vector<int> rws(V, f->rows), cls(V, f->cols), offs(V + 1, 0), idx;
+    for (int i = 0; i < V; ++i) {
+        cams[i] = f->views[i].cam;
+        idx.insert(idx.end(), f->sources[i].begin(), f->sources[i].end());
+        offs[i + 1] = (int)idx.size();
+    }
+    if (idx.empty()) {
+        idx.push_back(0);
+    }
+    const path ply_path = f->dense_folder / path("APD") / path("APD.ply");
+    const auto t_fuse = std::chrono::steady_clock::now();
+    std::cout << "Fusion inputs ready: prepared in " << f->prepare_ms << " ms behind the passes, waited "
+              << std::chrono::duration_cast<std::chrono::milliseconds>(t_fuse - t_wait).count() << " ms" << std::endl;
+    long long count = 0;
+    const int st = apd_fuse_views(f->device, V, cams.data(), f->imgs.data(), f->channels, depths.data(), normals.data(), weaks.data(),
+                                  f->any_block ? f->blocks.data() : nullptr, rws.data(), cls.data(), offs.data(), idx.data(), 1, ply_path.string().c_str(), &count);
+    std::cout << "Fusion + PLY: " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_fuse).count() << " ms" << std::endl;
+    const std::string err = st != APD_OK ? apd_fusion_last_error() : "";
+    CancelFusionInputs(f);
+    if (st != APD_OK) {
+        std::cerr << err << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    std::cout << "Fused " << count << " points into " << ply_path << std::endl;
 }
 
 extern "C" {

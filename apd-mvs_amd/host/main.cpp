@@ -164,7 +164,7 @@ bool CheckImages(const std::vector<Problem> &problems, int &width, int &height)
     width = height = 0;
     for (const Problem &p : problems) {
         Mat image;
-        if (!ReadGrayImage(p.dense_folder / "images" / ToFormatIndex(p.ref_image_id), image)) {
+        if (!ReadGrayImageShared(p.dense_folder / "images" / ToFormatIndex(p.ref_image_id), image)) {
             return false;
         }
         if (width == 0) {
@@ -223,6 +223,7 @@ void ProcessProblem(const Problem &problem)
 
 int main(int argc, char **argv)
 {
+    const auto t_start = std::chrono::steady_clock::now();
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
         fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl]\n");
@@ -269,20 +270,32 @@ int main(int argc, char **argv)
             }
         }
     }
+    {
+        std::vector<int> refs;
+        for (const Problem &p : problems) {
+            refs.push_back(p.ref_image_id);
+        }
+        APD::SetReconstructedViews(refs);
+    }
     PrefetchGrayImages(opt.dense_folder / "images", ids);  // decoded once, on several host threads
     if (opt.files && (opt.in_memory || opt.jacobi || opt.devices.size() > 1)) {
         fprintf(stderr, "--files is the single-device driver (no device list, --jacobi or --in-memory)\n");
         return EXIT_FAILURE;
     }
     // `APD dense_folder [gpu]`, the reference's command line: its order of views and its bytes, in memory when the folder fits the
-    // device (every level image, every view's state and two sets of depth maps resident: 4 N + 33 V + 25 bytes per pixel), through the
-    // files otherwise or with --files.
+    // device (InMemoryBytesPerPixel: level images, two sets of depth maps, every view's state, the handles of the views in flight, the
+    // final maps and the fusion's buffers), through the files otherwise or with --files.
     if (!opt.files && !opt.in_memory && !opt.jacobi && opt.devices.size() == 1) {
         int w = 0, h = 0;
         size_t free_bytes = 0, total_bytes = 0;
         if (CheckImages(problems, w, h) && apd_device_memory(opt.gpu_index, &free_bytes, &total_bytes) == APD_OK) {
-            const double need = (double)w * h * (4.0 * ids.size() + 33.0 * problems.size() + 25.0);
-            opt.in_memory = need < 0.6 * (double)free_bytes;
+            size_t max_src = 1;
+            for (const Problem &p : problems) {
+                max_src = std::max(max_src, p.src_image_ids.size());
+            }
+            const int lanes = opt.ranks_per_device > 0 ? opt.ranks_per_device : DefaultLanes((size_t)w * h);
+            const double need = (double)w * h * InMemoryBytesPerPixel((int)ids.size(), (int)problems.size(), 1, lanes, (int)max_src);
+            opt.in_memory = need < 0.9 * (double)free_bytes;
             if (!opt.in_memory) {
                 printf("%.1f GB of resident state against %.1f GB free on device %d: passing state through files\n", need / 1e9,
                        free_bytes / 1e9, opt.gpu_index);
@@ -294,6 +307,8 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
     if (opt.devices.size() > 1 || opt.jacobi || opt.in_memory) {
+        printf("Start-up (pair.txt, image decode on several threads, device query): %lld ms\n",
+               (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count());
         return RunMultiDevice(opt, problems);  // host/multi_device.cpp: in memory, views sharded over the device list
     }
     int width = 0, height = 0;

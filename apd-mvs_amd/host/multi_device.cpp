@@ -1,26 +1,37 @@
-// multi_device.cpp -- `APD dense_folder 0,1,2,3`: the pass table of the reference driver (main.cpp:168-215) on several
-// devices of one node, in memory.
+// multi_device.cpp -- the pass table of the reference driver (main.cpp:168-215) in memory, on one or several devices of one
+// node, with several views in flight per device.
 //
 // The reference takes one device index (main.cpp:149-153), processes the views one after the other and hands state from
 // pass to pass through four files per view; in a geometric pass a view reads its sources' depths.dmb as they are at that
 // moment.  Here:
 //   * rank r of the device list owns the reference views r, r + G, r + 2G, ... (round-robin: neighbouring views are usually
-//     each other's sources) and processes them on its own host thread, through its own handle and stream;
+//     each other's sources).  A rank runs `lanes` views at a time, each on its own host thread, handle and stream: one
+//     view's launches leave a 256-CU device partly idle (a 960 x 540 level is 1.3 rounds of workgroups); the lanes of a
+//     rank share its image and depth buffers;
 //   * planes, weak map and selected views of a view stay on its rank's device from pass to pass (apd_export_state_device ->
 //     apd_upload_prior, device to device); the nearest-neighbour resampling between pyramid levels runs on the device too;
 //   * after every pass the depth maps of all views are all-gathered (apd_exchange_allgather: RCCL over xGMI, or direct peer
 //     copies), which replaces the exchange through depths.dmb; after the last pass the planes (normal + depth) and weak
-//     maps are all-gathered the same way and rank 0's copy goes to the fusion;
-//   * every view of a pass reads the depth maps of the PREVIOUS pass (Jacobi over views; the file-based driver is
-//     Gauss-Seidel), so the result does not depend on the number of ranks: `APD folder 0 --jacobi` and `APD folder 0,0,0`
-//     write the same bytes (tests/test_gpu_dropin_binary.py), while it differs slightly, by construction, from the
-//     single-device file-based order.
+//     maps are all-gathered view by view and rank 0's copy is fused where it lies (apd_fuse_views on device pointers);
+//   * order of views.  `APD folder gpu` (one rank, the default of the drop-in): the REFERENCE's order -- a view of a
+//     geometric pass reads this pass's depth map of every source that precedes it in pair.txt and the previous pass's of
+//     the others (Gauss-Seidel; what the files hold at that moment, main.cpp:117-124, APD.cpp:497-500), so the bytes are
+//     those of the file-based driver.  Views still overlap: a photometric pass has no dependency between views at all
+//     (main.cpp:182), and in a geometric pass only the weak update, K14 and K15 read depth maps (APD.cu:752), so a lane runs
+//     the first half of its view (apd_run_before_depths), waits until its earlier sources have published, uploads the maps
+//     (apd_upload_depths) and runs the rest.  Device lists and --jacobi: every view reads the PREVIOUS pass's maps (Jacobi),
+//     so the result does not depend on the number of ranks or lanes: `APD folder 0 --jacobi` and `APD folder 0,0,0` write
+//     the same bytes (tests/test_gpu_dropin_binary.py), which differ slightly, by construction, from the reference order.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <stdexcept>
 #include <thread>
 #include <unordered_map>
 
@@ -29,12 +40,28 @@
 
 namespace {
 
+// A failing device call ends the run like the reference's CudaSafeCall (APD.cpp:315-323), but not from inside a worker
+// thread whose siblings are mid-launch: the worker records the message and stops, the others stop at their next step, and
+// the thread that joins them prints it and returns the exit code.
+struct Failure {
+    std::atomic<bool> failed{false};
+    std::mutex m;
+    std::string what;
+    void set(const std::string &msg)
+    {
+        std::lock_guard<std::mutex> lock(m);
+        if (!failed.load()) {
+            what = msg;
+            failed.store(true);
+        }
+    }
+};
+
 void Check(int rc, const char *what)
 {
-    if (rc != APD_OK) {  // reference: CudaSafeCall -> print + exit (APD.cpp:315-323)
+    if (rc != APD_OK) {
         const char *a = apd_last_error(), *b = apd_exchange_last_error();
-        fprintf(stderr, "%s failed: %s%s%s\n", what, a ? a : "", (b && b[0]) ? " / " : "", (b && b[0]) ? b : "");
-        exit(EXIT_FAILURE);
+        throw std::runtime_error(std::string(what) + " failed: " + (a ? a : "") + ((b && b[0]) ? " / " : "") + ((b && b[0]) ? b : ""));
     }
 }
 
@@ -66,17 +93,23 @@ struct ResidentView {
     bool valid = false;
 };
 
-struct Rank {
-    int device = 0;
-    std::vector<int> own;            // view indices, ascending
+// one view in flight: host thread + handle + stream
+struct Lane {
     apd_handle handle = nullptr;
     int handle_w = 0, handle_h = 0;
-    std::vector<DeviceBuffer> images;    // level image of every loaded view
-    DeviceBuffer send, recv;         // depth blocks of the all-gather (float)
-    DeviceBuffer depth_level;        // every view's depth map resampled to the current level, when the gathered ones are coarser
-    DeviceBuffer zero_depth;         // a source-only view has no estimate
-    DeviceBuffer scratch_planes, scratch_weak, scratch_views;  // resampling targets
+    DeviceBuffer scratch_planes, scratch_weak, scratch_views;  // resampling targets (swapped with a view's buffers)
+};
+
+struct Rank {
+    int device = 0;
+    std::vector<int> own;                // view indices, ascending
+    std::vector<Lane> lanes;
+    std::vector<char> needs;             // image i is the reference or a source of one of this rank's views
+    std::vector<DeviceBuffer> images;    // level image of every needed view
+    DeviceBuffer send, recv;             // depth blocks of the all-gather (float): this pass's own maps / every view's of the pass before
+    DeviceBuffer zero_depth;             // a source-only view has no estimate
     std::unordered_map<int, ResidentView> state;
+    std::atomic<int> next{0};            // next entry of `own` to hand to a lane
 };
 
 apd_params ToAbi(const PatchMatchParams &q)
@@ -105,9 +138,6 @@ apd_params ToAbi(const PatchMatchParams &q)
     return p;
 }
 
-}  // namespace
-
-namespace {
 struct StageClock {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     long long lap()
@@ -118,12 +148,31 @@ struct StageClock {
         return ms;
     }
 };
+
+// Views in flight per device by frame size (measured on 12 views of 1920 x 1080, profiles/r03/e2e_timing.txt: three lanes 12 % less
+// wall time, 2 % at 6200 x 4130).
 }  // namespace
+
+int DefaultLanes(size_t pixels) { return pixels <= ((size_t)4 << 20) ? 3 : (pixels <= ((size_t)12 << 20) ? 2 : 1); }
+
+// Device bytes an in-memory run keeps resident on its busiest device (rank 0 also fuses): level images, the two sets of
+// depth maps, every owned view's state, per lane the handle's own arrays (state 107 B/px, images + depth maps of the view
+// set, their packed copies -- float quads on the coarse levels) and scratch, and at the end the gathered final maps, their
+// depth / normal split and the fusion's buffers.  Upper bound per pixel of the finest level; main() compares it with the free
+// memory before choosing this scheduler and every in-memory mode checks it again here.
+double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources)
+{
+    const double slots = (double)((num_views + num_ranks - 1) / num_ranks);
+    const double m = (double)max_sources;
+    const double passes = 4.0 * num_images + 4.0 * slots * (1.0 + num_ranks) + 4.0 + 21.0 * slots + lanes * (21.0 + 107.0 + 8.0 * (m + 1.0) + 20.5 * m);
+    const double final_stage = 21.0 * slots + (num_ranks > 1 ? 17.0 * slots * num_ranks : 0.0) + 16.0 * num_views + 21.0 * num_views + 8.0 * m + 40.0;
+    return std::max(passes, final_stage);
+}
 
 int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
 {
     StageClock stage;
-    long long ms_load = 0, ms_setup = 0, ms_passes = 0, ms_gather = 0, ms_fusion = 0;
+    long long ms_load = 0, ms_setup = 0, ms_upload = 0, ms_passes = 0, ms_gather = 0, ms_fusion = 0;
     std::vector<int> devices = opt.devices;
     const int V = (int)problems.size();
     if (devices.empty() || V < 1) {
@@ -133,9 +182,11 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
     // ---- views: the reference views in pair.txt order, then the source-only images (main.cpp) ----
     std::vector<int> ids;
     std::unordered_map<int, int> index_of_id;
+    size_t max_src = 1;
     for (const Problem &p : problems) {
         index_of_id.emplace(p.ref_image_id, (int)ids.size());
         ids.push_back(p.ref_image_id);
+        max_src = std::max(max_src, p.src_image_ids.size());
     }
     for (const Problem &p : problems) {
         for (int s : p.src_image_ids) {
@@ -144,13 +195,17 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             }
         }
     }
+    if (max_src + 1 > MAX_IMAGES) {
+        fprintf(stderr, "Can't process so much images: %zu\n", max_src + 1);  // APD.cpp:428-431
+        return EXIT_FAILURE;
+    }
     const int N = (int)ids.size();
     std::vector<Mat> full(N);
     std::vector<Camera> cams0(N);
     std::vector<int> failed(N, 0);
     ParallelFor((size_t)N, [&](size_t i) {
         memset(&cams0[i], 0, sizeof(Camera));
-        if (!ReadGrayImage(opt.dense_folder / "images" / ToFormatIndex(ids[i]), full[i]) ||
+        if (!ReadGrayImageShared(opt.dense_folder / "images" / ToFormatIndex(ids[i]), full[i]) ||
             !ReadCamera(opt.dense_folder / "cams" / (ToFormatIndex(ids[i]) + "_cam.txt"), cams0[i])) {
             failed[i] = 1;
         }
@@ -164,345 +219,439 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
     ms_load = stage.lap();
     const int W0 = full[0].cols, H0 = full[0].rows;
     const size_t pix0 = (size_t)W0 * H0;
-    // A device takes several scheduler ranks when the frames are small: one view's launches leave a 256-CU device partly idle (a
-    // 960 x 540 level is 1.3 rounds of workgroups), two or three views in flight fill it -- 12 % less wall time on a 12-view 1080p
-    // folder, 2 % at 6200 x 4130 (profiles/r03/e2e_timing.txt), same bytes (Jacobi over views).  --ranks N: exactly N per device.
-    // The device list is repeated as a whole ("0,1,2,3" -> "0,1,2,3,0,1,2,3"): views stay round-robin over the devices, and the
-    // exchange runs RCCL between one leader rank per device and copies inside the devices (csrc/apd_exchange.hip).  A list that
-    // already names a device twice is taken as given.
-    if (!opt.in_memory) {
-        bool distinct = true;
-        for (size_t i = 0; i < devices.size(); ++i) {
-            for (size_t j = 0; j < i; ++j) {
-                distinct = distinct && devices[i] != devices[j];
-            }
-        }
-        int k = opt.ranks_per_device;
-        if (k <= 0) {
-            k = pix0 <= ((size_t)4 << 20) ? 3 : (pix0 <= ((size_t)12 << 20) ? 2 : 1);
-        }
-        k = std::max(1, std::min(k, V / (int)devices.size()));
-        if (distinct && k > 1) {
-            const std::vector<int> once = devices;
-            for (int rep = 1; rep < k; ++rep) {
-                devices.insert(devices.end(), once.begin(), once.end());
-            }
-        }
-    }
     const int G = (int)devices.size();
+    // Views in flight per rank.  A list that names a device more than once (0,0,0: the rank-count test of a one-GPU box) is
+    // taken as given, one view per rank; --ranks N: exactly N per rank.
+    bool distinct = true;
+    for (size_t i = 0; i < devices.size(); ++i) {
+        for (size_t j = 0; j < i; ++j) {
+            distinct = distinct && devices[i] != devices[j];
+        }
+    }
+    int lanes = opt.ranks_per_device > 0 ? opt.ranks_per_device : (distinct ? DefaultLanes(pix0) : 1);
+    lanes = std::max(1, std::min(lanes, (V + G - 1) / G));
+    const bool gauss_seidel = opt.in_memory;  // the reference's order of views (one rank); otherwise Jacobi over views
     const int round_num = opt.single_level ? 1 : RoundNum(W0, H0);
-    printf("There are %d problems needed to be processed on %d rank(s)!\nRound nums: %d\n", V, G, round_num);
-
-    // ---- ranks ----
-    const int slots = (V + G - 1) / G;  // views per rank, padded
-    std::vector<Rank> ranks(G);
-    for (int r = 0; r < G; ++r) {
-        Rank &k = ranks[r];
-        k.device = devices[r];
-        for (int v = r; v < V; v += G) {
-            k.own.push_back(v);
-        }
-        k.images.resize(N);
-        for (int i = 0; i < N; ++i) {
-            k.images[i].alloc(k.device, pix0 * sizeof(float));
-        }
-        k.send.alloc(k.device, (size_t)slots * pix0 * sizeof(float));
-        k.recv.alloc(k.device, (size_t)G * slots * pix0 * sizeof(float));
-        k.depth_level.alloc(k.device, (size_t)V * pix0 * sizeof(float));
-        k.zero_depth.alloc(k.device, pix0 * sizeof(float));
-        Check(apd_device_memset(k.device, k.zero_depth.p, 0, pix0 * sizeof(float)), "apd_device_memset");
-        k.scratch_planes.alloc(k.device, pix0 * 16);
-        k.scratch_weak.alloc(k.device, pix0);
-        k.scratch_views.alloc(k.device, pix0 * 4);
-        for (int v : k.own) {
-            ResidentView &s = k.state[v];
-            s.planes.alloc(k.device, pix0 * 16);
-            s.weak.alloc(k.device, pix0);
-            s.views.alloc(k.device, pix0 * 4);
-        }
-    }
-    const long long ms_alloc = stage.lap();
-    apd_exchange_t exchange = nullptr;
-    // RCCL's set-up costs seconds (5.6 s for one device on the MI355X box, against 4.0 s for all eight passes of a 12-view 1080p
-    // folder) and cannot be overlapped with the passes: ranks that share one device have nothing to send through xGMI and do without
-    // unless --rccl
-    int physical = 0;  // distinct devices of the list
-    for (int i = 0; i < G; ++i) {
-        bool seen = false;
-        for (int j = 0; j < i; ++j) {
-            seen = seen || devices[j] == devices[i];
-        }
-        physical += seen ? 0 : 1;
-    }
-    Check(apd_exchange_create(&exchange, G, devices.data(), (opt.use_rccl && (physical > 1 || opt.force_rccl)) ? 1 : 0), "apd_exchange_create");
-    printf("Device buffers: %lld ms, exchange set-up: %lld ms\n", ms_alloc, stage.lap());
-    printf("Exchange of depth maps between passes: %s\n", apd_exchange_backend(exchange));
-
-    auto block_of_view = [&](const Rank &k, int v, size_t pix) {  // view v inside a gathered block
-        return k.recv.as<float>() + ((size_t)(v % G) * slots + (size_t)(v / G)) * pix;
-    };
-
-    ms_setup = ms_alloc + stage.lap();
-    int level_scale = 0, LW = 0, LH = 0;   // current level
-    int gathered_w = 0, gathered_h = 0;    // size of the depth maps in `recv`
-    std::vector<Camera> cams(N);
-    const auto t_all = std::chrono::steady_clock::now();
-    for (const Pass &pass : BuildSchedule(round_num, opt.single_level)) {
-        // ---- level inputs (APD.cpp:464-488), once per level: resampled on the host, uploaded to every rank ----
-        if (pass.scale_size != level_scale) {
-            level_scale = pass.scale_size;
-            const float factor = 1.0f / (float)level_scale;
-            LW = level_scale == 1 ? W0 : (int)std::round(W0 * factor);
-            LH = level_scale == 1 ? H0 : (int)std::round(H0 * factor);
-            const float sx = LW / static_cast<float>(W0), sy = LH / static_cast<float>(H0);
-            std::vector<Mat> level(N);
-            ParallelFor((size_t)N, [&](size_t i) {
-                if (level_scale == 1) {
-                    level[i] = full[i];
-                } else {
-                    ResizeLinear(full[i], level[i], LW, LH);
-                }
-                cams[i] = cams0[i];
-                if (level_scale != 1) {
-                    cams[i].K[0] *= sx;
-                    cams[i].K[2] *= sx;
-                    cams[i].K[4] *= sy;
-                    cams[i].K[5] *= sy;
-                }
-                cams[i].width = LW;
-                cams[i].height = LH;
-            });
-            for (Rank &k : ranks) {
-                for (int i = 0; i < N; ++i) {
-                    Check(apd_device_memcpy(k.device, k.images[i].p, level[i].ptr<float>(), (size_t)LW * LH * sizeof(float)), "image upload");
-                }
-            }
-            printf("Image size: %d * %d\n", LW, LH);
-        }
-        const size_t pix = (size_t)LW * LH;
-        const bool resample_depths = pass.geom_consistency && (gathered_w != LW || gathered_h != LH);
-
-        // ---- one host thread per rank ----
-        std::vector<std::thread> workers;
-        for (int r = 0; r < G; ++r) {
-            workers.emplace_back([&, r]() {
-                Rank &k = ranks[r];
-                if (resample_depths) {  // the gathered maps are one level coarser (RescaleMatToTargetSize, APD.cpp:503-507)
-                    for (int v = 0; v < V; ++v) {
-                        Check(apd_rescale_nearest_device(k.device, block_of_view(k, v, (size_t)gathered_w * gathered_h), gathered_w, gathered_h,
-                                                         k.depth_level.as<float>() + (size_t)v * pix, LW, LH, 4),
-                              "apd_rescale_nearest_device");
-                    }
-                }
-                for (int v : k.own) {
-                    Problem &problem = problems[v];
-                    Configure(problem, pass, opt);
-                    PatchMatchParams q = problem.params;
-                    q.depth_min = cams0[v].depth_min * 0.6f;   // APD.cpp:454-455
-                    q.depth_max = cams0[v].depth_max * 1.2f;
-                    std::vector<int> order{v};
-                    for (int s : problem.src_image_ids) {
-                        order.push_back(index_of_id.at(s));
-                    }
-                    if (order.size() > MAX_IMAGES) {
-                        fprintf(stderr, "Can't process so much images: %zu\n", order.size());
-                        exit(EXIT_FAILURE);
-                    }
-                    q.num_images = (int)order.size();
-                    const apd_params p = ToAbi(q);
-                    if (!k.handle || k.handle_w != LW || k.handle_h != LH) {
-                        if (k.handle) {
-                            apd_destroy(k.handle);
-                        }
-                        Check(apd_create(&k.handle, k.device, LW, LH, &p), "apd_create");
-                        k.handle_w = LW;
-                        k.handle_h = LH;
-                    } else {
-                        Check(apd_reset(k.handle, &p), "apd_reset");
-                    }
-                    std::vector<Camera> vc;
-                    std::vector<const float *> img, dep;
-                    for (int j : order) {
-                        vc.push_back(cams[j]);
-                        img.push_back(k.images[j].as<float>());
-                        if (pass.geom_consistency) {
-                            if (j >= V) {
-                                dep.push_back(k.zero_depth.as<float>());
-                            } else if (resample_depths) {
-                                dep.push_back(k.depth_level.as<float>() + (size_t)j * pix);
-                            } else {
-                                dep.push_back(block_of_view(k, j, pix));
-                            }
-                        }
-                    }
-                    Check(apd_upload_views(k.handle, (int)order.size(), vc.data(), img.data(), pass.geom_consistency ? dep.data() : nullptr),
-                          "apd_upload_views");
-                    ResidentView &s = k.state[v];
-                    if (pass.state != FIRST_INIT) {  // prior state of the previous pass (APD.cpp:552-581), resampled if the level changed
-                        if (!s.valid) {
-                            fprintf(stderr, "view %d has no state of a previous pass\n", problem.ref_image_id);
-                            exit(EXIT_FAILURE);
-                        }
-                        if (s.W != LW || s.H != LH) {
-                            Check(apd_rescale_nearest_device(k.device, s.planes.p, s.W, s.H, k.scratch_planes.p, LW, LH, 16), "rescale planes");
-                            Check(apd_rescale_nearest_device(k.device, s.weak.p, s.W, s.H, k.scratch_weak.p, LW, LH, 1), "rescale weak");
-                            Check(apd_rescale_nearest_device(k.device, s.views.p, s.W, s.H, k.scratch_views.p, LW, LH, 4), "rescale views");
-                            std::swap(s.planes.p, k.scratch_planes.p);
-                            std::swap(s.weak.p, k.scratch_weak.p);
-                            std::swap(s.views.p, k.scratch_views.p);
-                            s.W = LW;
-                            s.H = LH;
-                        }
-                        Check(apd_upload_prior(k.handle, s.planes.as<float>(), s.views.as<uint32_t>(), pass.use_APD ? s.weak.as<uint8_t>() : nullptr),
-                              "apd_upload_prior");
-                    }
-                    Check(apd_run(k.handle), "apd_run");
-                    const size_t slot = (size_t)(v / G);
-                    Check(apd_export_state_device(k.handle, s.planes.as<float>(), s.weak.as<uint8_t>(), s.views.as<uint32_t>(),
-                                                  k.send.as<float>() + slot * pix),
-                          "apd_export_state_device");
-                    s.W = LW;
-                    s.H = LH;
-                    s.valid = true;
-                    if (opt.in_memory) {
-                        // the reference's order (Gauss-Seidel over views): ProcessProblem writes depths.dmb before the next view of
-                        // the pass reads its sources' (main.cpp:117-124, APD.cpp:497-500) -- the view's new map replaces the
-                        // gathered one at once (one rank: G == 1, slot == v)
-                        Check(apd_device_memcpy(k.device, block_of_view(k, v, pix), k.send.as<float>() + slot * pix, pix * sizeof(float)),
-                              "publish depth");
-                    }
-                    printf("pass %d (round %d, scale %d) view %08d done on rank %d (device %d)\n", pass.iteration, pass.level, pass.scale_size,
-                           problem.ref_image_id, r, k.device);
-                }
-            });
-        }
-        for (std::thread &t : workers) {
-            t.join();
-        }
-        // ---- every rank gets every view's depth map (the reference: depths.dmb files, APD.cpp:497-500) ----
-        std::vector<const void *> send(G);
-        std::vector<void *> recv(G);
-        for (int r = 0; r < G; ++r) {
-            send[r] = ranks[r].send.p;
-            recv[r] = ranks[r].recv.p;
-        }
-        Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)), "apd_exchange_allgather");
-        gathered_w = LW;
-        gathered_h = LH;
-        if (pass.iteration % 4 == 3) {
-            printf("Round: %d done\n", pass.level);
-        }
-        fflush(stdout);
-    }
-
-    ms_passes = stage.lap();
-    // ---- before fusion: planes (world normal + depth) and weak maps of all views on every rank ----
-    const size_t pix = (size_t)LW * LH;
-    std::vector<FinalMaps> maps(V);
+    printf("There are %d problems needed to be processed on %d rank(s), %d view(s) in flight per rank!\nRound nums: %d\n", V, G, lanes, round_num);
     {
-        std::vector<DeviceBuffer> send_pl(G), recv_pl(G), send_wk(G), recv_wk(G);
+        size_t free_bytes = 0, total_bytes = 0;
+        const double need = (double)pix0 * InMemoryBytesPerPixel(N, V, G, lanes, (int)max_src);
+        if (apd_device_memory(devices[0], &free_bytes, &total_bytes) == APD_OK && need > 0.9 * (double)free_bytes) {
+            fprintf(stderr, "%.1f GB of resident state against %.1f GB free on device %d: this folder does not fit the in-memory scheduler "
+                            "(use --files, more devices or fewer views in flight: --ranks 1)\n", need / 1e9, free_bytes / 1e9, devices[0]);
+            return EXIT_FAILURE;
+        }
+    }
+
+    // colour images, cameras and masks of the fusion: decoded and uploaded to rank 0's device behind the passes
+    FusionPrefetch *fusion_inputs = opt.no_fusion ? nullptr : StartFusionInputs(opt.dense_folder, problems, devices[0], W0, H0);
+    Failure failure;
+    std::vector<Rank> ranks(G);
+    apd_exchange_t exchange = nullptr;
+    std::vector<FinalMaps> maps;  // host copies, only with --keep-maps
+    // final maps on the fusion device (rank 0's): per view depth, normal (3 floats), weak
+    std::vector<DeviceBuffer> fuse_depth(V), fuse_normal(V);
+    std::vector<const uint8_t *> fuse_weak(V, nullptr);
+    DeviceBuffer final_planes0, final_weak0;
+    int LW = 0, LH = 0;
+    try {
+        // ---- ranks ----
+        const int slots = (V + G - 1) / G;  // views per rank, padded
         for (int r = 0; r < G; ++r) {
             Rank &k = ranks[r];
+            k.device = devices[r];
+            k.needs.assign(N, 0);
+            for (int v = r; v < V; v += G) {
+                k.own.push_back(v);
+                k.needs[v] = 1;
+                for (int s : problems[v].src_image_ids) {
+                    k.needs[index_of_id.at(s)] = 1;
+                }
+            }
+            k.images.resize(N);
+            for (int i = 0; i < N; ++i) {
+                if (k.needs[i]) {
+                    k.images[i].alloc(k.device, pix0 * sizeof(float));
+                }
+            }
+            k.send.alloc(k.device, (size_t)slots * pix0 * sizeof(float));
+            k.recv.alloc(k.device, (size_t)G * slots * pix0 * sizeof(float));
+            k.zero_depth.alloc(k.device, pix0 * sizeof(float));
+            Check(apd_device_memset(k.device, k.zero_depth.p, 0, pix0 * sizeof(float)), "apd_device_memset");
+            k.lanes.resize(lanes);
+            for (Lane &l : k.lanes) {
+                l.scratch_planes.alloc(k.device, pix0 * 16);
+                l.scratch_weak.alloc(k.device, pix0);
+                l.scratch_views.alloc(k.device, pix0 * 4);
+            }
+            for (int v : k.own) {
+                ResidentView &s = k.state[v];
+                s.planes.alloc(k.device, pix0 * 16);
+                s.weak.alloc(k.device, pix0);
+                s.views.alloc(k.device, pix0 * 4);
+            }
+        }
+        const long long ms_alloc = stage.lap();
+        // RCCL's set-up costs seconds (5.6 s for one device on the MI355X box, against 4.0 s for all eight passes of a 12-view 1080p
+        // folder) and cannot be overlapped with the passes: ranks that share one device have nothing to send through xGMI and do without
+        // unless --rccl
+        int physical = 0;  // distinct devices of the list
+        for (int i = 0; i < G; ++i) {
+            bool seen = false;
+            for (int j = 0; j < i; ++j) {
+                seen = seen || devices[j] == devices[i];
+            }
+            physical += seen ? 0 : 1;
+        }
+        Check(apd_exchange_create(&exchange, G, devices.data(), (opt.use_rccl && (physical > 1 || opt.force_rccl)) ? 1 : 0), "apd_exchange_create");
+        printf("Device buffers: %lld ms, exchange set-up: %lld ms\n", ms_alloc, stage.lap());
+        printf("Exchange of depth maps between passes: %s\n", apd_exchange_backend(exchange));
+
+        auto gathered_depth = [&](const Rank &k, int v, size_t pix) {  // view v inside a gathered block (the pass before)
+            return k.recv.as<float>() + ((size_t)(v % G) * slots + (size_t)(v / G)) * pix;
+        };
+
+        ms_setup = ms_alloc + stage.lap();
+        int level_scale = 0;
+        std::vector<Camera> cams(N);
+        // which pass has published view v's depth map (Gauss-Seidel order only)
+        std::vector<int> done_pass(V, -1);
+        std::mutex done_m;
+        std::condition_variable done_cv;
+        const auto t_all = std::chrono::steady_clock::now();
+        for (const Pass &pass : BuildSchedule(round_num, opt.single_level)) {
+            // ---- level inputs (APD.cpp:464-488), once per level: resampled on the host (one thread per image), uploaded by one
+            // thread per rank from page-locked memory, only the images a rank's views reference ----
+            if (pass.scale_size != level_scale) {
+                StageClock up;
+                level_scale = pass.scale_size;
+                const float factor = 1.0f / (float)level_scale;
+                LW = level_scale == 1 ? W0 : (int)std::round(W0 * factor);
+                LH = level_scale == 1 ? H0 : (int)std::round(H0 * factor);
+                const float sx = LW / static_cast<float>(W0), sy = LH / static_cast<float>(H0);
+                std::vector<Mat> level(N);
+                const size_t level_bytes = (size_t)LW * LH * sizeof(float);
+                std::vector<char> pinned(N, 0);
+                ParallelFor((size_t)N, [&](size_t i) {
+                    if (level_scale == 1) {
+                        level[i] = full[i];
+                    } else {
+                        ResizeLinear(full[i], level[i], LW, LH);
+                    }
+                    cams[i] = cams0[i];
+                    if (level_scale != 1) {
+                        cams[i].K[0] *= sx;
+                        cams[i].K[2] *= sx;
+                        cams[i].K[4] *= sy;
+                        cams[i].K[5] *= sy;
+                    }
+                    cams[i].width = LW;
+                    cams[i].height = LH;
+                    if (G > 1) {  // several devices read the same host buffer: page-lock it once (a single upload gains nothing)
+                        pinned[i] = apd_host_register(level[i].data(), level_bytes) == APD_OK ? 1 : 0;
+                    }
+                });
+                std::vector<std::thread> uploaders;
+                for (int r = 0; r < G; ++r) {
+                    uploaders.emplace_back([&, r]() {
+                        try {
+                            Rank &k = ranks[r];
+                            for (int i = 0; i < N; ++i) {
+                                if (k.needs[i]) {
+                                    Check(apd_device_memcpy(k.device, k.images[i].p, level[i].ptr<float>(), level_bytes), "image upload");
+                                }
+                            }
+                        } catch (const std::exception &e) {
+                            failure.set(e.what());
+                        }
+                    });
+                }
+                for (std::thread &t : uploaders) {
+                    t.join();
+                }
+                for (int i = 0; i < N; ++i) {
+                    if (pinned[i]) {
+                        apd_host_unregister(level[i].data());
+                    }
+                }
+                if (failure.failed) {
+                    throw std::runtime_error(failure.what);
+                }
+                printf("Image size: %d * %d\n", LW, LH);
+                ms_upload += up.lap();
+            }
+            const size_t pix = (size_t)LW * LH;
+
+            // ---- `lanes` host threads per rank, each with its own handle and stream; a rank's views are handed out in order ----
+            std::vector<std::thread> workers;
+            for (int r = 0; r < G; ++r) {
+                ranks[r].next.store(0);
+                for (int li = 0; li < lanes; ++li) {
+                    workers.emplace_back([&, r, li]() {
+                        Rank &k = ranks[r];
+                        Lane &lane = k.lanes[li];
+                        try {
+                            for (;;) {
+                                const int at = k.next.fetch_add(1);
+                                if (at >= (int)k.own.size() || failure.failed) {
+                                    break;
+                                }
+                                const int v = k.own[at];
+                                Problem &problem = problems[v];  // one lane per (view, pass): nobody else touches it
+                                Configure(problem, pass, opt);
+                                PatchMatchParams q = problem.params;
+                                q.depth_min = cams0[v].depth_min * 0.6f;   // APD.cpp:454-455
+                                q.depth_max = cams0[v].depth_max * 1.2f;
+                                std::vector<int> order{v};
+                                for (int s : problem.src_image_ids) {
+                                    order.push_back(index_of_id.at(s));
+                                }
+                                q.num_images = (int)order.size();
+                                const apd_params p = ToAbi(q);
+                                if (!lane.handle || lane.handle_w != LW || lane.handle_h != LH) {
+                                    if (lane.handle) {
+                                        apd_destroy(lane.handle);
+                                        lane.handle = nullptr;
+                                    }
+                                    Check(apd_create(&lane.handle, k.device, LW, LH, &p), "apd_create");
+                                    lane.handle_w = LW;
+                                    lane.handle_h = LH;
+                                } else {
+                                    Check(apd_reset(lane.handle, &p), "apd_reset");
+                                }
+                                void *stream = nullptr;
+                                Check(apd_get_stream(lane.handle, &stream), "apd_get_stream");
+                                std::vector<Camera> vc;
+                                std::vector<const float *> img;
+                                for (int j : order) {
+                                    vc.push_back(cams[j]);
+                                    img.push_back(k.images[j].as<float>());
+                                }
+                                Check(apd_upload_views_split(lane.handle, (int)order.size(), vc.data(), img.data()), "apd_upload_views_split");
+                                ResidentView &s = k.state[v];
+                                if (pass.state != FIRST_INIT) {  // prior state of the previous pass (APD.cpp:552-581), resampled if the level changed
+                                    if (!s.valid) {
+                                        throw std::runtime_error("view " + std::to_string(problem.ref_image_id) + " has no state of a previous pass");
+                                    }
+                                    if (s.W != LW || s.H != LH) {  // on the lane's stream, ahead of the upload that reads the result
+                                        Check(apd_rescale_nearest_async(k.device, stream, s.planes.p, s.W, s.H, lane.scratch_planes.p, LW, LH, 16), "rescale planes");
+                                        Check(apd_rescale_nearest_async(k.device, stream, s.weak.p, s.W, s.H, lane.scratch_weak.p, LW, LH, 1), "rescale weak");
+                                        Check(apd_rescale_nearest_async(k.device, stream, s.views.p, s.W, s.H, lane.scratch_views.p, LW, LH, 4), "rescale views");
+                                        std::swap(s.planes.p, lane.scratch_planes.p);
+                                        std::swap(s.weak.p, lane.scratch_weak.p);
+                                        std::swap(s.views.p, lane.scratch_views.p);
+                                        s.W = LW;
+                                        s.H = LH;
+                                    }
+                                    Check(apd_upload_prior(lane.handle, s.planes.as<float>(), s.views.as<uint32_t>(), pass.use_APD ? s.weak.as<uint8_t>() : nullptr),
+                                          "apd_upload_prior");
+                                }
+                                Check(apd_run_before_depths(lane.handle), "apd_run_before_depths");
+                                if (pass.geom_consistency) {
+                                    // The sources' depth maps: of this pass for the sources that precede the view in the reference's order
+                                    // (they must have published), of the pass before for the others and for the view itself.
+                                    std::vector<const float *> dep;
+                                    for (size_t a = 0; a < order.size(); ++a) {
+                                        const int j = order[a];
+                                        if (j >= V) {
+                                            dep.push_back(k.zero_depth.as<float>());
+                                        } else if (gauss_seidel && a > 0 && j < v) {
+                                            std::unique_lock<std::mutex> lock(done_m);
+                                            done_cv.wait(lock, [&]() { return done_pass[j] >= pass.iteration || failure.failed.load(); });
+                                            dep.push_back(k.send.as<float>() + (size_t)(j / G) * pix);
+                                        } else {
+                                            dep.push_back(gathered_depth(k, j, pix));
+                                        }
+                                    }
+                                    if (failure.failed) {
+                                        break;
+                                    }
+                                    Check(apd_upload_depths(lane.handle, (int)dep.size(), dep.data()), "apd_upload_depths");
+                                }
+                                Check(apd_run_after_depths(lane.handle), "apd_run_after_depths");
+                                const size_t slot = (size_t)(v / G);
+                                Check(apd_export_state_device(lane.handle, s.planes.as<float>(), s.weak.as<uint8_t>(), s.views.as<uint32_t>(),
+                                                              k.send.as<float>() + slot * pix),
+                                      "apd_export_state_device");
+                                s.W = LW;
+                                s.H = LH;
+                                s.valid = true;
+                                {
+                                    std::lock_guard<std::mutex> lock(done_m);
+                                    done_pass[v] = pass.iteration;
+                                    printf("pass %d (round %d, scale %d) view %08d done on rank %d (device %d)\n", pass.iteration, pass.level, pass.scale_size,
+                                           problem.ref_image_id, r, k.device);
+                                }
+                                done_cv.notify_all();
+                            }
+                        } catch (const std::exception &e) {
+                            failure.set(e.what());
+                            done_cv.notify_all();
+                        }
+                    });
+                }
+            }
+            for (std::thread &t : workers) {
+                t.join();
+            }
+            if (failure.failed) {
+                throw std::runtime_error(failure.what);
+            }
+            // ---- every rank gets every view's depth map (the reference: depths.dmb files, APD.cpp:497-500) ----
+            std::vector<const void *> send(G);
+            std::vector<void *> recv(G);
+            for (int r = 0; r < G; ++r) {
+                send[r] = ranks[r].send.p;
+                recv[r] = ranks[r].recv.p;
+            }
+            Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)), "apd_exchange_allgather");
+            if (pass.iteration % 4 == 3) {
+                printf("Round: %d done\n", pass.level);
+            }
+            fflush(stdout);
+        }
+        ms_passes = stage.lap() - ms_upload;
+
+        // ---- before fusion: planes (world normal + depth) and weak maps of all views on every rank, view by view ----
+        const size_t pix = (size_t)LW * LH;
+        for (Rank &k : ranks) {
+            for (Lane &l : k.lanes) {  // handles, level images and depth blocks are no longer needed: room for the final maps
+                if (l.handle) {
+                    apd_destroy(l.handle);
+                    l.handle = nullptr;
+                }
+                l.scratch_planes.release();
+                l.scratch_weak.release();
+                l.scratch_views.release();
+            }
             for (DeviceBuffer &b : k.images) {
                 b.release();
             }
-            k.depth_level.release();
             k.send.release();
             k.recv.release();
-            send_pl[r].alloc(k.device, (size_t)slots * pix * 16);
-            recv_pl[r].alloc(k.device, (size_t)G * slots * pix * 16);
-            send_wk[r].alloc(k.device, (size_t)slots * pix);
-            recv_wk[r].alloc(k.device, (size_t)G * slots * pix);
-            for (int v : k.own) {
-                const ResidentView &s = k.state[v];
-                Check(apd_device_memcpy(k.device, send_pl[r].as<char>() + (size_t)(v / G) * pix * 16, s.planes.p, pix * 16), "pack planes");
-                Check(apd_device_memcpy(k.device, send_wk[r].as<char>() + (size_t)(v / G) * pix, s.weak.p, pix), "pack weak");
+            k.zero_depth.release();
+        }
+        std::vector<const float *> planes_of(V, nullptr);  // on rank 0's device
+        if (G == 1) {  // one rank: everything is where the fusion runs
+            for (int v = 0; v < V; ++v) {
+                planes_of[v] = ranks[0].state[v].planes.as<float>();
+                fuse_weak[v] = ranks[0].state[v].weak.as<uint8_t>();
             }
-        }
-        std::vector<const void *> send(G);
-        std::vector<void *> recv(G);
-        for (int r = 0; r < G; ++r) {
-            send[r] = send_pl[r].p;
-            recv[r] = recv_pl[r].p;
-        }
-        Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * 16), "apd_exchange_allgather (planes)");
-        for (int r = 0; r < G; ++r) {
-            send[r] = send_wk[r].p;
-            recv[r] = recv_wk[r].p;
-        }
-        Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix), "apd_exchange_allgather (weak)");
-        // rank 0's copy goes to the host: depth / normal / weak as ProcessProblem writes them (main.cpp:105-124)
-        std::vector<float> planes(pix * 4);
-        for (int v = 0; v < V; ++v) {
-            const size_t at = (size_t)(v % G) * slots + (size_t)(v / G);
-            Check(apd_device_memcpy(ranks[0].device, planes.data(), recv_pl[0].as<char>() + at * pix * 16, pix * 16), "download planes");
-            FinalMaps &m = maps[v];
-            m.depth.create(LH, LW, MAT_32FC1);
-            m.normal.create(LH, LW, MAT_32FC3);
-            m.weak.create(LH, LW, MAT_8UC1);
-            Check(apd_device_memcpy(ranks[0].device, m.weak.data(), recv_wk[0].as<char>() + at * pix, pix), "download weak");
-            ParallelFor((size_t)LH, [&](size_t row) {
-                float *d = m.depth.ptr<float>((int)row);
-                Vec3f *n = m.normal.ptr<Vec3f>((int)row);
-                const float *src = planes.data() + row * (size_t)LW * 4;
-                for (int c = 0; c < LW; ++c) {
-                    n[c] = Vec3f{{src[4 * c], src[4 * c + 1], src[4 * c + 2]}};
-                    d[c] = src[4 * c + 3];
-                }
-            });
-        }
-        for (int r = 0; r < G; ++r) {
-            send_pl[r].release();
-            recv_pl[r].release();
-            send_wk[r].release();
-            recv_wk[r].release();
-        }
-    }
-    if (opt.keep_maps) {  // the four files of ProcessProblem (main.cpp:117-124)
-        for (int v = 0; v < V; ++v) {
-            Rank &k = ranks[v % G];
-            Mat views(LH, LW, MAT_32SC1);
-            Check(apd_device_memcpy(k.device, views.data(), k.state[v].views.p, pix * 4), "download views");
-            std::filesystem::create_directories(problems[v].result_folder);
-            const Mat *out[4] = {&maps[v].depth, &maps[v].normal, &maps[v].weak, &views};
-            for (int f = 0; f < 4; ++f) {
-                if (!WriteBinMat(problems[v].result_folder / kStateFiles[f], *out[f])) {
-                    fprintf(stderr, "cannot write %s\n", (problems[v].result_folder / kStateFiles[f]).string().c_str());
-                    return EXIT_FAILURE;
+        } else {
+            // One all-gather per slot straight out of the views' state buffers into [slot][rank] blocks, i.e. view order
+            // (view v = slot * G + rank); a rank without a view in the last slot sends its first view's buffer as padding.
+            std::vector<DeviceBuffer> all_planes(G), all_weak(G), padding(G);
+            for (int r = 0; r < G; ++r) {
+                all_planes[r].alloc(ranks[r].device, (size_t)slots * G * pix * 16);
+                all_weak[r].alloc(ranks[r].device, (size_t)slots * G * pix);
+                if ((int)ranks[r].own.size() < slots) {
+                    padding[r].alloc(ranks[r].device, pix * 16);
                 }
             }
+            std::vector<const void *> send(G);
+            std::vector<void *> recv(G);
+            for (int sl = 0; sl < slots; ++sl) {
+                for (int pass_kind = 0; pass_kind < 2; ++pass_kind) {
+                    const size_t elem = pass_kind == 0 ? 16 : 1;
+                    for (int r = 0; r < G; ++r) {
+                        Rank &k = ranks[r];
+                        if ((size_t)sl < k.own.size()) {
+                            const ResidentView &s = k.state[k.own[sl]];
+                            send[r] = pass_kind == 0 ? s.planes.p : s.weak.p;
+                        } else {
+                            send[r] = padding[r].p;
+                        }
+                        recv[r] = (pass_kind == 0 ? all_planes[r].as<char>() : all_weak[r].as<char>()) + (size_t)sl * G * pix * elem;
+                    }
+                    Check(apd_exchange_allgather(exchange, send.data(), recv.data(), pix * elem), "apd_exchange_allgather (final maps)");
+                }
+            }
+            for (int v = 0; v < V; ++v) {
+                planes_of[v] = all_planes[0].as<float>() + (size_t)v * pix * 4;
+                fuse_weak[v] = all_weak[0].as<uint8_t>() + (size_t)v * pix;
+            }
+            final_planes0 = all_planes[0];
+            final_weak0 = all_weak[0];
+            all_planes[0].p = all_weak[0].p = nullptr;  // kept for the fusion; the other ranks' copies are done with
+            for (int r = 0; r < G; ++r) {
+                all_planes[r].release();
+                all_weak[r].release();
+                padding[r].release();
+            }
         }
+        for (int v = 0; v < V; ++v) {  // depth + normal maps as the fusion takes them (main.cpp:105-124 writes the same split)
+            fuse_depth[v].alloc(ranks[0].device, pix * 4);
+            fuse_normal[v].alloc(ranks[0].device, pix * 12);
+            Check(apd_split_planes_async(ranks[0].device, nullptr, planes_of[v], pix, fuse_depth[v].as<float>(), fuse_normal[v].as<float>()), "apd_split_planes_async");
+        }
+        Check(apd_stream_synchronize(ranks[0].device, nullptr), "apd_stream_synchronize");
+        if (opt.keep_maps) {  // the four files of ProcessProblem (main.cpp:117-124)
+            maps.resize(V);
+            for (int v = 0; v < V; ++v) {
+                Rank &k = ranks[v % G];
+                FinalMaps &m = maps[v];
+                m.depth.create(LH, LW, MAT_32FC1);
+                m.normal.create(LH, LW, MAT_32FC3);
+                m.weak.create(LH, LW, MAT_8UC1);
+                Mat views(LH, LW, MAT_32SC1);
+                Check(apd_device_memcpy(ranks[0].device, m.depth.data(), fuse_depth[v].p, pix * 4), "download depth");
+                Check(apd_device_memcpy(ranks[0].device, m.normal.data(), fuse_normal[v].p, pix * 12), "download normals");
+                Check(apd_device_memcpy(ranks[0].device, m.weak.data(), fuse_weak[v], pix), "download weak");
+                Check(apd_device_memcpy(k.device, views.data(), k.state[v].views.p, pix * 4), "download views");
+                std::filesystem::create_directories(problems[v].result_folder);
+                const Mat *out[4] = {&m.depth, &m.normal, &m.weak, &views};
+                for (int f = 0; f < 4; ++f) {
+                    if (!WriteBinMat(problems[v].result_folder / kStateFiles[f], *out[f])) {
+                        throw std::runtime_error("cannot write " + (problems[v].result_folder / kStateFiles[f]).string());
+                    }
+                }
+            }
+        }
+        {
+            int with_rccl = 0, with_copies = 0;
+            apd_exchange_counts(exchange, &with_rccl, &with_copies);
+            printf("Exchanges: %d through RCCL, %d through direct copies\n", with_rccl, with_copies);
+        }
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_all).count();
+        printf("All passes done: %lld ms\n", (long long)ms);
+        ms_gather = stage.lap();
+        if (!opt.no_fusion) {
+            std::filesystem::create_directories(opt.dense_folder / "APD");
+            std::vector<const float *> d(V), n(V);
+            for (int v = 0; v < V; ++v) {
+                d[v] = fuse_depth[v].as<float>();
+                n[v] = fuse_normal[v].as<float>();
+            }
+            if (LW != W0 || LH != H0) {
+                throw std::runtime_error("the last pass did not run at the full resolution");  // BuildSchedule ends at scale 1
+            }
+            RunFusionOnDevice(fusion_inputs, d, n, fuse_weak);
+            fusion_inputs = nullptr;
+        }
+        ms_fusion = stage.lap();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s\n", e.what());
+        fflush(stderr);
+        CancelFusionInputs(fusion_inputs);
+        // device memory goes with the process (the reference exits at the failing call, APD.cpp:315-323)
+        return EXIT_FAILURE;
     }
     for (Rank &k : ranks) {
-        if (k.handle) {
-            apd_destroy(k.handle);
-        }
         for (auto &kv : k.state) {
             kv.second.planes.release();
             kv.second.weak.release();
             kv.second.views.release();
         }
-        k.zero_depth.release();
-        k.scratch_planes.release();
-        k.scratch_weak.release();
-        k.scratch_views.release();
     }
-    {
-        int with_rccl = 0, with_copies = 0;
-        apd_exchange_counts(exchange, &with_rccl, &with_copies);
-        printf("Exchanges: %d through RCCL, %d through direct copies\n", with_rccl, with_copies);
+    for (int v = 0; v < V; ++v) {
+        fuse_depth[v].release();
+        fuse_normal[v].release();
     }
+    final_planes0.release();
+    final_weak0.release();
     apd_exchange_destroy(exchange);
-    const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_all).count();
-    printf("All passes done: %lld ms\n", (long long)ms);
-    ms_gather = stage.lap();
-    if (!opt.no_fusion) {
-        std::filesystem::create_directories(opt.dense_folder / "APD");
-        RunFusionWithMaps(opt.dense_folder, problems, &maps);
-    }
-    ms_fusion = stage.lap();
-    printf("Stages: images + cameras %lld ms, device set-up %lld ms, passes %lld ms, final gather + maps %lld ms, fusion %lld ms\n", ms_load,
-           ms_setup, ms_passes, ms_gather, ms_fusion);
+    printf("Stages: images + cameras %lld ms, device set-up %lld ms, level images (resample + upload) %lld ms, passes %lld ms, final gather + maps %lld ms, "
+           "fusion %lld ms\n", ms_load, ms_setup, ms_upload, ms_passes, ms_gather, ms_fusion);
     printf("All done\n");
     return EXIT_SUCCESS;
 }

@@ -100,10 +100,23 @@ static const char *const kStateFiles[4] = {"depths.dmb", "normals.dmb", "weak.bi
 // all-gathered after every pass.  Returns the process exit code.
 int RunMultiDevice(const Options &opt, std::vector<Problem> &problems);
 
+// Views in flight per device by frame size, and the device bytes per pixel (finest level) the in-memory scheduler keeps resident
+// on its busiest device (host/multi_device.cpp).
+int DefaultLanes(size_t pixels);
+double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources);
+
 // APD.h:34 with the maps already in memory (index = problem index); RunFusion reads them from the result folders instead
 struct FinalMaps {
     Mat depth, normal, weak;
 };
 void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps);
+// ... and with the final maps resident on `device` (cols x rows each; depth, normal = 3 floats per pixel, weak): nothing is
+// downloaded.  StartFusionInputs decodes the colour images, reads cameras and masks and uploads them on a background thread
+// (call it before the passes); RunFusionOnDevice joins it and fuses; CancelFusionInputs joins and frees without fusing.
+struct FusionPrefetch;
+FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Problem> &problems, int device, int cols, int rows);
+void RunFusionOnDevice(FusionPrefetch *inputs, const std::vector<const float *> &depths, const std::vector<const float *> &normals,
+                       const std::vector<const uint8_t *> &weaks);
+void CancelFusionInputs(FusionPrefetch *inputs);
 
 #endif  // APD_MI355X_HOST_SCHEDULE_H_

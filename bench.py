@@ -39,6 +39,7 @@ VALU_CYCLES_PER_WAVE_INST = 2.0
 VALU_PEAK_GINST = NUM_SIMDS * MAX_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INST  # G wave64 instructions / s
 TCP_ACCESSES_PER_CLOCK = 1.85  # L1 tag accesses per clock and CU with every access a hit (profiles/r02/unaligned_gather.txt: 59 in 32 cycles)
 
+DEFAULT_WORKLOAD = "eth3d_office_fullres_8src"
 WORKLOADS = {
     # name: (width, height, num_src)
     "eth3d_office_fullres_8src": (6200, 4130, 8),    # BASELINE.json configs[1]
@@ -81,7 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="eth3d_office_fullres_8src",
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD,
                     help="one of %s, or custom_<W>x<H>_<N>src[_apd]" % ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1024x768", help="WxH of the CPU-baseline sample")
@@ -89,6 +90,8 @@ def parse_args(argv=None):
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="apd_set_option on the handle (A/B runs), e.g. --opt k67_windows=0; names: fast_rcp early_out source_quads "
                          "tiled_copy k67_windows k1415_windows.  Reported in config.options")
+    ap.add_argument("--no-workloads", action="store_true", help="headline only: skip the `workloads` block (the other BASELINE configs)")
+    ap.add_argument("--only-workloads", action="append", default=[], metavar="KEY", help="restrict the `workloads` block to these keys")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher / collective plumbing only, on CPU with gloo: no PatchMatch work is done or reported "
                          "(value is null); used by tests/test_bench_launcher.py to cover the --gpus N spawn path without GPUs")
@@ -119,7 +122,410 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+class Ctx:
+    """What every measurement of one process shares: package, device, rank layout, process group."""
+
+    def __init__(self, pkg, synth, np, torch, dev, rank, world, distributed, dist):
+        self.pkg, self.synth, self.np, self.torch = pkg, synth, np, torch
+        self.dev, self.rank, self.world, self.distributed, self.dist = dev, rank, world, distributed, dist
+
+    def barrier(self, handles=()):
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        for h in handles:
+            h.synchronize()
+
+    def max_over_ranks(self, values):
+        if not self.distributed:
+            return [float(v) for v in values]
+        t = self.torch.tensor(list(values), device=self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def gather_scalar(self, value):
+        if not self.distributed:
+            return [float(value)]
+        out = self.torch.zeros(self.world, device=self.dev, dtype=self.torch.float64)
+        self.dist.all_gather_into_tensor(out, self.torch.tensor([value], device=self.dev, dtype=self.torch.float64))
+        return [float(v) for v in out.tolist()]
+
+
+class SweepWorkload:
+    """One reference view per owned slot of a named workload, inputs resident in HBM: scene, handle, (APD: the prior of an
+    untimed FIRST_INIT pass).  measure() times iterations 0..K-1 of a freshly initialised pass, any number of times."""
+
+    def __init__(self, ctx, name, max_iters, opts=(), seed=12345, views_per_gpu=1):
+        pkg, torch, np = ctx.pkg, ctx.torch, ctx.np
+        self.ctx, self.name, self.opts, self.seed = ctx, name, list(opts), seed
+        (self.W, self.H, self.N), self.apd_mode = resolve_workload(name)
+        W, H, N = self.W, self.H, self.N
+        t0 = time.perf_counter()
+        self.handles, self.priors, self.gt = [], [], []
+        self.weak_fraction = 0.0
+        for slot in range(views_per_gpu):
+            # every rank owns different reference views of the same camera ring (round-robin, as the schedulers shard them)
+            view = ctx.rank + slot * ctx.world
+            sc = ctx.synth.make_scene(W, H, N, seed=0, ref_view=view, device=ctx.dev, textureless=0.2 if self.apd_mode else 0.0)
+            cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+            dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
+            prior = None
+            if not self.apd_mode:
+                params = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0,
+                                            state=pkg.FIRST_INIT, max_iterations=max_iters, seed=seed)
+                h = pkg.Handle(W, H, params, device=ctx.dev.index)
+                apply_options(h, self.opts)
+                h.upload_views(cams, sc.images)  # device->device copies: inputs are resident in HBM before timing
+            else:
+                # untimed: the photometric FIRST_INIT pass of main.cpp:169-190 (3 iterations, weak_peak_radius 6) that
+                # classifies pixels, then ProcessProblem's post-processing (main.cpp:105-115)
+                p0 = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0, state=pkg.FIRST_INIT,
+                                        max_iterations=3, weak_peak_radius=6, seed=seed)
+                h0 = pkg.Handle(W, H, p0, device=ctx.dev.index)
+                h0.upload_views(cams, sc.images)
+                h0.run()
+                planes, weak, views = h0.download()
+                h0.close()
+                bad = (planes[..., 3] < np.float32(dmin)) | (planes[..., 3] > np.float32(dmax))
+                planes[..., 3][bad] = 0
+                weak[bad] = pkg.UNKNOWN
+                params = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=1, state=pkg.REFINE_INIT,
+                                            max_iterations=max_iters, weak_peak_radius=6, rotate_time=4,
+                                            ransac_threshold=0.01 - 0.00125 * 3, seed=seed + 1)
+                h = pkg.Handle(W, H, params, device=ctx.dev.index)
+                apply_options(h, self.opts)
+                h.upload_views(cams, sc.images)
+                prior = (planes, views, weak)
+            self.handles.append(h)
+            self.priors.append(prior)
+            self.gt.append(sc.gt_depth)
+            del sc.images[:]
+            del sc
+        torch.cuda.empty_cache()
+        self.init_pass()
+        if self.apd_mode:
+            self.weak_fraction = self.handles[0].weak_count / float(W * H)
+        self.setup_s = time.perf_counter() - t0
+
+    def init_pass(self):
+        """Everything before the loop of APD.cu:2443 (not timed): prior state, K1..K5."""
+        pkg = self.ctx.pkg
+        for h, prior in zip(self.handles, self.priors):
+            if self.apd_mode:
+                h.upload_prior(*prior)
+            h.run_kernel(pkg.K1)
+            h.run_kernel(pkg.K2)
+            if self.apd_mode and h.weak_count > 0:
+                h.run_kernel(pkg.K3)
+                h.run_kernel(pkg.K4)
+            h.run_kernel(pkg.K5)
+
+    def close(self):
+        for h in self.handles:
+            h.close()
+        self.handles = []
+        self.priors = []
+        self.ctx.torch.cuda.empty_cache()
+
+    def measure(self, steps, warmup, pass_exchange=False):
+        """Times `steps` iterations of the sweep on every owned view (barrier + synchronize on both sides, MAX over ranks).
+        pass_exchange: the timed region also holds what ends a pass of the sharded scheduler -- K11..K13, the depth export and
+        the all-gather of every view's depth map (the exchange the reference does through depths.dmb, APD.cpp:497-500)."""
+        ctx, pkg, torch = self.ctx, self.ctx.pkg, self.ctx.torch
+        W, H, N = self.W, self.H, self.N
+        hs = self.handles
+        # Warm-up: W iterations of the same sweep (clocks, caches, code objects).  Then the state is re-initialised with the
+        # same seed (K1 + K5 again, untimed) so that the timed region is exactly what the config names: the first K
+        # iterations of a pass, INCLUDING iteration 0, whose random planes scatter the gathers over the whole source images
+        # and which costs about twice a later iteration.
+        if warmup > 0:
+            for h in hs:
+                h.run_sweeps(0, warmup)
+        self.init_pass()
+        for h in hs:
+            h.profile_enable(True)
+            h.profile_reset()
+        depth = [torch.empty((H, W), device=ctx.dev, dtype=torch.float32) for _ in hs] if pass_exchange else None
+        gathered = None
+        pass_allgather_ms = None
+
+        ctx.barrier(hs)
+        t0 = time.perf_counter()
+        hs[0].run_sweeps(0, 1, sync=False)
+        hs[0].synchronize()
+        t_first = time.perf_counter()
+        if steps > 1:
+            hs[0].run_sweeps(1, steps - 1, sync=False)
+        for h in hs[1:]:
+            h.run_sweeps(0, steps, sync=False)
+        if pass_exchange:
+            for h, d in zip(hs, depth):
+                for kid in (pkg.K11, pkg.K12, pkg.K13):
+                    h.run_kernel(kid)
+                h.export_depth_normal(d, None)
+        for h in hs:
+            h.synchronize()
+        torch.cuda.synchronize()
+        t_rank = time.perf_counter() - t0  # this rank's own work, before waiting for the others
+        if pass_exchange:
+            ta = time.perf_counter()
+            gathered = self.exchange_depths(depth)
+            torch.cuda.synchronize()
+            pass_allgather_ms = (time.perf_counter() - ta) * 1e3
+        if ctx.distributed:
+            ctx.dist.barrier()
+        elapsed = time.perf_counter() - t0
+        first_iter_s = t_first - t0
+        elapsed, first_iter_s = ctx.max_over_ranks([elapsed, first_iter_s])
+        rank_ms_per_step = ctx.gather_scalar(t_rank / steps * 1e3)
+        prof = hs[0].profile()
+        for h in hs:
+            h.profile_enable(False)
+
+        # after the timed region: post-loop kernels + all-gather of depth/normal maps (before fusion)
+        allgather_ms = None
+        t_post0 = time.perf_counter()
+        if not pass_exchange:
+            for kid in (pkg.K11, pkg.K12, pkg.K13):
+                hs[0].run_kernel(kid)
+            d0 = torch.empty((H, W), device=ctx.dev, dtype=torch.float32)
+            n0 = torch.empty((H, W, 3), device=ctx.dev, dtype=torch.float32)
+            hs[0].export_depth_normal(d0, n0)
+            torch.cuda.synchronize()
+            if ctx.distributed and len(hs) == 1:
+                from apd_mvs_amd import sharding
+                ta = time.perf_counter()
+                gathered_d = sharding.allgather_maps({ctx.rank: d0.view(H, W, 1)}, ctx.world)   # view index == rank here
+                torch.cuda.synchronize()
+                pass_allgather_ms = (time.perf_counter() - ta) * 1e3   # what every pass ends with: the sources' depth maps for the next one
+                gathered_n = sharding.allgather_maps({ctx.rank: n0}, ctx.world)
+                torch.cuda.synchronize()
+                allgather_ms = (time.perf_counter() - ta) * 1e3
+                assert gathered_d.shape[0] == ctx.world and torch.equal(gathered_d[ctx.rank, :, :, 0], d0)
+                assert gathered_n.shape[0] == ctx.world
+                del gathered_d, gathered_n
+            del n0
+        else:
+            d0 = depth[0]
+            views = len(hs) * ctx.world
+            assert gathered.shape[0] == views
+            for slot, d in enumerate(depth):   # every rank holds every view's map, its own ones bit for bit
+                assert torch.equal(gathered[ctx.rank + slot * ctx.world, :, :, 0], d)
+        gt = self.gt[0]
+        err = (d0 - gt).abs() / gt
+        within = float((err[8:-8, 8:-8] < 0.01).float().mean().item())
+        post_ms = (time.perf_counter() - t_post0) * 1e3
+        del d0, depth, gathered
+
+        mpix = W * H / 1e6
+        views_total = ctx.world * len(hs)
+        value = views_total * mpix * steps / elapsed
+        kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0], 3) for k, v in sorted(prof.items())}
+        roofline = strong_roofline(pkg, prof, W, H, N, self.weak_fraction, self.name, steps, warmup, self.opts, self.seed)
+        weak_path = weak_roofline = None
+        if self.apd_mode:
+            weak_path, weak_roofline = weak_rooflines(pkg, prof, W, H, N, self.weak_fraction, self.name, steps, warmup, self.opts, self.seed)
+        later_s = elapsed - first_iter_s
+        return {
+            "value": round(value, 4), "unit": "Mpix*iter/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "timed_region_ms": round(elapsed * 1e3, 3),
+            "config": {"workload": self.name, "width": W, "height": H, "num_src": N,
+                       "state": "REFINE_INIT+APD" if self.apd_mode else "FIRST_INIT",
+                       "views_per_gpu": len(hs), "parallelism": "views sharded, %d rank(s)" % ctx.world,
+                       "backend": "nccl" if ctx.distributed else "single process", "options": self.opts,
+                       "timed_region": ("%d sweep iterations per view + K11..K13 + depth export + all-gather of every view's depth map"
+                                        % steps) if pass_exchange else "%d sweep iterations (APD.cu:2443-2457)" % steps},
+            # two views in flight on one device share the CUs: per-launch times of such a line are not a kernel's own
+            "roofline": None if len(hs) > 1 else (weak_roofline if self.apd_mode else roofline),
+            "strong_path": roofline if (self.apd_mode and len(hs) == 1) else None,
+            "weak_path": weak_path,
+            "iterations": {"first_ms": round(first_iter_s * 1e3, 3),
+                           "later_ms_per_step": round(later_s / max(steps - 1, 1) * 1e3, 3) if steps > 1 and len(hs) == 1 and not pass_exchange else None,
+                           "later_value": round(views_total * mpix * (steps - 1) / later_s, 4) if steps > 1 and len(hs) == 1 and not pass_exchange else None,
+                           "note": "timed region = iterations 0..K-1 of a freshly initialised pass; iteration 0 starts from random planes"},
+            "rank_ms_per_step": [round(v, 3) for v in rank_ms_per_step],
+            "kernel_ms_timed_region": kernel_ms,
+            "post_loop_ms": round(post_ms, 1),
+            "allgather_ms": None if allgather_ms is None else round(allgather_ms, 3),
+            "pass_allgather_ms": None if pass_allgather_ms is None else round(pass_allgather_ms, 3),
+            "pass_allgather_inside_timed_region": bool(pass_exchange),
+            "quality_within_1pct_depth": round(within, 4),
+            "setup_s": round(self.setup_s, 2),
+        }
+
+    def exchange_depths(self, depth):
+        """Every rank's depth maps to every rank: one padded equal-count all-gather (sharding.allgather_maps) under a process
+        group, the identity for a single process."""
+        ctx, torch = self.ctx, self.ctx.torch
+        views = len(depth) * ctx.world
+        if ctx.distributed:
+            from apd_mvs_amd import sharding
+            return sharding.allgather_maps({ctx.rank + s * ctx.world: d.view(self.H, self.W, 1) for s, d in enumerate(depth)}, views)
+        out = torch.empty((views, self.H, self.W, 1), device=ctx.dev, dtype=torch.float32)
+        for s, d in enumerate(depth):
+            out[s, :, :, 0].copy_(d)
+        return out
+
+
+def strong_roofline(pkg, prof, W, H, N, weak_fraction, workload, steps, warmup, opts, seed):
+    """Roofline of K6/K7 (strong update).  Live in this run: the kernel's average launch duration (HIP events on the handle's
+    stream).  From the committed rocprofv3 counter passes of this workload (tools/profile_bench.py): VALU instructions and
+    memory-side bytes per launch, reduced over the launches this command line times.  The kernel is limited by vector-ALU issue
+    (DESIGN.md 6), so that is the bound the fraction is taken against; the memory-side rate and the SURVEY 8(d) algorithmic
+    count are reported beside it."""
+    k6 = prof.get(pkg.K6, (0.0, 0))
+    k7 = prof.get(pkg.K7, (0.0, 0))
+    launches = k6[1] + k7[1]
+    avg_ms = (k6[0] + k7[0]) / max(launches, 1)
+    # K6/K7 skip WEAK pixels; the weak fraction is the one at upload time (K4 only ever lowers it)
+    bytes_per_launch = (W * H / 2.0) * (1.0 - weak_fraction) * algorithmic_bytes_per_strong_pixel(N)
+    alg_gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    pmc = load_pmc_profile(workload, steps, warmup, "k67", opts, seed)
+    roofline = {
+        "bound": "valu-issue", "kernel": "k67w_update_strong (Black/RedPixelUpdateStrong, LDS source windows)",
+        "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwave-inst/s", "frac": None, "traffic": None,
+        "avg_launch_ms": round(avg_ms, 3), "launches": launches,
+        "peak_note": "%d SIMDs x %.1f GHz / %.0f cycles per wave64 VALU instruction (tools/valu_issue.hip)"
+                     % (NUM_SIMDS, MAX_CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST),
+        "hbm": None,
+        "algorithmic": {"bytes_per_launch": bytes_per_launch, "bytes_per_pixel_iter": algorithmic_bytes_per_strong_pixel(N),
+                        "GBps": round(alg_gbps, 1),
+                        "note": "SURVEY 8(d) nominal count (every tap of every nominal NCC priced as 20 B of HBM traffic); it counts "
+                                "L1/L2/LDS hits and early-outed NCCs, so it exceeds any memory roofline and is NOT one"},
+        "pmc_source": None,
+    }
+    if pmc is not None:
+        insts = pmc["valu_insts_per_launch"]
+        achieved = insts / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = pmc["hbm_bytes_per_launch"]
+        hbm_gbps = traffic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline.update({
+            "achieved": round(achieved, 1), "frac": round(achieved / VALU_PEAK_GINST, 4), "traffic": traffic,
+            "valu_insts_per_launch": insts,
+            "hbm": {"achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4),
+                    "bytes_per_launch": traffic, "note": "2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction of the guide)"},
+            "pmc_source": pmc["source"], "pmc_launch_ms": pmc.get("launch_ms"), "pmc_profile_steps": pmc["profile_steps"],
+            "pmc_extrapolated_launches": pmc["extrapolated_launches"],
+        })
+        mix = load_valu_mix(os.path.dirname(pmc["source"]))
+        if mix is not None:
+            busy = insts * mix["mean_cycles_per_inst"] / (NUM_SIMDS * MAX_CLOCK_GHZ * 1e9 * avg_ms * 1e-3)
+            roofline["valu_busy_estimate"] = {
+                "frac": round(busy, 4), "mean_issue_cycles_per_inst": mix["mean_cycles_per_inst"], "source": mix["source"],
+                "note": "VALU instructions per launch x mean issue cycles of the kernel's LDS-window body (static mix of THIS round's "
+                        "ISA, measured per-class costs) / (1024 SIMDs x 2.4 GHz x launch time); an estimate, the counters do not split by class"}
+    else:
+        roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s options=%s seed=%d under profiles/: "
+                                "achieved / frac / traffic are null rather than borrowed from another configuration"
+                                % (workload, list(opts), seed))
+    return roofline
+
+
+def weak_rooflines(pkg, prof, W, H, N, weak_fraction, workload, steps, warmup, opts, seed):
+    """K9/K10 (weak update): `weak_path` (nominal bytes, fabric) and the roofline against the L1 tag pipeline."""
+    k9, k10 = prof.get(pkg.K9, (0.0, 0)), prof.get(pkg.K10, (0.0, 0))
+    wl = k9[1] + k10[1]
+    wms = (k9[0] + k10[0]) / max(wl, 1)
+    wbytes = (W * H / 2.0) * weak_fraction * algorithmic_bytes_per_weak_pixel(N)
+    weak_path = {"kernel": "k910_update_weak (Black/RedPixelUpdateWeak)", "weak_fraction": round(weak_fraction, 4),
+                 "avg_launch_ms": round(wms, 3), "launches": wl, "algorithmic_bytes_per_launch_nominal_max": wbytes,
+                 "achieved_GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0}
+    # what bounds K9/K10 (DESIGN.md section 6): its scattered sub-patch gathers -- L1 tag look-ups per gather and the bytes the
+    # misses pull through the fabric; counters from the profile of this same command line, time measured live
+    wp = load_pmc_profile(workload, steps, warmup, "k910", opts, seed)
+    # K9/K10 owns most of an APD iteration: it is the dominant kernel of this workload and the line's `roofline`; the
+    # strong sweep's block moves to `strong_path`.  Bound: the L1 (TCP) tag pipeline -- a scattered dword gather costs one
+    # tag access per lane whatever the lines (tools/tcp_patterns.hip, profiles/r03/tcp_patterns.txt), and the pipeline
+    # sustains 1.85 accesses per clock and CU (tools/unaligned_gather.hip, profiles/r02/unaligned_gather.txt).
+    tag_peak = 256 * MAX_CLOCK_GHZ * TCP_ACCESSES_PER_CLOCK   # G accesses / s
+    weak_roofline = {"bound": "l1-tag-pipeline", "kernel": "k910_update_weak (Black/RedPixelUpdateWeak)", "achieved": None,
+                     "peak": round(tag_peak, 1), "unit": "Gaccess/s", "frac": None, "traffic": None, "avg_launch_ms": round(wms, 3),
+                     "launches": wl,
+                     "peak_note": "256 CUs x %.1f GHz x %.2f L1 tag accesses per clock (all-hit dword gathers, tools/unaligned_gather.hip)"
+                                  % (MAX_CLOCK_GHZ, TCP_ACCESSES_PER_CLOCK),
+                     "algorithmic": {"bytes_per_launch_nominal_max": wbytes, "bytes_per_weak_pixel_iter_nominal_max": algorithmic_bytes_per_weak_pixel(N),
+                                     "GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0,
+                                     "note": "SURVEY 8(d) nominal maximum (15 N NCCNew of 108 samples + N NCCOld, 20 B per sample); counts cache "
+                                             "hits and early-outed hypotheses: NOT a roofline"},
+                     "pmc_source": None}
+    if wp and wms > 0 and wp.get("tcp_tag_accesses_per_launch"):
+        acc = wp["tcp_tag_accesses_per_launch"] / (wms * 1e-3) / 1e9
+        hbm_b = wp["hbm_bytes_per_launch"]
+        weak_roofline.update({"achieved": round(acc, 1), "frac": round(acc / tag_peak, 4), "traffic": hbm_b,
+                              "tag_accesses_per_launch": wp["tcp_tag_accesses_per_launch"],
+                              # the pipeline's rate depends on where the lanes of a gather go: 1.85 per clock when they share
+                              # lines, 0.95 when every lane reads its own line (tools/tcp_mix.hip, profiles/r03/tcp_mix.txt:
+                              # 32 accesses in 33.6 clocks; tcp_patterns 3, 7, 30 agree); `frac` is against the former
+                              "tag_rate": {"achieved_per_clock_and_cu": round(acc / (256 * MAX_CLOCK_GHZ), 3),
+                                           "peak_lanes_sharing_lines": TCP_ACCESSES_PER_CLOCK, "peak_lanes_on_distinct_lines": 0.95,
+                                           "note": "more resident waves do not shorten the launch (profiles/r03/ab_k910_split.txt: 8 to 16 "
+                                                   "workgroups per CU, same time); L1 misses served by the L2 hide behind the tag "
+                                                   "accesses up to one miss per ~2.5 accesses (tcp_mix: 2.4 clocks per 128-byte line)"},
+                              "hbm": {"achieved": round(hbm_b / (wms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "frac": round(hbm_b / (wms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": hbm_b,
+                                      "note": "2 x FETCH_SIZE + WRITE_SIZE per launch"},
+                              "valu": {"achieved": round(wp["valu_insts_per_launch"] / (wms * 1e-3) / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1),
+                                       "unit": "Gwave-inst/s", "frac": round(wp["valu_insts_per_launch"] / (wms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)},
+                              "pmc_source": wp["source"], "pmc_launch_ms": wp.get("launch_ms"), "pmc_profile_steps": wp["profile_steps"],
+                              "pmc_extrapolated_launches": wp["extrapolated_launches"]})
+    else:
+        weak_roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s options=%s seed=%d under profiles/"
+                                     % (workload, list(opts), seed))
+    if wp and wms > 0 and wp.get("fetch_bytes_per_launch") and wp.get("vmem_rd_insts_per_launch"):
+        fabric = wp["fetch_bytes_per_launch"] / (wms * 1e-3) / 1e9
+        gathers = wp["vmem_rd_insts_per_launch"]
+        cyc = wms * 1e-3 * 2.4e9 * 256 / gathers
+        weak_path["bound"] = {"kind": "l1-tag pipeline + fabric", "fabric_GBps": round(fabric, 1), "fabric_peak_GBps": 8000.0,
+                              "fabric_frac": round(fabric / 8000.0, 4), "fabric_frac_of_achievable_6290": round(fabric / 6290.0, 4),
+                              "wave_gathers_per_launch": gathers,
+                              "tag_lookups_per_gather": round(wp["tcp_tag_accesses_per_launch"] / gathers, 1) if wp.get("tcp_tag_accesses_per_launch") else None,
+                              "cu_cycles_per_gather": round(cyc, 1),
+                              "cu_cycles_per_gather_all_hits": 32.0,
+                              "note": "an all-hit wave-level dword gather occupies a CU's L1 for 32 cycles (tools/unaligned_gather.hip); "
+                                      "FETCH_SIZE x 2 = bytes requested from the fabric (Infinity Cache + HBM)",
+                              "pmc_source": wp["source"]}
+    return weak_path, weak_roofline
+
+
+# The sub-lines of the `workloads` block: every BASELINE.json config on the clock of the same process, after the headline.
+# (key, workload, steps, warmup, pass_exchange, views_per_gpu)
+SUB_WORKLOADS = [
+    ("configs1_office_6iter", "eth3d_office_fullres_8src", 6, 1, False, 1),        # configs[1] at its own six iterations
+    ("configs1_office_ref_pass_3iter", "eth3d_office_fullres_8src", 3, 1, False, 1),  # ... at the reference's default pass (main.cpp:183)
+    ("configs2_pipes_apd_3iter", "eth3d_pipes_fullres_10src_apd", 3, 1, False, 1),  # configs[2]: adaptive patches on (K9/K10 roofline)
+    ("configs4_synthetic_16src_8iter", "synthetic_4096x3072_16src", 8, 1, False, 1),  # configs[4] shape, one replica per GPU
+    ("configs3_tt1080p_20iter", "tt_family_1080p_10src", 20, 5, False, 1),          # configs[3] frame size, sweep only
+    ("configs3_tt1080p_pass_with_exchange", "tt_family_1080p_10src", 3, 1, True, 2),  # configs[3] as the sharded scheduler runs it:
+    # two views per GPU, the reference's three iterations, then K11..K13 + export + all-gather of all depth maps inside the timed region
+]
+
+
+def init_distributed(args, torch, local_rank):
+    """RCCL process group with a bounded set-up: a communicator that cannot be built must end the run with a diagnosis, not hang
+    the node (the driver's 8-GPU run would otherwise sit until its own limit)."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    try:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("APD_BENCH_PG_TIMEOUT_S", "300"))))
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl", (dist.get_world_size(), dist.get_backend())
+        probe = torch.ones(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(probe)   # builds the communicator now: a failure shows up here, before any timed region
+        torch.cuda.synchronize()
+        assert int(probe.item()) == args.gpus
+    except Exception as e:  # noqa: BLE001 -- whatever RCCL raises
+        sys.stderr.write("bench.py: RCCL process group set-up failed on rank %s: %r\n"
+                         "bench.py: re-run with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,ENV for RCCL's own log (NCCL_DEBUG=%s in this run)\n"
+                         % (os.environ.get("RANK", "?"), e, os.environ.get("NCCL_DEBUG", "unset")))
+        sys.stderr.flush()
+        os._exit(4)
+    return dist
+
+
 def main():
+    t_main = time.perf_counter()
     args = parse_args()
     if args.gpus < 1:
         sys.stderr.write("bench.py: --gpus must be >= 1\n")
@@ -147,294 +553,86 @@ def main():
     if torch.cuda.device_count() < (local_rank + 1):
         sys.stderr.write("bench.py: rank %d needs HIP device %d, %d visible\n" % (rank, local_rank, torch.cuda.device_count()))
         return 3
+    dist = None
     if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl", (dist.get_world_size(), dist.get_backend())
+        if world > 1:
+            os.environ.setdefault("NCCL_DEBUG", "WARN")   # RCCL's own warnings reach the driver's log
+        dist = init_distributed(args, torch, local_rank)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if distributed else 0)
+    ctx = Ctx(pkg, synth, np, torch, dev, rank, world, distributed, dist)
 
-    (W, H, N), apd_mode = resolve_workload(args.workload)
-    # every rank owns a different reference view of the same camera ring
-    sc = synth.make_scene(W, H, N, seed=0, ref_view=rank, device=dev, textureless=0.2 if apd_mode else 0.0)
-    cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
-    total_iters = max(args.warmup, args.steps)
-    dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
-    weak_fraction = 0.0
-    if not apd_mode:
-        params = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0,
-                                    state=pkg.FIRST_INIT, max_iterations=total_iters, seed=args.seed)
-        h = pkg.Handle(W, H, params, device=dev.index)
-        apply_options(h, args.opt)
-        h.upload_views(cams, sc.images)  # device->device copies: inputs are resident in HBM before timing
-    else:
-        # untimed: the photometric FIRST_INIT pass of main.cpp:169-190 (3 iterations, weak_peak_radius 6) that
-        # classifies pixels, then ProcessProblem's post-processing (main.cpp:105-115)
-        p0 = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0, state=pkg.FIRST_INIT,
-                                max_iterations=3, weak_peak_radius=6, seed=args.seed)
-        h0 = pkg.Handle(W, H, p0, device=dev.index)
-        h0.upload_views(cams, sc.images)
-        h0.run()
-        planes, weak, views = h0.download()
-        h0.close()
-        bad = (planes[..., 3] < np.float32(dmin)) | (planes[..., 3] > np.float32(dmax))
-        planes[..., 3][bad] = 0
-        weak[bad] = pkg.UNKNOWN
-        params = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=1, state=pkg.REFINE_INIT,
-                                    max_iterations=total_iters, weak_peak_radius=6, rotate_time=4,
-                                    ransac_threshold=0.01 - 0.00125 * 3, seed=args.seed + 1)
-        h = pkg.Handle(W, H, params, device=dev.index)
-        apply_options(h, args.opt)
-        h.upload_views(cams, sc.images)
-        prior = (planes, views, weak)
-    del sc.images[:]
-    torch.cuda.empty_cache()
+    # ---- headline: BASELINE.json configs[1] (or --workload) at the command line's --steps / --warmup ----
+    # the `workloads` block belongs to the default line (the driver's command); tuning runs (--workload X, --opt) time one thing
+    subs = [] if (args.no_workloads or args.opt or (args.workload != DEFAULT_WORKLOAD and not args.only_workloads)) else \
+        [s for s in SUB_WORKLOADS if not args.only_workloads or s[0] in args.only_workloads]
+    same = [s for s in subs if s[1] == args.workload and s[5] == 1]
+    wl = SweepWorkload(ctx, args.workload, max([max(args.warmup, args.steps)] + [max(s[2], s[3]) for s in same]), args.opt, args.seed)
+    head = wl.measure(args.steps, args.warmup)
+    head_apd = wl.apd_mode
+    N_head = wl.N
 
-    def init_pass():
-        """Everything before the loop of APD.cu:2443 (not timed): prior state, K1..K5."""
-        if apd_mode:
-            h.upload_prior(*prior)
-        h.run_kernel(pkg.K1)
-        h.run_kernel(pkg.K2)
-        if apd_mode and h.weak_count > 0:
-            h.run_kernel(pkg.K3)
-            h.run_kernel(pkg.K4)
-        h.run_kernel(pkg.K5)
-
-    init_pass()
-    if apd_mode:
-        weak_fraction = h.weak_count / float(W * H)
-    # Warm-up: W iterations of the same sweep (clocks, caches, code objects).  Then the state is re-initialised with the
-    # same seed (K1 + K5 again, untimed) so that the timed region is exactly what the config names: the first K
-    # iterations of a pass, INCLUDING iteration 0, whose random planes scatter the gathers over the whole source images
-    # and which costs about twice a later iteration.
-    if args.warmup > 0:
-        h.run_sweeps(0, args.warmup)
-        init_pass()
-    h.profile_enable(True)
-    h.profile_reset()
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        h.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    h.run_sweeps(0, 1, sync=False)
-    h.synchronize()
-    t_first = time.perf_counter()
-    if args.steps > 1:
-        h.run_sweeps(1, args.steps - 1, sync=False)
-        h.synchronize()
-    torch.cuda.synchronize()
-    t_rank = time.perf_counter() - t0  # this rank's own sweep, before waiting for the others
-    if distributed:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    first_iter_s = t_first - t0
-    rank_ms_per_step = [t_rank / args.steps * 1e3]
-    if distributed:
-        tt = torch.tensor([elapsed, first_iter_s], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, first_iter_s = float(tt[0].item()), float(tt[1].item())
-        per_rank = torch.zeros(world, device=dev, dtype=torch.float64)
-        dist.all_gather_into_tensor(per_rank, torch.tensor([t_rank / args.steps * 1e3], device=dev, dtype=torch.float64))
-        rank_ms_per_step = [float(v) for v in per_rank.tolist()]
-    prof = h.profile()
-    h.profile_enable(False)
-
-    # after the timed region: post-loop kernels + all-gather of depth/normal maps (before fusion)
-    allgather_ms = pass_allgather_ms = None
-    t_post0 = time.perf_counter()
-    for kid in (pkg.K11, pkg.K12, pkg.K13):
-        h.run_kernel(kid)
-    depth = torch.empty((H, W), device=dev, dtype=torch.float32)
-    normal = torch.empty((H, W, 3), device=dev, dtype=torch.float32)
-    h.export_depth_normal(depth, normal)
-    torch.cuda.synchronize()
-    if distributed:
-        from apd_mvs_amd import sharding
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        gathered_d = sharding.allgather_maps({rank: depth.view(H, W, 1)}, world)   # view index == rank here
-        torch.cuda.synchronize()
-        pass_allgather_ms = (time.perf_counter() - ta) * 1e3   # what every pass ends with: the sources' depth maps for the next one
-        gathered_n = sharding.allgather_maps({rank: normal}, world)
-        torch.cuda.synchronize()
-        allgather_ms = (time.perf_counter() - ta) * 1e3
-        assert gathered_d.shape[0] == world and torch.equal(gathered_d[rank, :, :, 0], depth)
-        assert gathered_n.shape[0] == world
-    gt = sc.gt_depth
-    err = (depth - gt).abs() / gt
-    within = float((err[8:-8, 8:-8] < 0.01).float().mean().item())
-    post_ms = (time.perf_counter() - t_post0) * 1e3
-
-    mpix = W * H / 1e6
-    value = world * mpix * args.steps / elapsed
-
-    # ---- roofline of the dominant kernel (K6/K7 strong update) ----
-    # Live in this run: the kernel's average launch duration (HIP events on the handle's stream).  From the committed rocprofv3
-    # counter passes of this exact command line (workload, --steps, --warmup; tools/profile_bench.py): VALU instructions
-    # and memory-side bytes per launch.  The kernel is limited by vector-ALU issue (DESIGN.md 6), so that is the bound the
-    # fraction is taken against; the memory-side rate and the SURVEY 8(d) algorithmic count are reported beside it.
-    k6 = prof.get(pkg.K6, (0.0, 0))
-    k7 = prof.get(pkg.K7, (0.0, 0))
-    launches = k6[1] + k7[1]
-    avg_ms = (k6[0] + k7[0]) / max(launches, 1)
-    # K6/K7 skip WEAK pixels; the weak fraction is the one at upload time (K4 only ever lowers it)
-    bytes_per_launch = (W * H / 2.0) * (1.0 - weak_fraction) * algorithmic_bytes_per_strong_pixel(N)
-    alg_gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    pmc = load_pmc_profile(args.workload, args.steps, args.warmup, "k67", args.opt, args.seed)
-    roofline = {
-        "bound": "valu-issue", "kernel": "k67w_update_strong (Black/RedPixelUpdateStrong, LDS source windows)",
-        "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwave-inst/s", "frac": None, "traffic": None,
-        "avg_launch_ms": round(avg_ms, 3), "launches": launches,
-        "peak_note": "%d SIMDs x %.1f GHz / %.0f cycles per wave64 VALU instruction (tools/valu_issue.hip)"
-                     % (NUM_SIMDS, MAX_CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST),
-        "hbm": None,
-        "algorithmic": {"bytes_per_launch": bytes_per_launch, "bytes_per_pixel_iter": algorithmic_bytes_per_strong_pixel(N),
-                        "GBps": round(alg_gbps, 1),
-                        "note": "SURVEY 8(d) nominal count (every tap of every nominal NCC priced as 20 B of HBM traffic); it counts "
-                                "L1/L2/LDS hits and early-outed NCCs, so it exceeds any memory roofline and is NOT one"},
-        "pmc_source": None,
-    }
-    if pmc is not None:
-        insts = pmc["valu_insts_per_launch"]
-        achieved = insts / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = pmc["hbm_bytes_per_launch"]
-        hbm_gbps = traffic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        roofline.update({
-            "achieved": round(achieved, 1), "frac": round(achieved / VALU_PEAK_GINST, 4), "traffic": traffic,
-            "valu_insts_per_launch": insts,
-            "hbm": {"achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4),
-                    "bytes_per_launch": traffic, "note": "2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction of the guide)"},
-            "pmc_source": pmc["source"], "pmc_launch_ms": pmc.get("launch_ms"), "pmc_profile_steps": pmc["profile_steps"],
-            "pmc_extrapolated_launches": pmc["extrapolated_launches"],
-        })
-        mix = load_valu_mix()
-        if mix is not None:
-            busy = insts * mix["mean_cycles_per_inst"] / (NUM_SIMDS * MAX_CLOCK_GHZ * 1e9 * avg_ms * 1e-3)
-            roofline["valu_busy_estimate"] = {
-                "frac": round(busy, 4), "mean_issue_cycles_per_inst": mix["mean_cycles_per_inst"], "source": mix["source"],
-                "note": "VALU instructions per launch x mean issue cycles of the kernel's LDS-window body (static mix, measured "
-                        "per-class costs) / (1024 SIMDs x 2.4 GHz x launch time); an estimate, the counters do not split by class"}
-    else:
-        roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s options=%s seed=%d under profiles/: "
-                                "achieved / frac / traffic are null rather than borrowed from another configuration"
-                                % (args.workload, args.opt, args.seed))
-    kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0], 3) for k, v in sorted(prof.items())}
-    weak_path = None
-    weak_roofline = None
-    if apd_mode:
-        k9, k10 = prof.get(pkg.K9, (0.0, 0)), prof.get(pkg.K10, (0.0, 0))
-        wl = k9[1] + k10[1]
-        wms = (k9[0] + k10[0]) / max(wl, 1)
-        wbytes = (W * H / 2.0) * weak_fraction * algorithmic_bytes_per_weak_pixel(N)
-        weak_path = {"kernel": "k910_update_weak (Black/RedPixelUpdateWeak)", "weak_fraction": round(weak_fraction, 4),
-                     "avg_launch_ms": round(wms, 3), "launches": wl, "algorithmic_bytes_per_launch_nominal_max": wbytes,
-                     "achieved_GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0}
-        # what bounds K9/K10 (DESIGN.md section 6): its scattered sub-patch gathers -- L1 tag look-ups per gather and the bytes the
-        # misses pull through the fabric; counters from the profile of this same command line, time measured live
-        wp = load_pmc_profile(args.workload, args.steps, args.warmup, "k910", args.opt, args.seed)
-        # K9/K10 owns most of an APD iteration: it is the dominant kernel of this workload and the line's `roofline`; the
-        # strong sweep's block moves to `strong_path`.  Bound: the L1 (TCP) tag pipeline -- a scattered dword gather costs one
-        # tag access per lane whatever the lines (tools/tcp_patterns.hip, profiles/r03/tcp_patterns.txt), and the pipeline
-        # sustains 1.85 accesses per clock and CU (tools/unaligned_gather.hip, profiles/r02/unaligned_gather.txt).
-        tag_peak = 256 * MAX_CLOCK_GHZ * TCP_ACCESSES_PER_CLOCK   # G accesses / s
-        weak_roofline = {"bound": "l1-tag-pipeline", "kernel": "k910_update_weak (Black/RedPixelUpdateWeak)", "achieved": None,
-                         "peak": round(tag_peak, 1), "unit": "Gaccess/s", "frac": None, "traffic": None, "avg_launch_ms": round(wms, 3),
-                         "launches": wl,
-                         "peak_note": "256 CUs x %.1f GHz x %.2f L1 tag accesses per clock (all-hit dword gathers, tools/unaligned_gather.hip)"
-                                      % (MAX_CLOCK_GHZ, TCP_ACCESSES_PER_CLOCK),
-                         "algorithmic": {"bytes_per_launch_nominal_max": wbytes, "bytes_per_weak_pixel_iter_nominal_max": algorithmic_bytes_per_weak_pixel(N),
-                                         "GBps_nominal_max": round(wbytes / (wms * 1e-3) / 1e9, 1) if wms > 0 else 0.0,
-                                         "note": "SURVEY 8(d) nominal maximum (15 N NCCNew of 108 samples + N NCCOld, 20 B per sample); counts cache "
-                                                 "hits and early-outed hypotheses: NOT a roofline"},
-                         "pmc_source": None}
-        if wp and wms > 0 and wp.get("tcp_tag_accesses_per_launch"):
-            acc = wp["tcp_tag_accesses_per_launch"] / (wms * 1e-3) / 1e9
-            hbm_b = wp["hbm_bytes_per_launch"]
-            weak_roofline.update({"achieved": round(acc, 1), "frac": round(acc / tag_peak, 4), "traffic": hbm_b,
-                                  "tag_accesses_per_launch": wp["tcp_tag_accesses_per_launch"],
-                                  # the pipeline's rate depends on where the lanes of a gather go: 1.85 per clock when they share
-                                  # lines, 0.95 when every lane reads its own line (tools/tcp_mix.hip, profiles/r03/tcp_mix.txt:
-                                  # 32 accesses in 33.6 clocks; tcp_patterns 3, 7, 30 agree); `frac` is against the former
-                                  "tag_rate": {"achieved_per_clock_and_cu": round(acc / (256 * MAX_CLOCK_GHZ), 3),
-                                               "peak_lanes_sharing_lines": TCP_ACCESSES_PER_CLOCK, "peak_lanes_on_distinct_lines": 0.95,
-                                               "note": "more resident waves do not shorten the launch (profiles/r03/ab_k910_split.txt: 8 to 16 "
-                                                       "workgroups per CU, same time); L1 misses served by the L2 hide behind the tag "
-                                                       "accesses up to one miss per ~2.5 accesses (tcp_mix: 2.4 clocks per 128-byte line)"},
-                                  "hbm": {"achieved": round(hbm_b / (wms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                          "frac": round(hbm_b / (wms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": hbm_b,
-                                          "note": "2 x FETCH_SIZE + WRITE_SIZE per launch"},
-                                  "valu": {"achieved": round(wp["valu_insts_per_launch"] / (wms * 1e-3) / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1),
-                                           "unit": "Gwave-inst/s", "frac": round(wp["valu_insts_per_launch"] / (wms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)},
-                                  "pmc_source": wp["source"], "pmc_launch_ms": wp.get("launch_ms"), "pmc_profile_steps": wp["profile_steps"],
-                                  "pmc_extrapolated_launches": wp["extrapolated_launches"]})
-        else:
-            weak_roofline["pmc_note"] = ("no committed rocprofv3 counter profile for workload=%s options=%s seed=%d under profiles/"
-                                         % (args.workload, args.opt, args.seed))
-        if wp and wms > 0 and wp.get("fetch_bytes_per_launch") and wp.get("vmem_rd_insts_per_launch"):
-            fabric = wp["fetch_bytes_per_launch"] / (wms * 1e-3) / 1e9
-            gathers = wp["vmem_rd_insts_per_launch"]
-            cyc = wms * 1e-3 * 2.4e9 * 256 / gathers
-            weak_path["bound"] = {"kind": "l1-tag pipeline + fabric", "fabric_GBps": round(fabric, 1), "fabric_peak_GBps": 8000.0,
-                                  "fabric_frac": round(fabric / 8000.0, 4), "fabric_frac_of_achievable_6290": round(fabric / 6290.0, 4),
-                                  "wave_gathers_per_launch": gathers,
-                                  "tag_lookups_per_gather": round(wp["tcp_tag_accesses_per_launch"] / gathers, 1) if wp.get("tcp_tag_accesses_per_launch") else None,
-                                  "cu_cycles_per_gather": round(cyc, 1),
-                                  "cu_cycles_per_gather_all_hits": 32.0,
-                                  "note": "an all-hit wave-level dword gather occupies a CU's L1 for 32 cycles (tools/unaligned_gather.hip); "
-                                          "FETCH_SIZE x 2 = bytes requested from the fabric (Infinity Cache + HBM)",
-                                  "pmc_source": wp["source"]}
+    # ---- every other BASELINE config, in the same process, on the same clock ----
+    workloads = {}
+    t_subs = time.perf_counter()
+    cache = {(args.workload, 1): wl}
+    for key, name, steps, warmup, pass_exchange, vpg in subs:
+        w = cache.get((name, vpg))
+        if w is None:
+            for old in cache.values():   # one workload resident at a time: the next one gets the whole device
+                old.close()
+            cache.clear()
+            w = SweepWorkload(ctx, name, max([max(s[2], s[3]) for s in subs if s[1] == name and s[5] == vpg]), (), args.seed, views_per_gpu=vpg)
+            cache[(name, vpg)] = w
+        line = w.measure(steps, warmup, pass_exchange=pass_exchange)
+        line["n_gpus"] = world
+        line["scaling"] = "weak"
+        workloads[key] = line
+    for old in cache.values():
+        old.close()
+    cache.clear()
+    subs_s = time.perf_counter() - t_subs
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
-        cpu_baseline = run_cpu_baseline(args, N, np)
+        cpu_baseline = run_cpu_baseline(args, N_head, np)
 
     if rank == 0:
         out = {
             "metric": "Mpix*iterations/sec (PatchMatch sweep)",
-            "value": round(value, 4),
+            "value": head["value"],
             "unit": "Mpix*iter/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "width": W, "height": H, "num_src": N,
-                       "state": "REFINE_INIT+APD" if apd_mode else "FIRST_INIT",
-                       "views_per_gpu": 1, "parallelism": "views sharded, %d rank(s)" % world,
-                       "backend": "nccl" if distributed else "single process", "options": args.opt},
-            "roofline": weak_roofline if apd_mode else roofline,
-            "strong_path": roofline if apd_mode else None,
+            "config": head["config"],
+            "roofline": head["roofline"],
+            "strong_path": head["strong_path"] if head_apd else None,
             "cpu_baseline": cpu_baseline,
-            "weak_path": weak_path,
-            "iterations": {"first_ms": round(first_iter_s * 1e3, 3),
-                           "later_ms_per_step": round((elapsed - first_iter_s) / max(args.steps - 1, 1) * 1e3, 3) if args.steps > 1 else None,
-                           "later_value": round(world * mpix * (args.steps - 1) / (elapsed - first_iter_s), 4) if args.steps > 1 else None,
-                           "note": "timed region = iterations 0..K-1 of a freshly initialised pass; iteration 0 starts from random planes"},
-            "rank_ms_per_step": [round(v, 3) for v in rank_ms_per_step],
-            "kernel_ms_timed_region": kernel_ms,
-            "post_loop_ms": round(post_ms, 1),
-            "allgather_ms": None if allgather_ms is None else round(allgather_ms, 3),
-            "pass_allgather_ms": None if pass_allgather_ms is None else round(pass_allgather_ms, 3),
+            "weak_path": head["weak_path"],
+            "iterations": head["iterations"],
+            "rank_ms_per_step": head["rank_ms_per_step"],
+            "kernel_ms_timed_region": head["kernel_ms_timed_region"],
+            "post_loop_ms": head["post_loop_ms"],
+            "allgather_ms": head["allgather_ms"],
+            "pass_allgather_ms": head["pass_allgather_ms"],
             "allgather_note": "RCCL all-gather over the ranks after the timed region: depth maps (the exchange that ends every pass, "
-                              "pass_allgather_ms) + normal maps (before fusion; allgather_ms is both)",
-            "quality_within_1pct_depth": round(within, 4),
+                              "pass_allgather_ms) + normal maps (before fusion; allgather_ms is both); the sub-line "
+                              "configs3_tt1080p_pass_with_exchange has the per-pass exchange INSIDE its timed region",
+            "quality_within_1pct_depth": head["quality_within_1pct_depth"],
+            "workloads": workloads,
+            "workloads_note": "every BASELINE.json config timed in this process after the headline, same contract (barrier + synchronize on "
+                              "both sides, MAX over ranks, whole-job value): ms_per_step x steps of all lines lies inside this process's wall time",
+            "wall_s": {"sub_workloads": round(subs_s, 1), "process": round(time.perf_counter() - t_main, 1)},
         }
         print(json.dumps(out), flush=True)
-    h.close()
     if distributed:
         dist.destroy_process_group()
     return 0
@@ -470,13 +668,35 @@ def selftest_cpu(args, world, rank):
     g = sharding.allgather_maps({rank: depth}, world)
     allgather_ms = (time.perf_counter() - ta) * 1e3
     assert g.shape[0] == world and all(float(g[r].mean()) == float(r) for r in range(world))
+    # the pass-with-exchange sub-line of the `workloads` block: two views per rank, the all-gather of every view's depth map INSIDE
+    # the barrier-bracketed region, gathered maps in view order on every rank
+    vpg, hh, ww = 2, 6, 10
+    mine = {rank + s * world: torch.full((hh, ww, 1), float(rank + s * world), dtype=torch.float32) for s in range(vpg)}
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.005 * (rank + 1))
+    t_rank2 = time.perf_counter() - t0
+    ta = time.perf_counter()
+    g2 = sharding.allgather_maps(mine, vpg * world)
+    pass_ms = (time.perf_counter() - ta) * 1e3
+    dist.barrier()
+    elapsed2 = sharding.timed_region_max(time.perf_counter() - t0, torch.device("cpu"))
+    assert g2.shape[0] == vpg * world and all(float(g2[v].mean()) == float(v) for v in range(vpg * world))
+    per_rank2 = torch.zeros(world, dtype=torch.float64)
+    dist.all_gather_into_tensor(per_rank2, torch.tensor([t_rank2 * 1e3], dtype=torch.float64))
+    assert elapsed2 * 1e3 >= float(per_rank2.max()) + 0.0   # the exchange is inside: the region cannot be shorter than the slowest rank
     if rank == 0:
         print(json.dumps({"metric": "Mpix*iterations/sec (PatchMatch sweep)", "value": None, "unit": "Mpix*iter/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "selftest": "launcher and collectives only, CPU/gloo, no PatchMatch work", "scaling": "weak",
                           "config": {"workload": args.workload, "backend": dist.get_backend()},
                           "rank_ms_per_step": [round(float(v), 3) for v in per_rank.tolist()],
-                          "allgather_ms": round(allgather_ms, 3)}), flush=True)
+                          "allgather_ms": round(allgather_ms, 3),
+                          "workloads": {"configs3_tt1080p_pass_with_exchange": {
+                              "value": None, "n_gpus": world, "steps": 1, "ms_per_step": round(elapsed2 * 1e3, 3),
+                              "timed_region_ms": round(elapsed2 * 1e3, 3), "pass_allgather_ms": round(pass_ms, 3),
+                              "pass_allgather_inside_timed_region": True, "rank_ms_per_step": [round(float(v), 3) for v in per_rank2.tolist()],
+                              "config": {"views_per_gpu": vpg, "backend": dist.get_backend(), "views": vpg * world}}}}), flush=True)
     dist.destroy_process_group()
     return 0
 
@@ -545,10 +765,14 @@ def load_pmc_profile(workload, steps, warmup, kernel, options=(), seed=12345):
     return best
 
 
-def load_valu_mix():
+def load_valu_mix(prefer_dir=None):
+    """Static instruction mix of the K6/K7 window body (tools/valu_mix.py).  Only the file of the SAME round directory as the
+    counter profile describes the kernel that profile measured: with `prefer_dir` nothing else is used (a
+    round-2 mix priced a round-3 kernel)."""
     import glob
+    paths = [os.path.join(ROOT, prefer_dir, "valu_mix_k67w.json")] if prefer_dir else sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "valu_mix_k67w.json")))
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "valu_mix_k67w.json"))):
+    for path in paths:
         try:
             with open(path) as f:
                 rec = json.load(f)

@@ -138,12 +138,32 @@ int apd_reset(apd_handle h, const apd_params *params);
 int apd_upload_views(apd_handle h, int num_images, const apd_camera *cameras, const float *const *images,
                      const float *const *depths);
 
+/* A geometric pass in two halves, for a scheduler that keeps several views in flight: the sources' depth maps are the only
+ * input of a (view, pass) that other views of the same pass produce (the reference reads depths.dmb as the files are at that
+ * moment, APD.cpp:497-500), and only the weak update (K9/K10), K14 and K15 read them (ComputeGeomConsistencyCost, APD.cu:752).
+ *   apd_upload_views_split   = apd_upload_views without depth maps (their buffers are allocated);
+ *   apd_run_before_depths    = the longest prefix of the schedule that reads no depth map: K1..K5, iteration 0 of K6..K8 and --
+ *                              while no WEAK pixel exists -- the other iterations and K11..K13; without the geometric term the
+ *                              whole pass;
+ *   apd_upload_depths        = the num_images depth maps (index 0: the view's own), copied on the handle's stream, i.e. after the
+ *                              kernels already launched; returns when the copies are done;
+ *   apd_run_after_depths     = the rest of the schedule.
+ * before + after launch exactly the kernels of apd_run, in its order: same bits.  K9, K10, K14 and K15 return APD_ERR_STATE
+ * while the depth maps of a split upload are outstanding. */
+int apd_upload_views_split(apd_handle h, int num_images, const apd_camera *cameras, const float *const *images);
+int apd_upload_depths(apd_handle h, int num_images, const float *const *depths);
+int apd_run_before_depths(apd_handle h);
+int apd_run_after_depths(apd_handle h);
+
 /* Prior state of a previous pass (APD.cpp:552-581, 643-661): planes = (world normal xyz, depth w),
  * selected-view bitmasks and weak map.  Any pointer may be NULL: planes/views zero, weak = all STRONG
  * (APD.cpp:541-547).  Builds the weak index map of APD.cpp:526-537. */
 int apd_upload_prior(apd_handle h, const float *planes4, const uint32_t *selected_views, const uint8_t *weak_info);
 
-/* APD::RunPatchMatch (APD.cu:2386-2495), without the final device->host copies. */
+/* APD::RunPatchMatch (APD.cu:2386-2495), without the final device->host copies.  One handle is one (view, pass), like one
+ * APD object: K14 rewrites the weak map the WEAK lists, the neighbour table and its index map were sized for, so a second
+ * apd_run -- or K3 / K8 / K9 / K10 through apd_run_kernel after K14 or after apd_upload_state(APD_STATE_WEAK_INFO) -- returns
+ * APD_ERR_STATE until apd_upload_prior or apd_reset re-arms the handle. */
 int apd_run(apd_handle h);
 
 /* One kernel of the schedule (single stepping for snapshot tests). */
@@ -187,12 +207,24 @@ int apd_device_memcpy(int device, void *dst, const void *src, size_t bytes);   /
 int apd_device_memset(int device, void *dst, int value, size_t bytes);
 int apd_device_memory(int device, size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo: does an in-memory run fit? */
 int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes /* 1, 4, 16 */);
+/* The same helpers on a HIP stream (hipStream_t, e.g. apd_get_stream of the handle whose kernels produce or consume the data):
+ * asynchronous, ordered with that stream's work and with nothing else -- the device-wide forms above wait for the whole device,
+ * which stalls every other view in flight on it.  apd_stream_synchronize waits for that stream alone. */
+int apd_device_memcpy_async(int device, void *hip_stream, void *dst, const void *src, size_t bytes);
+int apd_rescale_nearest_async(int device, void *hip_stream, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes);
+int apd_stream_synchronize(int device, void *hip_stream);
+/* (float4 plane = world normal xyz + depth w) -> the depth map and the 3-float normal map apd_fuse_views takes; device pointers. */
+int apd_split_planes_async(int device, void *hip_stream, const float *planes4, size_t pixels, float *depth, float *normal3);
+/* Page-locks / releases a host buffer (hipHostRegister): uploads from it run at the link's rate and asynchronously. */
+int apd_host_register(void *p, size_t bytes);
+int apd_host_unregister(void *p);
 
 /* All-gather across `num_ranks` ranks of this process, rank r on devices[r]: after apd_exchange_allgather every recv[r]
  * holds send[0] | send[1] | ... (bytes_per_rank each).  prefer_rccl != 0: RCCL (ncclCommInitAll, grouped ncclAllGather,
  * one stream per rank; librccl is opened at run time); direct hipMemcpyPeerAsync copies when librccl is missing, when its
- * initialisation fails or when the list names a device twice (how a one-GPU box runs the multi-device scheduler).
- * Blocking; not thread-safe per exchange object. */
+ * initialisation fails or when there is a single rank.  A list that names devices more than once (several scheduler ranks
+ * per device, e.g. 0,1,0,1) runs RCCL between one leader rank per device and copies inside the devices; 0,0,0 (one device)
+ * uses copies unless RCCL is forced.  Blocking; not thread-safe per exchange object. */
 typedef struct apd_exchange *apd_exchange_t;
 /* prefer_rccl != 0: RCCL, set up before the call returns.  That takes seconds (librccl + ncclCommInitAll: 5.6 s for ONE device on
  * the MI355X box) and cannot be hidden behind the first passes (on a background thread it stalls their launches for as long
@@ -237,6 +269,8 @@ int apd_get_option(apd_handle h, int option, int *value);
 
 /* Use an existing HIP stream (hipStream_t) instead of the handle's own. */
 int apd_set_stream(apd_handle h, void *hip_stream);
+/* The stream the handle launches on (hipStream_t), for the stream forms of the device helpers. */
+int apd_get_stream(apd_handle h, void **hip_stream);
 
 /* Depth-map fusion on the device: what RunFusion (APD.cpp:826-977, ETH variant) + ExportPointCloud (APD.cpp:214-254)
  * produce, i.e. <dense>/APD/APD.ply, from the final maps of every view (after the all-gather in a multi-GPU run).

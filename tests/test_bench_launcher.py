@@ -29,6 +29,32 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_slowest():
     assert len(per_rank) == 2 and per_rank[1] > 1.5 * per_rank[0]           # rank 1 sleeps twice as long
     assert out["ms_per_step"] >= per_rank[1] * 0.99                            # MAX over ranks, not rank 0's own time
     assert out["allgather_ms"] is not None
+    # the C4-shaped sub-line: two views per rank, the per-pass depth all-gather inside the timed region
+    sub = out["workloads"]["configs3_tt1080p_pass_with_exchange"]
+    assert sub["n_gpus"] == 2 and sub["config"]["views_per_gpu"] == 2 and sub["config"]["views"] == 4
+    assert sub["pass_allgather_inside_timed_region"] is True and sub["pass_allgather_ms"] > 0
+    assert len(sub["rank_ms_per_step"]) == 2 and sub["timed_region_ms"] >= max(sub["rank_ms_per_step"])
+    assert sub["timed_region_ms"] >= sub["pass_allgather_ms"]
+
+
+def test_sub_workload_table_names_every_baseline_config():
+    """The `workloads` block of the default line: configs[1] at 6 and 3 iterations, configs[2] (APD), configs[4] shape, configs[3]
+    frame size alone and as a sharded pass with its exchange; names resolve, the shared-scene lines share a workload."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    keys = [s[0] for s in bench.SUB_WORKLOADS]
+    assert len(set(keys)) == len(keys) >= 6
+    by_wl = {}
+    for key, name, steps, warmup, exch, vpg in bench.SUB_WORKLOADS:
+        (w, h, n), apd = bench.resolve_workload(name)
+        assert steps >= 1 and warmup >= 0 and vpg >= 1 and w * h > 0 and n >= 1
+        by_wl.setdefault(name, []).append((steps, exch))
+    assert (6, False) in by_wl[bench.DEFAULT_WORKLOAD] and (3, False) in by_wl[bench.DEFAULT_WORKLOAD]
+    assert bench.resolve_workload("eth3d_pipes_fullres_10src_apd")[1] is True and "eth3d_pipes_fullres_10src_apd" in by_wl
+    assert (8, False) in by_wl["synthetic_4096x3072_16src"]
+    assert any(exch for _, exch in by_wl["tt_family_1080p_10src"])
 
 
 def test_refuses_more_gpus_than_visible():

@@ -210,6 +210,43 @@ def test_subset_of_views_with_source_only_images(gpu_pkg, synth, tmp_path):
     assert pa == pb and len(_read_ply(a / "APD" / "APD.ply")[0]) > 0
 
 
+def test_subset_run_ignores_what_an_earlier_full_run_left_on_disk(gpu_pkg, synth, tmp_path):
+    """whether a source is source-only (zero depth map in the geometric term) is decided by membership in
+    pair.txt, not by the result folders on the disk.  A full run with --keep-maps leaves APD/00000003/depths.dmb behind; a
+    later run of the same folder that reconstructs views 0..2 only must write what it writes in a clean folder -- in the file
+    mode (where the stale map used to be read) and in memory."""
+    import shutil
+    W, H, nviews, seed = 72, 56, 4, 5
+    dirty, clean, mem = tmp_path / "dirty", tmp_path / "clean", tmp_path / "mem"
+    dirty.mkdir()
+    _write_dense_folder(dirty, synth, W, H, nviews, jpeg=False)
+    pair = "3\n"
+    for i in range(3):
+        srcs = [j for j in range(nviews) if j != i]
+        pair += "%d\n%d %s\n" % (i, len(srcs), " ".join("%d %.1f" % (j, 10.0 - k) for k, j in enumerate(srcs)))
+
+    def run(folder, *flags):
+        r = subprocess.run([APD_BIN, str(folder), "0", "--seed", str(seed), "--iters", "1", "--keep-maps"] + list(flags),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+
+    shutil.copytree(dirty, clean)
+    run(dirty, "--files")                                    # all four views: leaves APD/00000003/* behind
+    assert (dirty / "APD" / "00000003" / "depths.dmb").exists()
+    for f in (dirty, clean):
+        (f / "pair.txt").write_text(pair)
+    shutil.copytree(clean, mem)
+    run(dirty, "--files")
+    run(clean, "--files")
+    run(mem, "--in-memory")
+    for idx in range(3):
+        for name in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
+            want = (clean / "APD" / ("%08d" % idx) / name).read_bytes()
+            assert (dirty / "APD" / ("%08d" % idx) / name).read_bytes() == want, ("files, stale folder", idx, name)
+            assert (mem / "APD" / ("%08d" % idx) / name).read_bytes() == want, ("in memory", idx, name)
+    assert (dirty / "APD" / "APD.ply").read_bytes() == (clean / "APD" / "APD.ply").read_bytes() == (mem / "APD" / "APD.ply").read_bytes()
+
+
 def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path):
     """`APD folder 0,0,0` (host/multi_device.cpp: three scheduler ranks -- here all on the one GPU of the box -- views sharded
     round-robin, state resident on the device, depth maps all-gathered after every pass, planes and weak maps before the
@@ -223,7 +260,7 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     _write_dense_folder(base, synth, W, H, nviews, jpeg=False)
     runs = {}
     for name, dev, extra in (("one", "0", ["--jacobi", "--rccl", "--ranks", "1"]), ("one_default", "0", ["--jacobi"]),
-                             ("one_copy", "0", ["--jacobi", "--no-rccl", "--ranks", "1"]), ("three_rccl", "0", ["--jacobi", "--rccl"]),
+                             ("one_copy", "0", ["--jacobi", "--no-rccl", "--ranks", "1"]), ("three_rccl", "0,0,0", ["--rccl"]),
                              ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", ["--files"]), ("in_memory", "0", [])):
         d = tmp_path / name
         shutil.copytree(base, d)
@@ -231,11 +268,12 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
                            stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:]
         runs[name] = (d, r.stdout)
-    # ranks: a small frame takes three per device (--ranks N: exactly N); with RCCL the leader rank of the device runs the
-    # collective (here with itself) and the two others copy its result
-    assert "processed on 1 rank(s)" in runs["one"][1] and "processed on 1 rank(s)" in runs["one_copy"][1]
-    assert "processed on 3 rank(s)" in runs["one_default"][1] and "processed on 2 rank(s)" in runs["two"][1]
-    assert "processed on 3 rank(s)" in runs["three_rccl"][1]
+    # views in flight: a small frame takes three per rank (--ranks N: exactly N), each on its own thread, handle and stream; a list
+    # that repeats a device is taken as given, one view per rank -- with RCCL the leader rank of the device runs the collective
+    # (here with itself) and the two others copy its result
+    assert "processed on 1 rank(s), 1 view(s) in flight" in runs["one"][1] and "processed on 1 rank(s), 1 view(s) in flight" in runs["one_copy"][1]
+    assert "processed on 1 rank(s), 3 view(s) in flight" in runs["one_default"][1] and "processed on 2 rank(s), 1 view(s) in flight" in runs["two"][1]
+    assert "processed on 3 rank(s), 1 view(s) in flight" in runs["three_rccl"][1] and "processed on 3 rank(s), 1 view(s) in flight" in runs["three"][1]
     assert "Exchange of depth maps between passes: rccl\n" in runs["three_rccl"][1], runs["three_rccl"][1][-2000:]
     assert "through RCCL, 0 through direct copies" in runs["three_rccl"][1]
     assert "Exchange of depth maps between passes: rccl\n" in runs["one"][1], runs["one"][1][-2000:]
@@ -256,7 +294,8 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     assert len(_read_ply(ref / "APD" / "APD.ply")[0]) > 0.3 * W * H
     # --in-memory: the same scheduler in the reference's order of views gives the bytes of the file-based driver
     fd, md = runs["files"][0], runs["in_memory"][0]
-    assert "processed on 1 rank(s)" in runs["in_memory"][1]
+    # ... with three views in flight: photometric passes have no order, a view of a geometric pass waits for its earlier sources
+    assert "processed on 1 rank(s), 3 view(s) in flight" in runs["in_memory"][1]
     for idx in range(nviews):
         for f in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
             assert (fd / "APD" / ("%08d" % idx) / f).read_bytes() == (md / "APD" / ("%08d" % idx) / f).read_bytes(), ("in_memory", idx, f)

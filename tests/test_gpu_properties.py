@@ -223,3 +223,45 @@ def test_recycled_handle_equals_a_new_one(gpu_pkg, synth):
         assert np.array_equal(common.bits(h.state(which)), common.bits(fresh.state(which))), which
     h.close()
     fresh.close()
+
+
+@pytest.mark.parametrize("use_apd", [0, 1])
+def test_split_pass_around_the_depth_maps_changes_no_bit(gpu_pkg, ob, synth, use_apd):
+    """apd_upload_views_split + apd_run_before_depths + apd_upload_depths + apd_run_after_depths (a scheduler that starts a
+    view before its sources of the same pass have published their depth maps) == apd_run == the oracle, for a geometric pass
+    with and without WEAK pixels and for a photometric pass; the kernels that read depth maps are refused while the maps are
+    outstanding, and rubbish in the depth buffers before the late upload changes nothing."""
+    W, H, N = 96, 72, 4
+    sc, imgs = common.scene_inputs(synth, W, H, N, seed=3, textureless=0.25 if use_apd else 0.0)
+    cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+    p0 = common.base_params(sc, N, seed=11, state=0, use_APD=0, weak_peak_radius=6)
+    h = gpu_pkg.Handle(W, H, gpu_pkg.default_params(**p0))
+    h.upload_views_split(cams, imgs)          # photometric: nothing to wait for, the first half is the whole pass
+    h.run_before_depths()
+    h.run_after_depths()
+    o = common.make_oracle(ob, sc, imgs, N, p0)
+    o.run()
+    common.assert_state_equal(gpu_pkg, h, o, "split photometric pass")
+    planes, weak, views = h.download()
+    prior = common.postprocess(planes, weak, views, p0["depth_min"], p0["depth_max"])
+    o.close()
+    depths = common.fake_depth_maps(W, H, N + 1)
+    p1 = common.base_params(sc, N, seed=12, state=2, use_APD=use_apd, weak_peak_radius=4, geom_consistency=1, max_iterations=2)
+    h.reset(gpu_pkg.default_params(**p1))
+    h.upload_views_split(cams, imgs)
+    h.upload_prior(prior[0], prior[1], prior[2] if use_apd else None)
+    assert (h.weak_count > 50) == bool(use_apd)
+    for kid in (9, 10, 14, 15):
+        with pytest.raises(gpu_pkg.ApdError, match="apd_upload_depths"):
+            h.run_kernel(kid)
+    with pytest.raises(gpu_pkg.ApdError, match="apd_upload_depths"):
+        h.run_after_depths()
+    h.run_before_depths()
+    h.synchronize()
+    h.upload_depths(depths)
+    h.run_after_depths()
+    o = common.make_oracle(ob, sc, imgs, N, p1, depths=depths, prior=(prior[0], prior[1], prior[2] if use_apd else None))
+    o.run()
+    common.assert_state_equal(gpu_pkg, h, o, "split geometric pass, use_APD=%d" % use_apd)
+    h.close()
+    o.close()

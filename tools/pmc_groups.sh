@@ -6,7 +6,7 @@ ARGS="${PMC_ARGS:---workload synthetic_4096x3072_8src --steps 2 --warmup 1 --no-
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $OUT/g$i -o pmc -- python bench.py $ARGS > $OUT/bench_g$i.json 2> $OUT/g$i.err || echo "group $i failed: $(tail -2 $OUT/g$i.err)"
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $OUT/g$i -o pmc -- python bench.py --no-workloads $ARGS > $OUT/bench_g$i.json 2> $OUT/g$i.err || echo "group $i failed: $(tail -2 $OUT/g$i.err)"
   python tools/pmc_summary.py $OUT/g$i $OUT/g${i}_summary.csv > /dev/null
 done
 find $OUT -type f -size +1M -delete

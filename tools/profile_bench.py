@@ -71,7 +71,7 @@ def main():
         raw = os.path.join("/tmp", "apd_prof_%s_%s" % (tag, name))
         subprocess.call(["rm", "-rf", raw])
         cmd = ["rocprofv3"] + prof_flags + ["--output-format", "csv", "-d", raw, "-o", name, "--", sys.executable,
-                                           os.path.join(ROOT, "bench.py")] + flags + ["--no-cpu-baseline"]
+                                           os.path.join(ROOT, "bench.py")] + flags + ["--no-cpu-baseline", "--no-workloads"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, timeout=1500)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:

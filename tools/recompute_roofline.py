@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Recomputes every `roofline` field of the committed bench lines from the committed counter files, nothing else.
 
-    python tools/recompute_roofline.py [profiles/r03]
+    python tools/recompute_roofline.py [profiles/rNN]      (default: the newest round that holds bench lines)
 
 For each bench line under the directory (bench_default.json, bench_driver_s20_w5.json, bench_apd_s3_w1.json, ...) it finds the
 counter profile of the same workload / --steps / --warmup (pmc_bench_<workload>_s<steps>_w<warmup>.json, written by
@@ -36,12 +36,16 @@ TAG_PEAK = 256 * 2.4 * 1.85  # G L1 tag accesses / s (bench.py: TCP_ACCESSES_PER
 
 
 def load_mix(directory):
-    """valu_mix_k67w.json of this directory, else the newest one of an earlier round (the window body has not changed)."""
-    cands = [os.path.join(directory, "valu_mix_k67w.json")] + sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "valu_mix_k67w.json")), reverse=True)
+    """valu_mix_k67w.json of the directory the counter profile lies in (the static mix of that round's kernel), or None: a line
+    without `valu_busy_estimate` is then expected (rounds 2 and 3 shared round 2's file; since round 4 a mix is never borrowed)."""
+    legacy = os.path.basename(os.path.normpath(directory)) in ("r02", "r03")
+    cands = [os.path.join(directory, "valu_mix_k67w.json")]
+    if legacy:
+        cands += sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[23]", "valu_mix_k67w.json")), reverse=True)
     for c in cands:
         if os.path.exists(c):
             return json.load(open(c))["window_body"]["mean_cycles_per_inst"]
-    raise SystemExit("no valu_mix_k67w.json under profiles/")
+    return None
 
 
 def timed_mean(k, profiled_steps, launches):
@@ -68,22 +72,25 @@ def check_k67(tag, roof, k, mix, problems, profiled_steps):
     traffic = mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024
     t = roof["avg_launch_ms"] * 1e-3
     achieved = insts / t / 1e9
-    for what, got, want, rel in (
+    for what, got, want, rel in ((
             ("valu_insts_per_launch", roof["valu_insts_per_launch"], insts, 1e-9),
             ("achieved", roof["achieved"], achieved, 1e-3),
             ("frac", roof["frac"], achieved / PEAK, 1e-3),
             ("peak", roof["peak"], PEAK, 1e-6),
             ("traffic", roof["traffic"], traffic, 1e-9),
             ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
-            ("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),
-            ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03)):
+            ) + ((("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),) if mix else ()) + (
+            ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03),)):
         ok = got == want if rel == 0 else close(got, want, rel)
         if not ok:
             problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
-    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or roof["valu_busy_estimate"]["frac"] > 1:
+    if mix is None and "valu_busy_estimate" in roof:
+        problems.append("%s: valu_busy_estimate without a valu_mix_k67w.json of the profile's own round" % tag)
+    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or (mix and roof["valu_busy_estimate"]["frac"] > 1):
         problems.append("%s: a fraction above 1" % tag)
-    return "k67 frac %.4f  hbm %.4f  busy %.4f  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
-        achieved / PEAK, traffic / t / 1e9 / HBM, insts * mix / (1024 * 2.4e9 * t), n, t * 1e3, mean("duration_ns@trace") * 1e-6)
+    return "k67 frac %.4f  hbm %.4f  busy %s  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
+        achieved / PEAK, traffic / t / 1e9 / HBM, ("%.4f" % (insts * mix / (1024 * 2.4e9 * t))) if mix else "n/a", n, t * 1e3,
+        mean("duration_ns@trace") * 1e-6)
 
 
 def check_k910(tag, roof, k, problems, profiled_steps):
@@ -113,6 +120,13 @@ def check_k910(tag, roof, k, problems, profiled_steps):
         achieved / TAG_PEAK, traffic / t / 1e9 / HBM, insts / t / 1e9 / PEAK, n, t * 1e3, mean("duration_ns@trace") * 1e-6)
 
 
+def sub_lines(name, line):
+    """The line itself and every sub-line of its `workloads` block (round 4: every BASELINE config in one process)."""
+    yield name, line
+    for key, sub in (line.get("workloads") or {}).items():
+        yield "%s[%s]" % (name, key), sub
+
+
 def check(directory):
     problems, lines = [], 0
     mix = load_mix(directory)
@@ -120,40 +134,46 @@ def check(directory):
         with open(path) as f:
             first = f.readline()
         try:
-            line = json.loads(first)
+            top = json.loads(first)
         except ValueError:
             continue
-        roof = line.get("roofline")
-        if not roof or roof.get("achieved") is None:
-            continue
-        cfg = line["config"]
-        # the profile the line names (any --steps / --warmup of a workload is served by one profile of that workload, see timed_mean)
-        prof_path = os.path.join(ROOT, roof.get("pmc_source") or "")
-        if not roof.get("pmc_source") or not os.path.exists(prof_path):
-            problems.append("%s: cites counters but %r is not committed" % (os.path.basename(path), roof.get("pmc_source")))
-            continue
-        prof = json.load(open(prof_path))
-        kernels, pcfg = prof["kernels"], prof["config"]
-        tag = os.path.basename(path)
-        if pcfg["workload"] != cfg["workload"] or list(pcfg.get("options", [])) != list(cfg.get("options", [])):
-            problems.append("%s: profile %s is of workload %s options %s" % (tag, roof["pmc_source"], pcfg["workload"], pcfg.get("options")))
-            continue
-        if line["steps"] * 2 != roof["launches"]:
-            problems.append("%s: %d launches for %d steps" % (tag, roof["launches"], line["steps"]))
-        lines += 1
-        if roof.get("bound") == "l1-tag-pipeline":
-            msg = check_k910(tag, roof, kernels["k910"], problems, pcfg["steps"])
-            strong = line.get("strong_path")
-            if strong and strong.get("achieved") is not None:
-                msg += " | " + check_k67(tag + " strong_path", strong, kernels["k67"], mix, problems, pcfg["steps"])
-        else:
-            msg = check_k67(tag, roof, kernels["k67"], mix, problems, pcfg["steps"])
-        print("%-36s %s  %s" % (tag, cfg["workload"], msg))
+        for tag, line in sub_lines(os.path.basename(path), top):
+            roof = line.get("roofline")
+            if not roof or roof.get("achieved") is None:
+                continue
+            cfg = line["config"]
+            # the profile the line names (any --steps / --warmup of a workload is served by one profile of that workload, see timed_mean)
+            prof_path = os.path.join(ROOT, roof.get("pmc_source") or "")
+            if not roof.get("pmc_source") or not os.path.exists(prof_path):
+                problems.append("%s: cites counters but %r is not committed" % (tag, roof.get("pmc_source")))
+                continue
+            prof = json.load(open(prof_path))
+            kernels, pcfg = prof["kernels"], prof["config"]
+            if pcfg["workload"] != cfg["workload"] or list(pcfg.get("options", [])) != list(cfg.get("options", [])):
+                problems.append("%s: profile %s is of workload %s options %s" % (tag, roof["pmc_source"], pcfg["workload"], pcfg.get("options")))
+                continue
+            if line["steps"] * 2 != roof["launches"]:
+                problems.append("%s: %d launches for %d steps" % (tag, roof["launches"], line["steps"]))
+            lines += 1
+            line_mix = load_mix(os.path.dirname(prof_path)) if os.path.dirname(prof_path) != os.path.normpath(directory) else mix
+            if roof.get("bound") == "l1-tag-pipeline":
+                msg = check_k910(tag, roof, kernels["k910"], problems, pcfg["steps"])
+                strong = line.get("strong_path")
+                if strong and strong.get("achieved") is not None:
+                    msg += " | " + check_k67(tag + " strong_path", strong, kernels["k67"], line_mix, problems, pcfg["steps"])
+            else:
+                msg = check_k67(tag, roof, kernels["k67"], line_mix, problems, pcfg["steps"])
+            print("%-36s %s  %s" % (tag, cfg["workload"], msg))
     return problems, lines
 
 
+def newest_round():
+    rounds = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]")) if glob.glob(os.path.join(d, "bench_*.json")))
+    return rounds[-1] if rounds else os.path.join(ROOT, "profiles", "r02")
+
+
 def main():
-    directory = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02")
+    directory = sys.argv[1] if len(sys.argv) > 1 else newest_round()   # the newest round that holds bench lines, like bench.py's profile choice
     problems, lines = check(directory)
     for p in problems:
         print("MISMATCH " + p)
