@@ -288,6 +288,28 @@ int apd_device_memcpy_async(int device, void *hip_stream, void *dst, const void 
     return APD_OK;
 }
 
+int apd_stream_create(int device, void **hip_stream)
+{
+    if (!hip_stream) {
+        return xfail(APD_ERR_INVALID, "apd_stream_create: null result pointer");
+    }
+    hipStream_t st = nullptr;
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *hip_stream = (void *)st;
+    return APD_OK;
+}
+
+int apd_stream_destroy(int device, void *hip_stream)
+{
+    if (!hip_stream) {
+        return APD_OK;
+    }
+    X_TRY(hipSetDevice(device));
+    X_TRY(hipStreamDestroy((hipStream_t)hip_stream));
+    return APD_OK;
+}
+
 int apd_stream_synchronize(int device, void *hip_stream)
 {
     X_TRY(hipSetDevice(device));

@@ -86,7 +86,7 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems) {
 namespace {
 
 bool prepare_fusion_inputs(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps, int map_cols,
-                           int map_rows, std::vector<FusionView> &views, std::vector<std::vector<int>> &sources)
+                           int map_rows, std::vector<FusionView> &views, std::vector<std::vector<int>> &sources, unsigned threads = 0)
 {
     const bool on_device = !maps && map_cols > 0 && map_rows > 0;
     views.assign(problems.size(), FusionView());
@@ -162,7 +162,7 @@ bool prepare_fusion_inputs(const path &dense_folder, const std::vector<Problem> 
                 }
             }
         }
-    }, 0);
+    }, threads);
     for (int f : failed) {
         if (f) {
             return false;
@@ -226,7 +226,7 @@ struct FusionPrefetch {
     std::string error;
 };
 
-FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Problem> &problems, int device, int cols, int rows)
+FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Problem> &problems, int device, int cols, int rows, unsigned threads)
 {
     FusionPrefetch *f = new FusionPrefetch();
     f->dense_folder = dense_folder;
@@ -234,9 +234,9 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
     f->device = device;
     f->cols = cols;
     f->rows = rows;
-    f->worker = std::thread([f]() {
+    f->worker = std::thread([f, threads]() {
         const auto t0 = std::chrono::steady_clock::now();
-        if (!prepare_fusion_inputs(f->dense_folder, f->problems, nullptr, f->cols, f->rows, f->views, f->sources)) {
+        if (!prepare_fusion_inputs(f->dense_folder, f->problems, nullptr, f->cols, f->rows, f->views, f->sources, threads)) {
             f->error = "fusion inputs could not be read";
             return;
         }
@@ -254,12 +254,36 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
             f->owned.push_back(p);
             return p;
         };
+        // one allocation for every view's colour image: device allocations are not free while other threads launch kernels
+        const size_t image_bytes = n * 4 * (size_t)f->channels;
+        void *all_images = nullptr;
+        if (apd_device_malloc(f->device, image_bytes * (size_t)std::max(V, 1), &all_images) != APD_OK) {
+            f->error = std::string("fusion: device allocation failed: ") + apd_exchange_last_error();
+            return;
+        }
+        f->owned.push_back(all_images);
+        // Uploads on a stream of their own from page-locked memory: a plain hipMemcpy of pageable memory held up the kernels of
+        // the passes running beside it (24 views of 1920 x 1080: passes 8.2 -> 8.6 s, all that the early start had saved).
+        void *stream = nullptr;
+        if (apd_stream_create(f->device, &stream) != APD_OK) {
+            stream = nullptr;
+        }
         for (int i = 0; i < V; ++i) {
-            f->imgs[i] = (const float *)upload(f->views[i].image.data(), n * 4 * (size_t)f->channels);
-            f->views[i].image = Mat();  // the host copy is done with
-            if (!f->imgs[i]) {
+            void *dst = (char *)all_images + (size_t)i * image_bytes;
+            void *src = f->views[i].image.data();
+            const bool pinned = stream && apd_host_register(src, image_bytes) == APD_OK;
+            const int rc = pinned ? (apd_device_memcpy_async(f->device, stream, dst, src, image_bytes) != APD_OK ? APD_ERR_HIP : apd_stream_synchronize(f->device, stream))
+                                  : apd_device_memcpy(f->device, dst, src, image_bytes);
+            if (pinned) {
+                apd_host_unregister(src);
+            }
+            if (rc != APD_OK) {
+                f->error = std::string("fusion: device upload failed: ") + apd_exchange_last_error();
+                apd_stream_destroy(f->device, stream);
                 return;
             }
+            f->imgs[i] = (const float *)dst;
+            f->views[i].image = Mat();  // the host copy is done with
             if (!f->views[i].block.empty()) {
                 f->blocks[i] = (const uint8_t *)upload(f->views[i].block.data(), n);
                 if (!f->blocks[i]) {
@@ -268,6 +292,7 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
                 f->any_block = true;
             }
         }
+        apd_stream_destroy(f->device, stream);
         f->prepare_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
         f->ok = true;
     });

@@ -65,6 +65,8 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.keep_maps = true;
         } else if (a == "--no-fusion") {
             o.no_fusion = true;
+        } else if (a == "--late-fusion-inputs") {
+            o.late_fusion_inputs = true;
         } else if (a == "--jacobi") {
             o.jacobi = true;
         } else if (a == "--in-memory") {

@@ -153,7 +153,10 @@ struct StageClock {
 // wall time, 2 % at 6200 x 4130).
 }  // namespace
 
-int DefaultLanes(size_t pixels) { return pixels <= ((size_t)4 << 20) ? 3 : (pixels <= ((size_t)12 << 20) ? 2 : 1); }
+int DefaultLanes(size_t pixels)
+{
+    return pixels <= ((size_t)1 << 20) ? 6 : (pixels <= ((size_t)4 << 20) ? 3 : (pixels <= ((size_t)12 << 20) ? 2 : 1));
+}
 
 // Device bytes an in-memory run keeps resident on its busiest device (rank 0 also fuses): level images, the two sets of
 // depth maps, every owned view's state, per lane the handle's own arrays (state 107 B/px, images + depth maps of the view
@@ -228,11 +231,16 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             distinct = distinct && devices[i] != devices[j];
         }
     }
-    int lanes = opt.ranks_per_device > 0 ? opt.ranks_per_device : (distinct ? DefaultLanes(pix0) : 1);
-    lanes = std::max(1, std::min(lanes, (V + G - 1) / G));
-    const bool gauss_seidel = opt.in_memory;  // the reference's order of views (one rank); otherwise Jacobi over views
     const int round_num = opt.single_level ? 1 : RoundNum(W0, H0);
-    printf("There are %d problems needed to be processed on %d rank(s), %d view(s) in flight per rank!\nRound nums: %d\n", V, G, lanes, round_num);
+    // per pyramid level: a coarse level's launches are small, more of its views fit the device side by side
+    auto lanes_at = [&](size_t level_pixels) {
+        const int want = opt.ranks_per_device > 0 ? opt.ranks_per_device : (distinct ? DefaultLanes(level_pixels) : 1);
+        return std::max(1, std::min(want, (V + G - 1) / G));
+    };
+    const int coarsest = opt.single_level ? 1 : 1 << (round_num - 1);
+    const int lanes = std::max(lanes_at(pix0), lanes_at((size_t)std::lround(W0 / (double)coarsest) * (size_t)std::lround(H0 / (double)coarsest)));
+    const bool gauss_seidel = opt.in_memory;  // the reference's order of views (one rank); otherwise Jacobi over views
+    printf("There are %d problems needed to be processed on %d rank(s), up to %d view(s) in flight per rank!\nRound nums: %d\n", V, G, lanes, round_num);
     {
         size_t free_bytes = 0, total_bytes = 0;
         const double need = (double)pix0 * InMemoryBytesPerPixel(N, V, G, lanes, (int)max_src);
@@ -244,7 +252,8 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
     }
 
     // colour images, cameras and masks of the fusion: decoded and uploaded to rank 0's device behind the passes
-    FusionPrefetch *fusion_inputs = opt.no_fusion ? nullptr : StartFusionInputs(opt.dense_folder, problems, devices[0], W0, H0);
+    // (four decode threads: the lanes' host threads must stay prompt with their launches)
+    FusionPrefetch *fusion_inputs = (opt.no_fusion || opt.late_fusion_inputs) ? nullptr : StartFusionInputs(opt.dense_folder, problems, devices[0], W0, H0, 4);
     Failure failure;
     std::vector<Rank> ranks(G);
     apd_exchange_t exchange = nullptr;
@@ -377,16 +386,17 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                 if (failure.failed) {
                     throw std::runtime_error(failure.what);
                 }
-                printf("Image size: %d * %d\n", LW, LH);
+                printf("Image size: %d * %d, %d view(s) in flight per rank\n", LW, LH, lanes_at((size_t)LW * LH));
                 ms_upload += up.lap();
             }
             const size_t pix = (size_t)LW * LH;
+            const int level_lanes = lanes_at(pix);
 
             // ---- `lanes` host threads per rank, each with its own handle and stream; a rank's views are handed out in order ----
             std::vector<std::thread> workers;
             for (int r = 0; r < G; ++r) {
                 ranks[r].next.store(0);
-                for (int li = 0; li < lanes; ++li) {
+                for (int li = 0; li < level_lanes; ++li) {
                     workers.emplace_back([&, r, li]() {
                         Rank &k = ranks[r];
                         Lane &lane = k.lanes[li];
@@ -624,6 +634,9 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             }
             if (LW != W0 || LH != H0) {
                 throw std::runtime_error("the last pass did not run at the full resolution");  // BuildSchedule ends at scale 1
+            }
+            if (!fusion_inputs) {
+                fusion_inputs = StartFusionInputs(opt.dense_folder, problems, devices[0], W0, H0, 0);
             }
             RunFusionOnDevice(fusion_inputs, d, n, fuse_weak);
             fusion_inputs = nullptr;

@@ -25,6 +25,7 @@ struct Options {
     int iters = 3;          // PatchMatchParams::max_iterations of every pass (reference: 3)
     int max_src = 0;        // > 0: keep only the first N sources of each pair.txt entry (they are sorted by score)
     bool single_level = false, keep_maps = false, no_fusion = false;
+    bool late_fusion_inputs = false;  // --late-fusion-inputs: colour decode + upload after the passes instead of behind them (A/B measurements)
 };
 
 
@@ -114,7 +115,7 @@ void RunFusionWithMaps(const path &dense_folder, const std::vector<Problem> &pro
 // downloaded.  StartFusionInputs decodes the colour images, reads cameras and masks and uploads them on a background thread
 // (call it before the passes); RunFusionOnDevice joins it and fuses; CancelFusionInputs joins and frees without fusing.
 struct FusionPrefetch;
-FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Problem> &problems, int device, int cols, int rows);
+FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Problem> &problems, int device, int cols, int rows, unsigned threads);
 void RunFusionOnDevice(FusionPrefetch *inputs, const std::vector<const float *> &depths, const std::vector<const float *> &normals,
                        const std::vector<const uint8_t *> &weaks);
 void CancelFusionInputs(FusionPrefetch *inputs);

@@ -213,6 +213,8 @@ int apd_rescale_nearest_device(int device, const void *src, int src_w, int src_h
 int apd_device_memcpy_async(int device, void *hip_stream, void *dst, const void *src, size_t bytes);
 int apd_rescale_nearest_async(int device, void *hip_stream, const void *src, int src_w, int src_h, void *dst, int dst_w, int dst_h, int elem_bytes);
 int apd_stream_synchronize(int device, void *hip_stream);
+int apd_stream_create(int device, void **hip_stream);    /* a non-blocking stream of its own (not ordered with the null stream) */
+int apd_stream_destroy(int device, void *hip_stream);
 /* (float4 plane = world normal xyz + depth w) -> the depth map and the 3-float normal map apd_fuse_views takes; device pointers. */
 int apd_split_planes_async(int device, void *hip_stream, const float *planes4, size_t pixels, float *depth, float *normal3);
 /* Page-locks / releases a host buffer (hipHostRegister): uploads from it run at the link's rate and asynchronously. */

@@ -268,12 +268,12 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
                            stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:]
         runs[name] = (d, r.stdout)
-    # views in flight: a small frame takes three per rank (--ranks N: exactly N), each on its own thread, handle and stream; a list
+    # views in flight: a small frame takes up to six per rank (five views here; --ranks N: exactly N), each on its own thread, handle and stream; a list
     # that repeats a device is taken as given, one view per rank -- with RCCL the leader rank of the device runs the collective
     # (here with itself) and the two others copy its result
-    assert "processed on 1 rank(s), 1 view(s) in flight" in runs["one"][1] and "processed on 1 rank(s), 1 view(s) in flight" in runs["one_copy"][1]
-    assert "processed on 1 rank(s), 3 view(s) in flight" in runs["one_default"][1] and "processed on 2 rank(s), 1 view(s) in flight" in runs["two"][1]
-    assert "processed on 3 rank(s), 1 view(s) in flight" in runs["three_rccl"][1] and "processed on 3 rank(s), 1 view(s) in flight" in runs["three"][1]
+    assert "processed on 1 rank(s), up to 1 view(s) in flight" in runs["one"][1] and "processed on 1 rank(s), up to 1 view(s) in flight" in runs["one_copy"][1]
+    assert "processed on 1 rank(s), up to 5 view(s) in flight" in runs["one_default"][1] and "processed on 2 rank(s), up to 1 view(s) in flight" in runs["two"][1]
+    assert "processed on 3 rank(s), up to 1 view(s) in flight" in runs["three_rccl"][1] and "processed on 3 rank(s), up to 1 view(s) in flight" in runs["three"][1]
     assert "Exchange of depth maps between passes: rccl\n" in runs["three_rccl"][1], runs["three_rccl"][1][-2000:]
     assert "through RCCL, 0 through direct copies" in runs["three_rccl"][1]
     assert "Exchange of depth maps between passes: rccl\n" in runs["one"][1], runs["one"][1][-2000:]
@@ -294,8 +294,8 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     assert len(_read_ply(ref / "APD" / "APD.ply")[0]) > 0.3 * W * H
     # --in-memory: the same scheduler in the reference's order of views gives the bytes of the file-based driver
     fd, md = runs["files"][0], runs["in_memory"][0]
-    # ... with three views in flight: photometric passes have no order, a view of a geometric pass waits for its earlier sources
-    assert "processed on 1 rank(s), 3 view(s) in flight" in runs["in_memory"][1]
+    # ... with five views in flight: photometric passes have no order, a view of a geometric pass waits for its earlier sources
+    assert "processed on 1 rank(s), up to 5 view(s) in flight" in runs["in_memory"][1]
     for idx in range(nviews):
         for f in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
             assert (fd / "APD" / ("%08d" % idx) / f).read_bytes() == (md / "APD" / ("%08d" % idx) / f).read_bytes(), ("in_memory", idx, f)

@@ -95,7 +95,9 @@ def main():
                         per_dispatch[key][r_["Counter_Name"]].append(float(r_["Counter_Value"]))
                         meta[key] = {"kernel_name": r_["Kernel_Name"], "grid": r_["Grid_Size"], "workgroup": r_["Workgroup_Size"],
                                      "lds_bytes": r_["LDS_Block_Size"], "scratch_bytes_per_lane": r_["Scratch_Size"],
-                                     "vgpr": r_["VGPR_Count"], "sgpr": r_["SGPR_Count"]}
+                                     # rocprofv3's VGPR_Count / SGPR_Count columns are granule values of the dispatch packet, NOT the kernel's
+                                     # allocation: the allocation, spills and occupancy are in profiles/<round>/kernel_resources.txt (tools/kres.py)
+                                     "rocprof_vgpr_field": r_["VGPR_Count"], "rocprof_sgpr_field": r_["SGPR_Count"]}
         if name == "trace":
             for path in glob.glob(os.path.join(raw, "**", "*kernel_stats.csv"), recursive=True):
                 with open(path) as f, open(os.path.join(out_dir, "kernel_stats_%s.csv" % tag), "w") as g:
@@ -155,9 +157,9 @@ def main():
         w.writerow(["kernel", "counter", "timed_launch_index", "value"])
         w.writerows(rows_csv)
     for key, k in out["kernels"].items():
-        print("%s: %s launches, %.3f ms/launch, VALU %.4g/launch, fetch %.4g B, write %.4g B, scratch %s B/lane, vgpr %s" % (
+        print("%s: %s launches, %.3f ms/launch, VALU %.4g/launch, fetch %.4g B, write %.4g B, scratch %s B/lane" % (
             key, k["launches_timed"], k["launch_ms"] or 0, k["valu_insts_per_launch"] or 0, k["fetch_bytes_per_launch"] or 0,
-            k["write_bytes_per_launch"] or 0, k.get("scratch_bytes_per_lane"), k.get("vgpr")))
+            k["write_bytes_per_launch"] or 0, k.get("scratch_bytes_per_lane")))
     return 0
 
 

@@ -1,8 +1,9 @@
 #!/bin/bash
 # One round's measurement set, on the GPU box: counter profiles (tools/profile_bench.py) of every workload a bench line is
 # committed for, then the bench lines themselves -- made AFTER their profiles, in the same checkout, so that every roofline
-# field follows from the committed counters (tools/recompute_roofline.py).  Usage: tools/profile_round.sh <out_dir>
+# field follows from the committed counters (tools/recompute_roofline.py).  Usage: tools/profile_round.sh <out_dir> [round, e.g. r04]
 OUT=${1:-gpurun_out/profile_round}
+ROUND=${2:-r04}
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
@@ -13,18 +14,25 @@ run_profile eth3d_office_fullres_8src 24
 run_profile eth3d_pipes_fullres_10src_apd 6
 run_profile synthetic_4096x3072_16src 8
 run_profile tt_family_1080p_10src 24
-mkdir -p profiles/r03 && cp "$OUT"/pmc_bench_*.json profiles/r03/   # where they will be committed; bench.py looks under profiles/*/
+mkdir -p profiles/$ROUND && cp "$OUT"/pmc_bench_*.json profiles/$ROUND/   # where they will be committed; bench.py looks under profiles/*/
+# the two lines of the round: the default command and the driver's; each carries the `workloads` block (every BASELINE config)
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_driver_s20_w5.json" 2>/dev/null
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_ref_default_pass_s3_w1.json" 2>/dev/null
-python bench.py --workload eth3d_pipes_fullres_10src_apd --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_apd_s3_w1.json" 2>/dev/null
-python bench.py --workload synthetic_4096x3072_16src --steps 8 --warmup 1 --no-cpu-baseline > "$OUT/bench_16src_s8_w1.json" 2>/dev/null
-python bench.py --workload tt_family_1080p_10src --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_tt1080p_s20_w5.json" 2>/dev/null
+# the rocprofv3 --kernel-trace --stats summary of the driver's command, workloads block included
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/apd_trace_driver -o trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_driver_traced.json" 2> "$OUT/trace_driver.err"
+find /tmp/apd_trace_driver -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bench_driver_s20_w5_with_workloads.csv" \;
+rm -rf /tmp/apd_trace_driver
 
-for f in "$OUT"/bench_*.json; do python - "$f" <<'PY'
+for f in "$OUT"/bench_default.json "$OUT"/bench_driver_s20_w5.json; do python - "$f" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).readline())
-r = d["roofline"]
-print("%-34s %8.2f %s  %s frac %s  %.3f ms/launch  src %s" % (sys.argv[1].split("/")[-1], d["value"], d["unit"], r["bound"], r["frac"], r["avg_launch_ms"], r.get("pmc_source")))
+def show(tag, v):
+    r = v.get("roofline") or {}
+    print("%-46s %8.2f Mpix*iter/s  %-16s frac %-7s %s ms/launch  src %s" % (tag, v["value"], r.get("bound"), r.get("frac"), r.get("avg_launch_ms"), r.get("pmc_source")))
+show(sys.argv[1].split("/")[-1], d)
+for k, v in (d.get("workloads") or {}).items():
+    show("  " + k, v)
+print("  wall_s", d.get("wall_s"))
 PY
 done
+python tools/recompute_roofline.py "$OUT" | tail -20

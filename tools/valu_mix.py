@@ -5,7 +5,8 @@ gfx950 issues the plain binary32 multiply / add / FMA (and v_mov, v_add_u32, v_a
 transcendental instructions in ~8 and everything else in ~4 (tools/valu_issue.hip -> profiles/r02/valu_issue.csv).  A count of
 VALU instructions alone therefore says little about how busy the pipe is; this tool weights the static instruction mix of
 the three 36-sample bodies of k67w_update_strong<8, true, false, false> (LDS window, global fast reciprocal, global IEEE division)
-with the measured costs and writes profiles/r02/valu_mix_k67w.json, which bench.py uses for `roofline.valu_busy_estimate`.
+with the measured costs and writes profiles/<round>/valu_mix_k67w.json; bench.py uses the file of the SAME round directory as the
+counter profile for `roofline.valu_busy_estimate` (a mix of another round's kernel is never borrowed).
 
 usage: tools/valu_mix.py [out.json]
 """
@@ -42,7 +43,7 @@ def base(op):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02", "valu_mix_k67w.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04", "valu_mix_k67w.json")
     asm = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "apd-mvs_amd", "csrc", "apd_kernels_k67w.hip"),
                           "-o", "-"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
     m = re.search(r"^_ZN3apd18k67w_update_strongILi8ELb1ELb0ELb0EEEvNS_9FrameArgsEii:(.*?)s_endpgm", asm, re.S | re.M)
@@ -89,7 +90,15 @@ def main():
     res["window_body"] = account(win[0])
     glob.sort(key=lambda b: sum(b["ops"].values()))
     res["global_fast_body"] = account(glob[0])
-    res["global_ieee_body"] = account(glob[-1])
+    # since round 4 the IEEE-division body is two rolled loops (one sample per trip): the block that holds the division sequence
+    ieee = [b for b in blocks if any(k.startswith("v_div_fmas_f32") for k in b["ops"]) and any(k.startswith("global_load") for k in b["ops"])]
+    if ieee:
+        one = account(ieee[0])
+        one["note"] = "rolled: this block is ONE sample (36 trips per NCC); per_sample_* = the block itself"
+        one["per_sample_insts"], one["per_sample_cycles"] = float(one["valu_insts"]), one["issue_cycles"]
+        res["global_ieee_body"] = one
+    else:
+        res["global_ieee_body"] = account(glob[-1])
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
     for k in ("window_body", "global_fast_body", "global_ieee_body"):
