@@ -354,6 +354,25 @@ int apd_host_register(void *p, size_t bytes)
     return APD_OK;
 }
 
+int apd_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) {
+        return xfail(APD_ERR_INVALID, "apd_host_alloc: bad argument");
+    }
+    *out = nullptr;
+    X_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return APD_OK;
+}
+
+int apd_host_free(void *p)
+{
+    if (!p) {
+        return APD_OK;
+    }
+    X_TRY(hipHostFree(p));
+    return APD_OK;
+}
+
 int apd_host_unregister(void *p)
 {
     if (!p) {

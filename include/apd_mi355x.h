@@ -217,9 +217,14 @@ int apd_stream_create(int device, void **hip_stream);    /* a non-blocking strea
 int apd_stream_destroy(int device, void *hip_stream);
 /* (float4 plane = world normal xyz + depth w) -> the depth map and the 3-float normal map apd_fuse_views takes; device pointers. */
 int apd_split_planes_async(int device, void *hip_stream, const float *planes4, size_t pixels, float *depth, float *normal3);
-/* Page-locks / releases a host buffer (hipHostRegister): uploads from it run at the link's rate and asynchronously. */
+/* Page-locks / releases a host buffer (hipHostRegister): uploads from it run at the link's rate and asynchronously.
+ * apd_host_alloc / apd_host_free: a page-locked buffer of its own (hipHostMalloc) -- a staging buffer that is mapped ONCE: every
+ * map / unmap of host pages (hipHostRegister, and the on-the-fly pinning a plain hipMemcpy of pageable memory does) holds up the
+ * kernels running on the device for milliseconds. */
 int apd_host_register(void *p, size_t bytes);
 int apd_host_unregister(void *p);
+int apd_host_alloc(size_t bytes, void **out);
+int apd_host_free(void *p);
 
 /* All-gather across `num_ranks` ranks of this process, rank r on devices[r]: after apd_exchange_allgather every recv[r]
  * holds send[0] | send[1] | ... (bytes_per_rank each).  prefer_rccl != 0: RCCL (ncclCommInitAll, grouped ncclAllGather,

@@ -79,14 +79,14 @@ def check_k67(tag, roof, k, mix, problems, profiled_steps):
             ("peak", roof["peak"], PEAK, 1e-6),
             ("traffic", roof["traffic"], traffic, 1e-9),
             ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
-            ) + ((("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),) if mix else ()) + (
+            ) + ((("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),) if (mix and "valu_busy_estimate" in roof) else ()) + (
             ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03),)):
         ok = got == want if rel == 0 else close(got, want, rel)
         if not ok:
             problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
     if mix is None and "valu_busy_estimate" in roof:
         problems.append("%s: valu_busy_estimate without a valu_mix_k67w.json of the profile's own round" % tag)
-    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or (mix and roof["valu_busy_estimate"]["frac"] > 1):
+    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or (mix and "valu_busy_estimate" in roof and roof["valu_busy_estimate"]["frac"] > 1):
         problems.append("%s: a fraction above 1" % tag)
     return "k67 frac %.4f  hbm %.4f  busy %s  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
         achieved / PEAK, traffic / t / 1e9 / HBM, ("%.4f" % (insts * mix / (1024 * 2.4e9 * t))) if mix else "n/a", n, t * 1e3,
