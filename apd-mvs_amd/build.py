@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB_PATH = os.path.join(OUT_DIR, "libapd_mi355x.so")
 SOURCES = ["apd_kernels.hip", "apd_kernels_k67w.hip", "apd_kernels_k1415w.hip", "apd_kernels_weak.hip", "apd_fusion.hip", "apd_exchange.hip", "apd_capi.hip"]
-HEADERS = ["apd_device.h", "apd_sweep.h", "apd_window.h", "apd_fusion_math.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
+HEADERS = ["apd_device.h", "apd_sweep.h", "apd_window.h", "apd_tuning.h", "apd_lab.h", "apd_fusion_math.h", os.path.join("..", "..", "include", "apd_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

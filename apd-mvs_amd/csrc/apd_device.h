@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/apd_mi355x.h"
+#include "apd_tuning.h"
 
 namespace apd {
 
@@ -915,9 +916,6 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
     sum_rs = 0.0f;
     // software pipeline over the six rows: the gathers of the next APD_ROW_PREFETCH rows are in flight while row i
     // is reduced
-#ifndef APD_ROW_PREFETCH
-#define APD_ROW_PREFETCH 1
-#endif
     constexpr int kDepth = APD_ROW_PREFETCH, kBuf = kDepth + 1;
     float a[kBuf][kPatchN], b[kBuf][kPatchN];
     quad_t t[kQuad ? kBuf : 1][kPatchN];
@@ -974,9 +972,6 @@ __device__ __forceinline__ void ncc_fixed_moments(const FrameArgs &fa, const Vie
 // lock-step body keeps six IEEE division sequences in flight -- the register peak of every kernel that inlines it, which the
 // allocator pays for with spills around the (rare) path; this one is slower per call and is only taken when a denominator of the
 // patch leaves the range of the exact fast reciprocal.  Needs a reference patch that can be indexed at run time (LDS).
-#ifndef APD_IEEE_COMPACT
-#define APD_IEEE_COMPACT 1
-#endif
 template <bool kQuad, bool kTiled, typename Ref>
 __device__ __forceinline__ void ncc_fixed_moments_ieee_rolled(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H,
                                                               int px, int py, float &sum_s, float &sum_ss, float &sum_rs)
@@ -1059,12 +1054,10 @@ __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const Vie
     }
     bool fast_recip = denominators_fast(H, (float)(px - kPatchRadius), (float)(px + kPatchRadius), (float)(py - kPatchRadius),
                                         (float)(py + kPatchRadius));
-#ifndef APD_RECIP_DIVERGENT
     // One 36-sample body per wave and NCC.  The IEEE division gives the bits of the fast reciprocal wherever that one is
     // valid, so when a single lane of the wave needs it, every lane takes it (random normals produce such lanes: a wave
     // with one of them used to run both bodies in turn).
     fast_recip = __builtin_amdgcn_ballot_w64(!fast_recip) == 0;
-#endif
     float sum_s, sum_ss, sum_rs;
     if (__builtin_expect(fast_recip, 1)) {
         ncc_fixed_moments<kQuad, kRecipExact, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);

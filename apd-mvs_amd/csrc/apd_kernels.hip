@@ -54,9 +54,6 @@ __global__ __launch_bounds__(64) void k1_init_random_states(FrameArgs fa)
 
 // Full-frame kernels (K5, K14, K15): a wave64 covers a (64 / APD_FF_ROWS) x APD_FF_ROWS block of pixels, four waves a
 // workgroup tile (same trade-off as APD_CB_ROWS in apd_sweep.h).
-#ifndef APD_FF_ROWS
-#define APD_FF_ROWS 8
-#endif
 constexpr int kFfWaveH = APD_FF_ROWS, kFfWaveW = 64 / kFfWaveH;
 constexpr int kFfWavesX = (kFfWaveH == 8) ? 2 : 1, kFfWavesY = 4 / kFfWavesX;
 constexpr int kFullTileW = kFfWaveW * kFfWavesX, kFullTileH = kFfWaveH * kFfWavesY;  // 16x16 (rows 8, 4) or 32x8 (rows 2)
@@ -234,9 +231,6 @@ __device__ __forceinline__ bool arm_candidate(const FrameArgs &fa, int px, int p
 
 // One launch = one colour.  Hypotheses 0..7 are the propagation arms, 8 the current plane,
 // 9..13 the refinement set; a single loop keeps one inlined copy of the 36-sample NCC.
-#ifndef APD_K67_WAVES
-#define APD_K67_WAVES 4  // minimum waves per SIMD the register allocator must leave room for (ms per launch at 4096x3072 N=8 -- ref patch in registers: 2: 32.0, 3: 28.3; ref patch in LDS: 3: 28.2, 4: 27.4)
-#endif
 template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArgs fa, int colour, int iter)
 {
@@ -256,17 +250,6 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
     if (fa.weak_info[center] == APD_WEAK) {
         return;
     }
-#ifdef APD_K67_REF_IN_REGS
-    RefPatch rp;
-#pragma unroll
-    for (int i = 0; i < kPatchN; ++i) {
-#pragma unroll
-        for (int j = 0; j < kPatchN; ++j) {
-            rp.v[i * kPatchN + j] = tile[(t.ly + kPatchStep * j) * kLdsPitch + (t.lx + kPatchStep * i)];
-        }
-    }
-    ref_patch_finish(rp);
-#else
     // the 36 reference texels stay in the LDS tile (one ds_read per sample); only their moments live in registers
     RefPatchLds<kLdsPitch> rp;
     rp.base = &tile[t.ly * kLdsPitch + t.lx];
@@ -283,7 +266,6 @@ __global__ __launch_bounds__(256, APD_K67_WAVES) void k67_update_strong(FrameArg
         rp.mean = tmp.mean;
         rp.var = tmp.var;
     }
-#endif
 
     const int nsrc = fa.num_src;
     Rng rng = rng_load(fa.rng, center);

@@ -17,31 +17,10 @@ namespace apd {
 
 constexpr int kFwTile = 16;                                // workgroup tile: 16x16 pixels, wave64 = 8x8
 constexpr int kFwLds = kFwTile + 2 * kPatchRadius;         // 26
-#ifndef APD_FW_TILE_PITCH
-#define APD_FW_TILE_PITCH (kFwLds + 1)
-#endif
 constexpr int kFwPitch = APD_FW_TILE_PITCH;                // 27
-#ifndef APD_K1415_WIN_PITCH
-#define APD_K1415_WIN_PITCH 72  // entries per window row: a 32-lane group reads four rows of eight columns (apd_window.h)
-#endif
 constexpr int kFwWinPitch = APD_K1415_WIN_PITCH;
 static_assert(kFwWinPitch >= kWinW && kFwWinPitch <= 127, "window pitch: at least the wave width; two-address LDS reads need offset1 < 256 dwords");
-#ifndef APD_K14_WIN_H
-#define APD_K14_WIN_H 32  // rows of fetch positions: 8 + 2 * (patch radius 5 + 7 texels of slack)
-#endif
-#ifndef APD_K14_WIN_H_F32
-#define APD_K14_WIN_H_F32 32
-#endif
 template <bool kQuad> constexpr int k14_win_h() { return kQuad ? APD_K14_WIN_H : APD_K14_WIN_H_F32; }
-#ifndef APD_K14_COMPACT
-#define APD_K14_COMPACT 1  // K14 may walk the (sample, lane) pairs of a chunk 64 at a time instead of one sample per wave-level NCC (0: never)
-#endif
-#ifndef APD_K14_PAIRS_FROM_N
-#define APD_K14_PAIRS_FROM_N 10  // ... in launches with at least this many source views
-#endif
-#ifndef APD_K14_CHUNK
-#define APD_K14_CHUNK 8  // depth samples per staged window (K14 ms at 4096x3072, 8 views: 4: 144.7, 6: 138.8, 8: 135.6, 16: 140.6, 31: 161.1)
-#endif
 
 __device__ __forceinline__ void fw_pixel(int &px, int &py)
 {
@@ -121,16 +100,6 @@ __device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewCon
 // K14
 // ------------------------------------------------------------------------------------------------
 
-#ifndef APD_K14W_WAVES
-#define APD_K14W_WAVES 4  // ms at 4096x3072, 8 views: 4 waves/SIMD (128 VGPRs, 18 spilled) 140.6, 3 waves 150.1
-#endif
-#ifndef APD_K15W_WAVES
-#define APD_K15W_WAVES 3  // 4 waves/SIMD (100 VGPRs spilled) 30.5, 3 waves 27.1
-#endif
-#ifndef APD_K1415W_WAVES_F32
-#define APD_K1415W_WAVES_F32 3  // float windows (single-texel entries, 9.5 KB per wave like the 8-bit ones); ms at 2048x1536, 8 views, K14 / K15:
-                                // 2 waves/SIMD 41.6 / 3.77, 3 waves 34.5 / 3.18, 4 waves 36.5 / 3.87 (8-byte pair entries, 2 waves: 40.4 / 3.80)
-#endif
 // kPairs: the kernel may walk the (sample, lane) pairs of a chunk instead of its samples (see the chunk loop).  Carrying that
 // second loop costs the sample loop registers (4096x3072, 8 sources: 119.6 -> 124.0 ms; float images 34.5 -> 40.1 at 2048x1536),
 // so the launcher picks it where views are selected sparsely enough for it to pay: from ten sources on (15 draws over N views;
@@ -219,9 +188,6 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
     // chunks that cover [RADIUS - weak_peak_radius, RADIUS + weak_peak_radius] against every selected view; lanes that are
     // WEAK by that argument write their result and drop out, and phase 1 scores the remaining chunks for the others
     // (a wave of a textureless region ends after phase 0).  Every sample still adds its views in view order.
-#ifndef APD_K14_CENTRE_FIRST
-#define APD_K14_CENTRE_FIRST 1
-#endif
     const int wr = min(max(fa.weak_peak_radius, 0), RADIUS);
     const int centre_lo = ((RADIUS - wr) / APD_K14_CHUNK) * APD_K14_CHUNK;                        // first sample of the first centre chunk
     const int centre_hi = (APD_K14_CENTRE_FIRST && fa.early_out) ? ((RADIUS + wr) / APD_K14_CHUNK + 1) * APD_K14_CHUNK : 0;  // one past the last centre chunk
@@ -341,9 +307,6 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                 } else {
                     // pw[] and pc[] are indexed dynamically and live in scratch memory: the two reads of sample i + 1 are issued
                     // before sample i is scored instead of stalling its start and its end
-#ifndef APD_K14_PREFETCH
-#define APD_K14_PREFETCH 1
-#endif
                     float pw_next = pw[c0], pc_next = pc[c0];
 #pragma unroll 1
                     for (int i = c0; i < c1; ++i) {
@@ -525,9 +488,6 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
         }
     }
     float lost = __builtin_inff();
-#ifndef APD_K15_EARLY_OUT
-#define APD_K15_EARLY_OUT 1
-#endif
     if (APD_K15_EARLY_OUT && fa.early_out && alive && !(fa.geom_factor < 0.0f)) {
         // bound >= cost_now - 0.0999 in real arithmetic (|cost_now| <= 2 + 3 * geom_factor: two roundings are far below 1e-6)
         const float bound = (acc_now / weight_normal - 0.0999f) + 1e-6f;
@@ -623,6 +583,4 @@ hipError_t launch_k15_windowed(const FrameArgs &fa, hipStream_t s)
 }  // namespace apd
 
 
-#ifdef APD_LAB_WIN_STATS
 APD_WIN_STATS_ACCESSOR(apd_debug_win_stats_k1415)
-#endif

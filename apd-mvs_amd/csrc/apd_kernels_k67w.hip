@@ -22,9 +22,6 @@
 
 namespace apd {
 
-#ifndef APD_WIN_H
-#define APD_WIN_H (kWaveH + 16)   // rows of fetch positions: footprint + 2 * (patch radius 5 + 3 texels of slack)
-#endif
 constexpr int kWinH = APD_WIN_H;
 
 // Places the window around the projections of the live pixels' centres under their current planes and stages it.
@@ -53,11 +50,9 @@ __device__ __forceinline__ SrcWindow stage_window(const FrameArgs &fa, const Vie
         correspond(H, (float)px, (float)py, cx, cy);
         ok = cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf;  // false for NaN
     }
-#ifndef APD_WIN_NO_TRUST
     if (__builtin_amdgcn_ballot_w64(ok && trusted) != 0) {
         ok = ok && trusted;
     }
-#endif
     return stage_window_around<kQuad, kWinH>(fa, vc, win, ok, cx, cy);
 }
 
@@ -114,21 +109,8 @@ __device__ __forceinline__ bool arm_pos(const FrameArgs &fa, int px, int py, int
     return true;
 }
 
-#ifndef APD_WIN_TRUST
-#define APD_WIN_TRUST 0.5f
-#endif
-#ifndef APD_WIN_FROM_ITER
-#define APD_WIN_FROM_ITER 1  // first iteration of a FIRST_INIT pass that stages windows; configs[1] Mpix*iter/s: 0: 207, 1: 216
-#endif
 constexpr float kTrustedCost = APD_WIN_TRUST;
 
-#ifndef APD_K67W_WAVES
-#define APD_K67W_WAVES 4
-#endif
-#ifndef APD_K67W_WAVES_F32
-#define APD_K67W_WAVES_F32 3  // float windows: three waves per SIMD also with the single-texel entries (4 waves, 128 VGPRs: 32.4 against 29.1 ms
-                              // for the first iteration at 2048x1536, 16.0 against 14.6 later)
-#endif
 // kTiled: NCCs that miss the window (all of them while the windows are off) gather from the tiled copy of the quad image
 // kApprox: tolerance mode APD_OPT_FAST_RCP (bare v_rcp_f32 in the sample loops; not bit-identical to the oracle)
 template <int NMAX, bool kQuad, bool kTiled, bool kApprox>
@@ -475,6 +457,4 @@ hipError_t launch_k67_windowed(const FrameArgs &fa, int colour, int iter, hipStr
 }  // namespace apd
 
 
-#ifdef APD_LAB_WIN_STATS
 APD_WIN_STATS_ACCESSOR(apd_debug_win_stats)
-#endif

@@ -11,20 +11,6 @@
 
 namespace apd {
 
-#ifdef APD_LAB_WIN_STATS  // diagnostic build only (tools/weak_stats.py): lane-level against wave-level work of K9/K10
-// [0] lane NCCNew of the propagation phase, [1] wave-level ones, [2] / [3] the same for hypotheses 9..14, [4] lane sub-patches, [5] wave sub-patches
-static __device__ unsigned long long g_weak_stats[8];
-#define APD_WEAK_COUNT(i, n) atomicAdd(&g_weak_stats[i], (unsigned long long)(n))
-#define APD_WEAK_COUNT_WAVE(i)                                                                     \
-    do {                                                                                           \
-        if ((int)(threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {       \
-            APD_WEAK_COUNT(i, 1);                                                                  \
-        }                                                                                          \
-    } while (0)
-#else
-#define APD_WEAK_COUNT(i, n) ((void)0)
-#define APD_WEAK_COUNT_WAVE(i) ((void)0)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // K2  FindNearestStrongPoint (APD.cu:2234-2270)
@@ -608,12 +594,6 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
     }
 }
 
-#ifndef APD_K910_WINDOW
-#define APD_K910_WINDOW 1  // 0: no centre-patch window (A/B runs)
-#endif
-#ifndef APD_K910_WIN_DIVERGENT
-#define APD_K910_WIN_DIVERGENT 1  // 0: a wave with lanes outside the window takes the global path whole (A/B runs)
-#endif
 // w: this wave's window of view v for the centre patch (texel-quad mode; valid = 0: none staged)
 template <bool kQuad, typename Ref>
 __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLdsT<kQuad> &lds,
@@ -699,9 +679,6 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
 // image neighbours in both directions, and an XCD that walks one contiguous eighth of the list (weak_chunk_of_block)
 // keeps a compact 2-D region of every source image in its private L2 instead of a full-width strip shared with the
 // seven other XCDs.  WEAK pixels only change in K4 and K14, so the two lists are built once per pass (apd_capi.hip).
-#ifndef APD_WEAK_SUPER_SHIFT
-#define APD_WEAK_SUPER_SHIFT 4
-#endif
 constexpr int kSuperShift = APD_WEAK_SUPER_SHIFT, kSuperTiles = 1 << kSuperShift;  // supertile edge in tiles
 constexpr int kListTileW = 16, kListTileH = 8;                  // 64 pixels of one colour
 constexpr int kCountTilesPerBlock = 64;
@@ -794,11 +771,7 @@ __global__ __launch_bounds__(256) void k_weak_tile_scatter(FrameArgs fa, TileOrd
 // Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md): XCD x walks list chunks [x * per_xcd, (x + 1) * per_xcd).
 __device__ __forceinline__ int weak_chunk_of_block(int b, int per_xcd)
 {
-#ifdef APD_LAB_K910_INTERLEAVED  // A/B: consecutive chunks on consecutive XCDs (every L2 sees the whole live region)
-    return b;
-#else
     return (b & 7) * per_xcd + (b >> 3);
-#endif
 }
 
 // Plane of reliable neighbour h of a WEAK pixel (slot h + 1 of its neighbour table): re-read where it is needed -- the planes
@@ -813,9 +786,6 @@ __device__ __forceinline__ float4 candidate_plane(const FrameArgs &fa, const sho
 // five rows either side, the rest is slack for hypotheses that move the patch along a slanted epipolar line.  With the packed
 // sub-patch moments the workgroup's LDS stays below 20 KB, i.e. eight workgroups per CU: the kernel loses 17 % with seven
 // (profiles/r03/ab_k910_occupancy.txt).
-#ifndef APD_K910_WIN_H
-#define APD_K910_WIN_H 28
-#endif
 constexpr int kK910WinH = APD_K910_WIN_H;
 
 // Window of view vc around where the wave's pixels land under their current planes.  Every lane of the wave calls this.
@@ -842,12 +812,6 @@ __device__ __forceinline__ SrcWindow no_window()
 
 // Hypotheses: 0..7 the eight reliable neighbours' planes, 8 the current plane, 9 the RANSAC fit
 // plane, 10..14 the refinement set, 15 the final fixed-patch re-score.
-#ifndef APD_K910_WAVES
-#define APD_K910_WAVES 2
-#endif
-#ifndef APD_K910_COMPACT_REFINE
-#define APD_K910_COMPACT_REFINE 1
-#endif
 template <int NMAX, bool kQuad>
 __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs fa, int iter, const int *__restrict__ list, int count, int per_xcd)
 {
@@ -856,12 +820,6 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
     constexpr bool kCompact = kQuad && APD_K910_COMPACT_REFINE != 0;
     __shared__ uint16_t refine_items[kCompact ? 5 * 64 : 1];
     __shared__ float refine_cost[kCompact ? 5 : 1][64];
-#ifdef APD_LAB_K910_LDS_PAD  // A/B runs: extra LDS bytes per workgroup, i.e. fewer workgroups per CU
-    __shared__ uint32_t lab_pad[APD_LAB_K910_LDS_PAD / 4];
-    if (count < 0) {
-        lab_pad[threadIdx.x] = 0;  // never taken: keeps the array
-    }
-#endif
     // the wave's window of the current source view for the centre patches (texel-quad mode)
     __shared__ uint32_t centre_window[kQuad ? window_dwords(true, kK910WinH) : 1];
     const int lane = threadIdx.x;
@@ -1106,39 +1064,20 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
                         __builtin_amdgcn_wave_barrier();
                         const ViewConst &vc = view_const(fa, v);
                         const SrcWindow w = APD_K910_WINDOW != 0 ? weak_stage_window(fa, vc, centre_window, px, py, plane_now) : no_window();
-#ifdef APD_LAB_K910_IDENTITY  // diagnostic: every lane scores its own pairs, one hypothesis per slot (no cross-lane motion)
-                        const int slot_step = 1, slot_end = 5;
-#else
                         const int slot_step = nworkers, slot_end = total;
-#endif
 #pragma unroll 1
                         for (int first = 0; first < slot_end; first += slot_step) {
-#ifdef APD_LAB_K910_IDENTITY
-                            const bool valid = ((open >> first) & 1u) != 0;
-                            const unsigned item = (unsigned)((first << 6) | lane);
-                            const int owner = (int)(item & 63u), hyp = (int)(item >> 6);
-                            const int last = first;
-                            if (__builtin_amdgcn_ballot_w64(valid) == 0) {
-                                continue;
-                            }
-#else
                             const int idx = first + wid;
                             const bool valid = idx < total;
                             const unsigned item = valid ? (unsigned)refine_items[idx] : (unsigned)lane;
                             const int owner = (int)(item & 63u), hyp = (int)(item >> 6);
                             const int last = min(total, first + nworkers) - 1;
-#endif
                             int k_lo = 0, k_hi = 0;
-#ifdef APD_LAB_K910_IDENTITY
-                            k_lo = k_hi = first;
-                            (void)last;
-#else
 #pragma unroll
                             for (int k = 1; k < 5; ++k) {
                                 k_lo += off[k] <= first ? 1 : 0;
                                 k_hi += off[k] <= last ? 1 : 0;
                             }
-#endif
                             float4 hp = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
 #pragma unroll 1
                             for (int k = k_lo; k <= k_hi; ++k) {
@@ -1488,16 +1427,4 @@ hipError_t launch_weak_kernel(const FrameArgs &fa, int kernel_id, int iter, hipS
 }  // namespace apd
 
 
-#ifdef APD_LAB_WIN_STATS
-extern "C" int apd_debug_weak_stats(unsigned long long *out, int reset)
-{
-    hipDeviceSynchronize();
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(apd::g_weak_stats), sizeof(apd::g_weak_stats));
-    if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(apd::g_weak_stats), z, sizeof(z));
-    }
-    return (int)e;
-}
-APD_WIN_STATS_ACCESSOR(apd_debug_win_stats_weak)
-#endif
+APD_LAB_WEAK_STATS_ACCESSOR

@@ -28,9 +28,6 @@ __device__ __forceinline__ void sort_ascending(float *d, int n)  // APD.cu:3-12
 // workgroup tile.  The footprint shape trades two things: a wide, flat footprint makes one wave-level gather touch
 // fewer 128-B lines of the row-major source image (the L1 looks lines up one per cycle), a square one keeps the
 // patch halo, i.e. the L1 working set, small.
-#ifndef APD_CB_ROWS
-#define APD_CB_ROWS 4
-#endif
 constexpr int kWaveH = APD_CB_ROWS, kWaveLanesX = 64 / kWaveH, kWaveW = 2 * kWaveLanesX;
 constexpr int kWavesX = (kWaveH == 8) ? 2 : 1, kWavesY = 4 / kWavesX;
 constexpr int kTileW = kWaveW * kWavesX, kTileH = kWaveH * kWavesY, kHalo = kPatchRadius;  // 32x16 (rows 8, 4) or 64x8 (rows 2)
@@ -207,9 +204,6 @@ __device__ __forceinline__ void select_views(const FrameArgs &fa, int iter, cons
 // whatever the remaining views cost.  Returns such a t: fl(cost * weight_norm) is within 2^-24 (relative) of the
 // product, two roundings and the factor 1 + 2^-22 put the result strictly above it.  Tiny, zero-weight and non-finite
 // inputs return +inf or NaN (never "lost": the loops then score every view, as the reference does).
-#ifndef APD_REFINE_EARLY_OUT
-#define APD_REFINE_EARLY_OUT 1
-#endif
 __device__ __forceinline__ float refinement_lost_bound(const FrameArgs &fa, float cost, float weight_norm)
 {
     const float p = cost * weight_norm;

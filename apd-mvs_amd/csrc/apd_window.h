@@ -3,6 +3,7 @@
 #pragma once
 
 #include "apd_device.h"
+#include "apd_lab.h"
 
 
 namespace apd {
@@ -23,9 +24,6 @@ constexpr int kWinW = 64;
 // the same rounded subtraction the {texel, difference} pairs of the float texel-quad image store, two more plain FP32
 // instructions per sample, half the LDS (K6/K7 47 -> 26 KB, K14/K15 79 -> 41 KB per workgroup: the occupancy of the 8-bit
 // kernels).  -DAPD_WIN_F32_PAIRS=1 rebuilds the 8-byte {texel, difference} entries of rounds 1-2.
-#ifndef APD_WIN_F32_PAIRS
-#define APD_WIN_F32_PAIRS 0
-#endif
 constexpr bool kWinF32Pairs = APD_WIN_F32_PAIRS != 0;
 // LDS dwords of a window with WINH rows of fetch positions (+ the row below the last one)
 constexpr int window_dwords(bool quad, int winh, int pitch = kWinW) { return pitch * (winh + 1) * ((quad || !kWinF32Pairs) ? 1 : 2); }
@@ -92,24 +90,6 @@ __device__ __forceinline__ WinTaps<pair_t> lds_read_texels(int addr)
     return t;
 }
 
-#ifdef APD_LAB_WIN_STATS  // diagnostic build only: [0] NCCs through the window, [1] global fast, [2] global slow,
-                                 // [3] wave-level NCC calls, [4] of those with both window and global lanes, [5] windows staged
-static __device__ unsigned long long g_k67w_stats[8];  // one copy per translation unit (no relocatable device code)
-#define APD_WIN_COUNT(i, n) atomicAdd(&g_k67w_stats[i], (unsigned long long)(n))
-#define APD_WIN_STATS_ACCESSOR(name)                                                                   \
-    extern "C" int name(unsigned long long *out, int reset)                                            \
-    {                                                                                                  \
-        hipDeviceSynchronize();                                                                        \
-        hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(apd::g_k67w_stats), sizeof(apd::g_k67w_stats)); \
-        if (e == hipSuccess && reset) {                                                                \
-            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                        \
-            e = hipMemcpyToSymbol(HIP_SYMBOL(apd::g_k67w_stats), z, sizeof(z));                        \
-        }                                                                                              \
-        return (int)e;                                                                                 \
-    }
-#else
-#define APD_WIN_COUNT(i, n) ((void)0)
-#endif
 
 struct SrcWindow {
     int valid;        // wave-uniform: a window is staged
@@ -321,9 +301,6 @@ __device__ __forceinline__ void win_row_issue(const Homography &H, float bx, flo
     // the low 23 bits of the binary32 encoding are the integer itself -- one v_and_b32 (2 cycles) instead of v_cvt_i32_f32
     // (4).  addr0 is above -2^23 - 2^20 for every image apd_create accepts (height <= 16384, window rows of at most 576
     // bytes), so every step stays an integer of magnitude below 2^24.  (ds_read does not ignore the high address bits: tools/lds_addr_bits.hip.)
-#ifndef APD_WIN_ADDR_MAGIC
-#define APD_WIN_ADDR_MAGIC 1
-#endif
     constexpr float kEntryBytes = (float)(1 << WinEntry<kQuad>::kShift), kPitchBytes = (float)(kPitch << WinEntry<kQuad>::kShift);
     const float addr0f = (float)addr0 + (APD_WIN_ADDR_MAGIC ? 8388608.0f : 0.0f);
     float fx[kPatchN], fy[kPatchN];
@@ -399,9 +376,6 @@ __device__ __forceinline__ void win_row_lerp(const WinTaps<typename WinEntry<kQu
 // ncc_fixed_moments (fast reciprocal) reading the window.
 // cX / cY: positions of the four corner samples {(x0,y0), (x0,y1), (x1,y0), (x1,y1)} from the caller's window test; rows 0 and
 // kPatchN - 1 take their end samples from there instead of computing them a second time (APD_WIN_CORNER_REUSE=0: recompute).
-#ifndef APD_WIN_CORNER_REUSE
-#define APD_WIN_CORNER_REUSE 1
-#endif
 template <bool kQuad, int kPitch, bool kApprox, typename Ref>
 __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homography &H, int px, int py, int addr0, float &sum_s,
                                                    float &sum_ss, float &sum_rs, const float (&cX)[4], const float (&cY)[4])
@@ -415,9 +389,6 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
     sum_s = 0.0f;
     sum_ss = 0.0f;
     sum_rs = 0.0f;
-#ifndef APD_WIN_SETPRIO
-#define APD_WIN_SETPRIO 1  // issue priority for the wave inside its 36-sample burst: +0.7 % on configs[1] (0 = off)
-#endif
 #if APD_WIN_SETPRIO > 0
     __builtin_amdgcn_s_setprio(APD_WIN_SETPRIO);
 #endif
@@ -509,26 +480,11 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
         const float yl = fminf(fminf(cY[0], cY[1]), fminf(cY[2], cY[3])), yh = fmaxf(fmaxf(cY[0], cY[1]), fmaxf(cY[2], cY[3]));
         in_window = xl >= w.lo_x && xh < w.hi_x && yl >= w.lo_y && yh < w.hi_y;
     }
-#ifdef APD_LAB_WIN_STATS
-    {
-        const unsigned long long m_all = __builtin_amdgcn_ballot_w64(true), m_in = __builtin_amdgcn_ballot_w64(in_window);
-        if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_all)) {
-            APD_WIN_COUNT(3, 1);
-            APD_WIN_COUNT(4, (m_in != 0 && m_in != m_all) ? 1 : 0);
-        }
-        APD_WIN_COUNT(in_window ? 0 : (fast_recip ? 1 : 2), 1);
-    }
-#endif
-#ifndef APD_WIN_DIVERGENT
+    APD_LAB_NCC_STATS(in_window, fast_recip);
     // one path per wave and NCC: lanes inside and outside the window would otherwise run both 36-sample bodies in turn
     in_window = in_window && __builtin_amdgcn_ballot_w64(!in_window) == 0;
-#endif
-#ifndef APD_RECIP_DIVERGENT
     // the same for the two global bodies: if one lane needs the IEEE division, every lane of the wave takes it (same bits)
     const bool fast_body = __builtin_amdgcn_ballot_w64(!fast_recip) == 0;
-#else
-    const bool fast_body = fast_recip;
-#endif
     float sum_s, sum_ss, sum_rs;
     if (in_window) {
         ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs, cX, cY);
@@ -584,28 +540,13 @@ __device__ __forceinline__ float ncc_fixed_windowed_from_h(const FrameArgs &fa, 
         const float yl = fminf(fminf(cY[0], cY[1]), fminf(cY[2], cY[3])), yh = fmaxf(fmaxf(cY[0], cY[1]), fmaxf(cY[2], cY[3]));
         in_window = xl >= w.lo_x && xh < w.hi_x && yl >= w.lo_y && yh < w.hi_y;
     }
-#ifdef APD_LAB_WIN_STATS
-    {
-        const unsigned long long m_all = __builtin_amdgcn_ballot_w64(true), m_in = __builtin_amdgcn_ballot_w64(in_window);
-        if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_all)) {
-            APD_WIN_COUNT(3, 1);
-            APD_WIN_COUNT(4, (m_in != 0 && m_in != m_all) ? 1 : 0);
-        }
-        APD_WIN_COUNT(in_window ? 0 : (fast_recip ? 1 : 2), 1);
-    }
-#endif
-#ifndef APD_WIN_DIVERGENT
+    APD_LAB_NCC_STATS(in_window, fast_recip);
     if constexpr (!kDivergent) {
         // one path per wave and NCC: lanes inside and outside the window would otherwise run both 36-sample bodies in turn
         in_window = in_window && __builtin_amdgcn_ballot_w64(!in_window) == 0;
     }
-#endif
-#ifndef APD_RECIP_DIVERGENT
     // the same for the two global bodies: if one lane needs the IEEE division, every lane of the wave takes it (same bits)
     const bool fast_body = __builtin_amdgcn_ballot_w64(!fast_recip) == 0;
-#else
-    const bool fast_body = fast_recip;
-#endif
     float sum_s, sum_ss, sum_rs;
     if (in_window) {
         ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs, cX, cY);

@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "APD.h"
+#include "schedule.h"
 #include "../csrc/apd_fusion_math.h"
 
 bool DecodeJpegGray(const uint8_t *data, size_t size, std::vector<uint8_t> &gray, int &width, int &height);
@@ -100,6 +101,32 @@ void apdhost_fusion_math(const float *in, int n, int which, float *out)
     for (int i = 0; i < n; ++i) {
         out[i] = which == 0 ? apd_fusion::acos_c9(in[i]) : apd_fusion::exp_c9(in[i]);
     }
+}
+
+// The pass table of the reference driver (main.cpp:72-88, :168-215) as host/schedule.h builds it for both C++ schedulers: the one
+// implementation; apd-mvs_amd/pipeline.py reads it from here.  Row k of `rows` (9 ints) = level, iteration, scale_size, state,
+// geom_consistency, use_APD, weak_peak_radius, rotate_time, and ransac_threshold as the bit pattern of the float.
+int apdhost_round_num(int width, int height) { return RoundNum(width, height); }
+
+int apdhost_schedule(int round_num, int single_level, int *rows, int cap_rows)
+{
+    const std::vector<Pass> plan = BuildSchedule(round_num, single_level != 0);
+    if (rows) {
+        for (size_t k = 0; k < plan.size() && (int)k < cap_rows; ++k) {
+            const Pass &p = plan[k];
+            int *r = rows + 9 * k;
+            r[0] = p.level;
+            r[1] = p.iteration;
+            r[2] = p.scale_size;
+            r[3] = (int)p.state;
+            r[4] = p.geom_consistency ? 1 : 0;
+            r[5] = p.use_APD ? 1 : 0;
+            r[6] = p.weak_peak_radius;
+            r[7] = p.rotate_time;
+            memcpy(&r[8], &p.ransac_threshold, sizeof(float));
+        }
+    }
+    return (int)plan.size();
 }
 
 // HIP device of the fusion started by apdhost_fuse / RunFusion (default 0)

@@ -18,6 +18,7 @@ processed and the previous pass's maps of everybody else's.
 
 The compute backend is injected: `HipBackend` (the product) drives the C ABI; the CPU tests plug the oracle in.
 """
+import ctypes as C
 import math
 from dataclasses import dataclass, field
 
@@ -60,32 +61,25 @@ class ViewState:
 
 
 def compute_round_num(width, height):
-    """main.cpp:72-88: halve until max(W, H) <= 1000."""
-    max_size = max(width, height)
-    round_num = 1
-    while max_size > 1000:
-        max_size //= 2
-        round_num += 1
-    return round_num
+    """main.cpp:72-88: halve until max(W, H) <= 1000 (host/schedule.h: RoundNum)."""
+    return int(host_lib().apdhost_round_num(int(width), int(height)))
 
 
 def pass_schedule(round_num, iters=3, single_level=False):
-    """Per-pass parameters of main.cpp:168-215."""
+    """Per-pass parameters of main.cpp:168-215.  ONE implementation: the table host/schedule.h builds for the C++ schedulers
+    (BuildSchedule), read through libapd_host.so; level 0 leaves ransac_threshold / rotate_time at the struct defaults, as the
+    reference's long-lived PatchMatchParams does (schedule.h: Configure)."""
+    L = host_lib()
+    n = L.apdhost_schedule(int(round_num), 1 if single_level else 0, None, 0)
+    rows = (C.c_int * (9 * n))()
+    L.apdhost_schedule(int(round_num), 1 if single_level else 0, rows, n)
     out = []
-    it = 0
-    for i in range(round_num):
-        scale = 1 if single_level else int(2 ** (round_num - 1 - i))
-        apd = dict(use_APD=0) if i == 0 else dict(use_APD=1, ransac_threshold=float(np.float32(0.01 - i * 0.00125)),
-                                                  rotate_time=min(int(2 ** i), 4))
-        p = dict(state=0 if i == 0 else 1, geom_consistency=0, max_iterations=iters, weak_peak_radius=6)
-        p.update(apd)
-        out.append(PassSpec(i, it, scale, p))
-        it += 1
-        for j in range(3):
-            p = dict(state=2, geom_consistency=1, max_iterations=iters, weak_peak_radius=max(4 - 2 * j, 2))
-            p.update(apd)
-            out.append(PassSpec(i, it, scale, p))
-            it += 1
+    for k in range(n):
+        level, iteration, scale, state, geom, use_apd, peak, rotate, thr_bits = rows[9 * k:9 * k + 9]
+        p = dict(state=state, geom_consistency=geom, max_iterations=iters, weak_peak_radius=peak, use_APD=use_apd)
+        if use_apd:
+            p.update(ransac_threshold=float(np.array([thr_bits], np.int32).view(np.float32)[0]), rotate_time=rotate)
+        out.append(PassSpec(level, iteration, scale, p))
     return out
 
 
@@ -346,6 +340,8 @@ def host_lib():
         L.apdhost_read_gray_image.argtypes = [C.c_char_p, ip, ip, fp, C.c_size_t]
         L.apdhost_write_bin_mat.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.apdhost_fuse.restype = C.c_longlong
+        L.apdhost_round_num.argtypes = [C.c_int, C.c_int]
+        L.apdhost_schedule.argtypes = [C.c_int, C.c_int, ip, C.c_int]
         _host = L
     return _host
 
