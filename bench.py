@@ -500,6 +500,23 @@ SUB_WORKLOADS = [
 ]
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator is built ("RCCL version : ...", "Librccl path : ...").
+    This program's stdout is ONE JSON line: file descriptor 1 points at stderr while the process group is set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def init_distributed(args, torch, local_rank):
     """RCCL process group with a bounded set-up: a communicator that cannot be built must end the run with a diagnosis, not hang
     the node (the driver's 8-GPU run would otherwise sit until its own limit)."""
@@ -508,13 +525,16 @@ def init_distributed(args, torch, local_rank):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local_rank)
     try:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(seconds=int(os.environ.get("APD_BENCH_PG_TIMEOUT_S", "300"))))
-        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl", (dist.get_world_size(), dist.get_backend())
-        probe = torch.ones(1, device=torch.device("cuda", local_rank))
-        dist.all_reduce(probe)   # builds the communicator now: a failure shows up here, before any timed region
-        torch.cuda.synchronize()
-        assert int(probe.item()) == args.gpus
+        with stdout_to_stderr():
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=int(os.environ.get("APD_BENCH_PG_TIMEOUT_S", "300"))))
+            assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl", (dist.get_world_size(), dist.get_backend())
+            probe = torch.ones(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(probe)   # builds the communicator now: a failure shows up here, before any timed region
+            objs = [None] * args.gpus
+            dist.all_gather_object(objs, int(os.environ.get("RANK", "0")))   # ... and the object path sharding.allgather_maps uses
+            torch.cuda.synchronize()
+        assert int(probe.item()) == args.gpus and objs == list(range(args.gpus))
     except Exception as e:  # noqa: BLE001 -- whatever RCCL raises
         sys.stderr.write("bench.py: RCCL process group set-up failed on rank %s: %r\n"
                          "bench.py: re-run with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,ENV for RCCL's own log (NCCL_DEBUG=%s in this run)\n"

@@ -31,22 +31,52 @@ def run_case(case):
               dict(state=1, use_APD=1, weak_peak_radius=6, rotate_time=2, ransac_threshold=0.01 - 0.00125),
               dict(state=2, use_APD=1, weak_peak_radius=4, rotate_time=4, ransac_threshold=0.01 - 0.0025, geom_consistency=1)]
     prior = None
-    label = "case %d: %dx%d N=%d textureless=%.2f iters=%d %s" % (case, W, H, N, tl, iters, "float" if float_images else "8-bit")
-    for pi, extra in enumerate(passes):
-        p = common.base_params(sc, N, seed=100 + case, max_iterations=iters, **extra)
-        geom = bool(p.get("geom_consistency"))
-        h = common.make_handle(pkg, sc, imgs, N, p, depths=deps if geom else None, prior=prior)
-        o = common.make_oracle(ob, sc, imgs, N, p, depths=deps if geom else None, prior=prior)
-        try:
-            assert h.weak_count == o.weak_count, label
-            h.run()
-            o.run()
-            common.assert_state_equal(pkg, h, o, "%s pass %d" % (label, pi))
-            planes, weak, views = h.download()
-            prior = common.postprocess(planes, weak, views, p["depth_min"], p["depth_max"])
-        finally:
+    # how the HIP side is driven (the oracle always runs the plain schedule): one handle per pass (the reference's object per
+    # view and pass), or ONE handle recycled with apd_reset for all three passes; the whole pass in one call, or split around the
+    # depth maps (apd_upload_views_split / apd_run_before_depths / apd_upload_depths / apd_run_after_depths) as the scheduler
+    # with several views in flight drives it
+    recycle = bool(rng.rand() < 0.5)
+    split = bool(rng.rand() < 0.5)
+    label = "case %d: %dx%d N=%d textureless=%.2f iters=%d %s%s%s" % (case, W, H, N, tl, iters, "float" if float_images else "8-bit",
+                                                                    " recycled" if recycle else "", " split" if split else "")
+    cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+    h = None
+    try:
+        for pi, extra in enumerate(passes):
+            p = common.base_params(sc, N, seed=100 + case, max_iterations=iters, **extra)
+            geom = bool(p.get("geom_consistency"))
+            if h is None:
+                h = pkg.Handle(W, H, pkg.default_params(**p), device=0)
+            else:
+                h.reset(pkg.default_params(**p))
+            if split:
+                h.upload_views_split(cams, imgs)
+            else:
+                h.upload_views(cams, imgs, deps if geom else None)
+            if prior is not None:
+                h.upload_prior(*prior)
+            o = common.make_oracle(ob, sc, imgs, N, p, depths=deps if geom else None, prior=prior)
+            try:
+                assert h.weak_count == o.weak_count, label
+                if split:
+                    h.run_before_depths()
+                    if geom:
+                        h.upload_depths(deps)
+                    h.run_after_depths()
+                else:
+                    h.run()
+                o.run()
+                common.assert_state_equal(pkg, h, o, "%s pass %d" % (label, pi))
+                planes, weak, views = h.download()
+                prior = common.postprocess(planes, weak, views, p["depth_min"], p["depth_max"])
+            finally:
+                o.close()
+            if not recycle:
+                h.close()
+                h = None
+    finally:
+        if h is not None:
             h.close()
-            o.close()
     return label
 
 
