@@ -261,7 +261,8 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     runs = {}
     for name, dev, extra in (("one", "0", ["--jacobi", "--rccl", "--ranks", "1"]), ("one_default", "0", ["--jacobi"]),
                              ("one_copy", "0", ["--jacobi", "--no-rccl", "--ranks", "1"]), ("three_rccl", "0,0,0", ["--rccl"]),
-                             ("three", "0,0,0", []), ("two", "0,0", []), ("files", "0", ["--files"]), ("in_memory", "0", [])):
+                             ("three", "0,0,0", []), ("two", "0,0", []), ("two_by_two", "0,0", ["--ranks", "2"]),
+                             ("files", "0", ["--files"]), ("in_memory", "0", [])):
         d = tmp_path / name
         shutil.copytree(base, d)
         r = subprocess.run([APD_BIN, str(d), dev, "--seed", str(seed), "--iters", "1", "--keep-maps"] + extra, stdout=subprocess.PIPE,
@@ -285,7 +286,8 @@ def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path
     assert "Exchange of depth maps between passes: peer-copy" in runs["three"][1]   # one device named three times: RCCL needs distinct devices
     assert "Round nums: 2" in runs["one"][1] and "rank 2 (device 0)" in runs["three"][1]
     ref = runs["one"][0]
-    for name in ("one_default", "one_copy", "three", "two", "three_rccl"):
+    assert "processed on 2 rank(s), up to 2 view(s) in flight" in runs["two_by_two"][1]   # ranks x lanes: two views in flight on each of two ranks
+    for name in ("one_default", "one_copy", "three", "two", "two_by_two", "three_rccl"):
         d = runs[name][0]
         for idx in range(nviews):
             for f in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
