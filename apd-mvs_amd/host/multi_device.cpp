@@ -27,6 +27,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -149,13 +150,13 @@ struct StageClock {
     }
 };
 
-// Views in flight per device by frame size (measured on 12 views of 1920 x 1080, profiles/r03/e2e_timing.txt: three lanes 12 % less
-// wall time, 2 % at 6200 x 4130).
+// Views in flight per device by level size (profiles/r04/ab_lanes_tt24.txt, 24 views of 1920 x 1080, passes in s: one 9.08, two 8.15,
+// three 8.29, four 7.92, six 8.00, eight 8.08 in the reference's order; 2 % at 6200 x 4130).
 }  // namespace
 
 int DefaultLanes(size_t pixels)
 {
-    return pixels <= ((size_t)1 << 20) ? 6 : (pixels <= ((size_t)4 << 20) ? 3 : (pixels <= ((size_t)12 << 20) ? 2 : 1));
+    return pixels <= ((size_t)1 << 20) ? 6 : (pixels <= ((size_t)4 << 20) ? 4 : (pixels <= ((size_t)12 << 20) ? 2 : 1));
 }
 
 // Device bytes an in-memory run keeps resident on its busiest device (rank 0 also fuses): level images, the two sets of
@@ -328,169 +329,270 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         std::mutex done_m;
         std::condition_variable done_cv;
         const auto t_all = std::chrono::steady_clock::now();
-        for (const Pass &pass : BuildSchedule(round_num, opt.single_level)) {
-            // ---- level inputs (APD.cpp:464-488), once per level: resampled on the host (one thread per image), uploaded by one
-            // thread per rank from page-locked memory, only the images a rank's views reference ----
-            if (pass.scale_size != level_scale) {
-                StageClock up;
-                level_scale = pass.scale_size;
-                const float factor = 1.0f / (float)level_scale;
-                LW = level_scale == 1 ? W0 : (int)std::round(W0 * factor);
-                LH = level_scale == 1 ? H0 : (int)std::round(H0 * factor);
-                const float sx = LW / static_cast<float>(W0), sy = LH / static_cast<float>(H0);
-                std::vector<Mat> level(N);
-                const size_t level_bytes = (size_t)LW * LH * sizeof(float);
-                std::vector<char> pinned(N, 0);
-                ParallelFor((size_t)N, [&](size_t i) {
-                    if (level_scale == 1) {
-                        level[i] = full[i];
-                    } else {
-                        ResizeLinear(full[i], level[i], LW, LH);
-                    }
-                    cams[i] = cams0[i];
-                    if (level_scale != 1) {
-                        cams[i].K[0] *= sx;
-                        cams[i].K[2] *= sx;
-                        cams[i].K[4] *= sy;
-                        cams[i].K[5] *= sy;
-                    }
-                    cams[i].width = LW;
-                    cams[i].height = LH;
-                    if (G > 1) {  // several devices read the same host buffer: page-lock it once (a single upload gains nothing)
-                        pinned[i] = apd_host_register(level[i].data(), level_bytes) == APD_OK ? 1 : 0;
+        // ---- level inputs (APD.cpp:464-488), once per level: resampled on the host (one thread per image), uploaded by one thread per
+        // rank, only the images a rank's views reference ----
+        auto prepare_level = [&](const Pass &pass) {
+            StageClock up;
+            level_scale = pass.scale_size;
+            const float factor = 1.0f / (float)level_scale;
+            LW = level_scale == 1 ? W0 : (int)std::round(W0 * factor);
+            LH = level_scale == 1 ? H0 : (int)std::round(H0 * factor);
+            const float sx = LW / static_cast<float>(W0), sy = LH / static_cast<float>(H0);
+            std::vector<Mat> level(N);
+            const size_t level_bytes = (size_t)LW * LH * sizeof(float);
+            std::vector<char> pinned(N, 0);
+            ParallelFor((size_t)N, [&](size_t i) {
+                if (level_scale == 1) {
+                    level[i] = full[i];
+                } else {
+                    ResizeLinear(full[i], level[i], LW, LH);
+                }
+                cams[i] = cams0[i];
+                if (level_scale != 1) {
+                    cams[i].K[0] *= sx;
+                    cams[i].K[2] *= sx;
+                    cams[i].K[4] *= sy;
+                    cams[i].K[5] *= sy;
+                }
+                cams[i].width = LW;
+                cams[i].height = LH;
+                if (G > 1) {  // several devices read the same host buffer: page-lock it once (a single upload gains nothing)
+                    pinned[i] = apd_host_register(level[i].data(), level_bytes) == APD_OK ? 1 : 0;
+                }
+            });
+            std::vector<std::thread> uploaders;
+            for (int r = 0; r < G; ++r) {
+                uploaders.emplace_back([&, r]() {
+                    try {
+                        Rank &k = ranks[r];
+                        for (int i = 0; i < N; ++i) {
+                            if (k.needs[i]) {
+                                Check(apd_device_memcpy(k.device, k.images[i].p, level[i].ptr<float>(), level_bytes), "image upload");
+                            }
+                        }
+                    } catch (const std::exception &e) {
+                        failure.set(e.what());
                     }
                 });
-                std::vector<std::thread> uploaders;
-                for (int r = 0; r < G; ++r) {
-                    uploaders.emplace_back([&, r]() {
-                        try {
-                            Rank &k = ranks[r];
-                            for (int i = 0; i < N; ++i) {
-                                if (k.needs[i]) {
-                                    Check(apd_device_memcpy(k.device, k.images[i].p, level[i].ptr<float>(), level_bytes), "image upload");
-                                }
-                            }
-                        } catch (const std::exception &e) {
-                            failure.set(e.what());
-                        }
-                    });
+            }
+            for (std::thread &t : uploaders) {
+                t.join();
+            }
+            for (int i = 0; i < N; ++i) {
+                if (pinned[i]) {
+                    apd_host_unregister(level[i].data());
                 }
-                for (std::thread &t : uploaders) {
-                    t.join();
+            }
+            if (failure.failed) {
+                throw std::runtime_error(failure.what);
+            }
+            printf("Image size: %d * %d, %d view(s) in flight per rank\n", LW, LH, lanes_at((size_t)LW * LH));
+            ms_upload += up.lap();
+        };
+
+        // ---- one (view, pass) on a lane.  depth_of(a, j): where view j's depth map for this view's slot a lies (it may block until the
+        // map is published; nullptr: the run has failed); depth_out: where this view's new depth map goes; before_export(): may block
+        // until nobody reads what the export overwrites any more ----
+        auto wait_done = [&](int view, int at_least) {  // false: the run has failed
+            std::unique_lock<std::mutex> lock(done_m);
+            done_cv.wait(lock, [&]() { return done_pass[view] >= at_least || failure.failed.load(); });
+            return !failure.failed.load();
+        };
+        auto run_view = [&](int r, Lane &lane, const Pass &pass, int v, const std::function<const float *(size_t, int)> &depth_of, float *depth_out,
+                            const std::function<bool()> &before_export) {
+            Rank &k = ranks[r];
+            Problem &problem = problems[v];  // one lane per (view, pass), and a view's passes follow one another: nobody else touches it
+            Configure(problem, pass, opt);
+            PatchMatchParams q = problem.params;
+            q.depth_min = cams0[v].depth_min * 0.6f;   // APD.cpp:454-455
+            q.depth_max = cams0[v].depth_max * 1.2f;
+            std::vector<int> order{v};
+            for (int s : problem.src_image_ids) {
+                order.push_back(index_of_id.at(s));
+            }
+            q.num_images = (int)order.size();
+            const apd_params p = ToAbi(q);
+            if (!lane.handle || lane.handle_w != LW || lane.handle_h != LH) {
+                if (lane.handle) {
+                    apd_destroy(lane.handle);
+                    lane.handle = nullptr;
                 }
-                for (int i = 0; i < N; ++i) {
-                    if (pinned[i]) {
-                        apd_host_unregister(level[i].data());
+                Check(apd_create(&lane.handle, k.device, LW, LH, &p), "apd_create");
+                lane.handle_w = LW;
+                lane.handle_h = LH;
+            } else {
+                Check(apd_reset(lane.handle, &p), "apd_reset");
+            }
+            void *stream = nullptr;
+            Check(apd_get_stream(lane.handle, &stream), "apd_get_stream");
+            std::vector<Camera> vc;
+            std::vector<const float *> img;
+            for (int j : order) {
+                vc.push_back(cams[j]);
+                img.push_back(k.images[j].as<float>());
+            }
+            Check(apd_upload_views_split(lane.handle, (int)order.size(), vc.data(), img.data()), "apd_upload_views_split");
+            ResidentView &s = k.state[v];
+            if (pass.state != FIRST_INIT) {  // prior state of the previous pass (APD.cpp:552-581), resampled if the level changed
+                if (!s.valid) {
+                    throw std::runtime_error("view " + std::to_string(problem.ref_image_id) + " has no state of a previous pass");
+                }
+                if (s.W != LW || s.H != LH) {  // on the lane's stream, ahead of the upload that reads the result
+                    Check(apd_rescale_nearest_async(k.device, stream, s.planes.p, s.W, s.H, lane.scratch_planes.p, LW, LH, 16), "rescale planes");
+                    Check(apd_rescale_nearest_async(k.device, stream, s.weak.p, s.W, s.H, lane.scratch_weak.p, LW, LH, 1), "rescale weak");
+                    Check(apd_rescale_nearest_async(k.device, stream, s.views.p, s.W, s.H, lane.scratch_views.p, LW, LH, 4), "rescale views");
+                    std::swap(s.planes.p, lane.scratch_planes.p);
+                    std::swap(s.weak.p, lane.scratch_weak.p);
+                    std::swap(s.views.p, lane.scratch_views.p);
+                    s.W = LW;
+                    s.H = LH;
+                }
+                Check(apd_upload_prior(lane.handle, s.planes.as<float>(), s.views.as<uint32_t>(), pass.use_APD ? s.weak.as<uint8_t>() : nullptr),
+                      "apd_upload_prior");
+            }
+            Check(apd_run_before_depths(lane.handle), "apd_run_before_depths");
+            if (pass.geom_consistency) {
+                std::vector<const float *> dep;
+                for (size_t a = 0; a < order.size(); ++a) {
+                    const float *d = order[a] >= V ? k.zero_depth.as<float>() : depth_of(a, order[a]);
+                    if (!d) {
+                        return;  // the run has failed elsewhere
                     }
+                    dep.push_back(d);
                 }
-                if (failure.failed) {
-                    throw std::runtime_error(failure.what);
+                Check(apd_upload_depths(lane.handle, (int)dep.size(), dep.data()), "apd_upload_depths");
+            }
+            Check(apd_run_after_depths(lane.handle), "apd_run_after_depths");
+            if (!before_export()) {
+                return;
+            }
+            Check(apd_export_state_device(lane.handle, s.planes.as<float>(), s.weak.as<uint8_t>(), s.views.as<uint32_t>(), depth_out),
+                  "apd_export_state_device");
+            s.W = LW;
+            s.H = LH;
+            s.valid = true;
+            {
+                std::lock_guard<std::mutex> lock(done_m);
+                done_pass[v] = pass.iteration;
+                printf("pass %d (round %d, scale %d) view %08d done on rank %d (device %d)\n", pass.iteration, pass.level, pass.scale_size,
+                       problem.ref_image_id, r, k.device);
+            }
+            done_cv.notify_all();
+        };
+
+        const std::vector<Pass> plan = BuildSchedule(round_num, opt.single_level);
+        // One rank: no collective to wait for, so the passes of a level need no barrier between them either.  A (view, pass) task
+        // needs exactly what it reads: its own previous pass; in a geometric pass the maps of its sources -- this pass's for the
+        // sources that precede it and the previous pass's for the others in the reference's order, the previous pass's for all
+        // with --jacobi; and nobody may still read the two-passes-old depth map it overwrites.  View 0 of pass p + 1 starts while
+        // the last views of pass p are still in their second halves: the chains of consecutive passes overlap.  Depth maps live in
+        // two versions by pass parity.
+        const bool wavefront = G == 1 && !opt.force_rccl;
+        std::vector<std::vector<int>> readers(V);  // readers[u]: the views that list u as a source
+        for (int v = 0; v < V; ++v) {
+            for (int s_id : problems[v].src_image_ids) {
+                const int u = index_of_id.at(s_id);
+                if (u < V) {
+                    readers[u].push_back(v);
                 }
-                printf("Image size: %d * %d, %d view(s) in flight per rank\n", LW, LH, lanes_at((size_t)LW * LH));
-                ms_upload += up.lap();
+            }
+        }
+        for (size_t first = 0; first < plan.size();) {
+            size_t last = first;  // passes [first, last) run at one level
+            while (last < plan.size() && plan[last].scale_size == plan[first].scale_size) {
+                ++last;
+            }
+            if (plan[first].scale_size != level_scale) {
+                prepare_level(plan[first]);
             }
             const size_t pix = (size_t)LW * LH;
             const int level_lanes = lanes_at(pix);
-
-            // ---- `lanes` host threads per rank, each with its own handle and stream; a rank's views are handed out in order ----
-            std::vector<std::thread> workers;
-            for (int r = 0; r < G; ++r) {
-                ranks[r].next.store(0);
+            if (wavefront) {
+                Rank &k = ranks[0];
+                float *const version[2] = {k.send.as<float>(), k.recv.as<float>()};
+                const int P = (int)(last - first);
+                const int first_iteration = plan[first].iteration;
+                std::vector<int> remaining(P, V), frontier(P, 0), active(P, 0);
+                // Which task a free lane takes (under done_m).  Within a pass the views go out in order; the earliest pass that has
+                // an eligible view wins.  Eligible: the view's own previous pass is done, the maps of the previous pass it will read
+                // are published and the last readers of the map it will overwrite are done (so that a running task only ever waits for
+                // views of its OWN pass that went out before it: no wait can point at a task nobody holds), and -- in the reference's
+                // order, where the second halves of a geometric pass form a chain -- at most two lanes work on one pass: a third would
+                // only queue up behind the chain, while the next pass can already start its first views.  The smallest unfinished
+                // (pass, view) is always eligible or running, so the level drains.
+                auto eligible = [&](int pi, int v) {
+                    const Pass &pass = plan[first + (size_t)pi];
+                    const int it = pass.iteration;
+                    if (pi > 0 && done_pass[v] < it - 1) {
+                        return false;
+                    }
+                    if (it - 2 >= first_iteration) {  // the export will overwrite the view's map of pass it - 2: its last readers must be done
+                        for (int w : readers[v]) {
+                            if (done_pass[w] < ((gauss_seidel && w > v) ? it - 2 : it - 1)) {
+                                return false;
+                            }
+                        }
+                    }
+                    if (pass.geom_consistency) {
+                        if (gauss_seidel && active[pi] >= 2) {
+                            return false;
+                        }
+                        for (int s_id : problems[v].src_image_ids) {
+                            const int u = index_of_id.at(s_id);
+                            if (u < V && !(gauss_seidel && u < v) && done_pass[u] < it - 1) {
+                                return false;
+                            }
+                        }
+                    }
+                    return true;
+                };
+                auto take_task = [&](int &pi_out, int &v_out) {  // false: nothing left (or the run has failed)
+                    std::unique_lock<std::mutex> lock(done_m);
+                    for (;;) {
+                        bool any_left = false;
+                        for (int pi = 0; pi < P; ++pi) {
+                            if (frontier[pi] >= V) {
+                                continue;
+                            }
+                            any_left = true;
+                            if (eligible(pi, frontier[pi])) {
+                                pi_out = pi;
+                                v_out = frontier[pi]++;
+                                ++active[pi];
+                                return true;
+                            }
+                        }
+                        if (!any_left || failure.failed.load()) {
+                            return false;
+                        }
+                        done_cv.wait(lock);
+                    }
+                };
+                std::vector<std::thread> workers;
                 for (int li = 0; li < level_lanes; ++li) {
-                    workers.emplace_back([&, r, li]() {
-                        Rank &k = ranks[r];
+                    workers.emplace_back([&, li]() {
                         Lane &lane = k.lanes[li];
                         try {
-                            for (;;) {
-                                const int at = k.next.fetch_add(1);
-                                if (at >= (int)k.own.size() || failure.failed) {
-                                    break;
-                                }
-                                const int v = k.own[at];
-                                Problem &problem = problems[v];  // one lane per (view, pass): nobody else touches it
-                                Configure(problem, pass, opt);
-                                PatchMatchParams q = problem.params;
-                                q.depth_min = cams0[v].depth_min * 0.6f;   // APD.cpp:454-455
-                                q.depth_max = cams0[v].depth_max * 1.2f;
-                                std::vector<int> order{v};
-                                for (int s : problem.src_image_ids) {
-                                    order.push_back(index_of_id.at(s));
-                                }
-                                q.num_images = (int)order.size();
-                                const apd_params p = ToAbi(q);
-                                if (!lane.handle || lane.handle_w != LW || lane.handle_h != LH) {
-                                    if (lane.handle) {
-                                        apd_destroy(lane.handle);
-                                        lane.handle = nullptr;
+                            int pi = 0, v = 0;
+                            while (take_task(pi, v)) {
+                                const Pass &pass = plan[first + (size_t)pi];
+                                const int it = pass.iteration;
+                                auto depth_of = [&](size_t a, int j) -> const float * {
+                                    const bool this_pass = gauss_seidel && a > 0 && j < v;
+                                    const int need = this_pass ? it : it - 1;
+                                    if (!wait_done(j, need)) {
+                                        return nullptr;
                                     }
-                                    Check(apd_create(&lane.handle, k.device, LW, LH, &p), "apd_create");
-                                    lane.handle_w = LW;
-                                    lane.handle_h = LH;
-                                } else {
-                                    Check(apd_reset(lane.handle, &p), "apd_reset");
-                                }
-                                void *stream = nullptr;
-                                Check(apd_get_stream(lane.handle, &stream), "apd_get_stream");
-                                std::vector<Camera> vc;
-                                std::vector<const float *> img;
-                                for (int j : order) {
-                                    vc.push_back(cams[j]);
-                                    img.push_back(k.images[j].as<float>());
-                                }
-                                Check(apd_upload_views_split(lane.handle, (int)order.size(), vc.data(), img.data()), "apd_upload_views_split");
-                                ResidentView &s = k.state[v];
-                                if (pass.state != FIRST_INIT) {  // prior state of the previous pass (APD.cpp:552-581), resampled if the level changed
-                                    if (!s.valid) {
-                                        throw std::runtime_error("view " + std::to_string(problem.ref_image_id) + " has no state of a previous pass");
-                                    }
-                                    if (s.W != LW || s.H != LH) {  // on the lane's stream, ahead of the upload that reads the result
-                                        Check(apd_rescale_nearest_async(k.device, stream, s.planes.p, s.W, s.H, lane.scratch_planes.p, LW, LH, 16), "rescale planes");
-                                        Check(apd_rescale_nearest_async(k.device, stream, s.weak.p, s.W, s.H, lane.scratch_weak.p, LW, LH, 1), "rescale weak");
-                                        Check(apd_rescale_nearest_async(k.device, stream, s.views.p, s.W, s.H, lane.scratch_views.p, LW, LH, 4), "rescale views");
-                                        std::swap(s.planes.p, lane.scratch_planes.p);
-                                        std::swap(s.weak.p, lane.scratch_weak.p);
-                                        std::swap(s.views.p, lane.scratch_views.p);
-                                        s.W = LW;
-                                        s.H = LH;
-                                    }
-                                    Check(apd_upload_prior(lane.handle, s.planes.as<float>(), s.views.as<uint32_t>(), pass.use_APD ? s.weak.as<uint8_t>() : nullptr),
-                                          "apd_upload_prior");
-                                }
-                                Check(apd_run_before_depths(lane.handle), "apd_run_before_depths");
-                                if (pass.geom_consistency) {
-                                    // The sources' depth maps: of this pass for the sources that precede the view in the reference's order
-                                    // (they must have published), of the pass before for the others and for the view itself.
-                                    std::vector<const float *> dep;
-                                    for (size_t a = 0; a < order.size(); ++a) {
-                                        const int j = order[a];
-                                        if (j >= V) {
-                                            dep.push_back(k.zero_depth.as<float>());
-                                        } else if (gauss_seidel && a > 0 && j < v) {
-                                            std::unique_lock<std::mutex> lock(done_m);
-                                            done_cv.wait(lock, [&]() { return done_pass[j] >= pass.iteration || failure.failed.load(); });
-                                            dep.push_back(k.send.as<float>() + (size_t)(j / G) * pix);
-                                        } else {
-                                            dep.push_back(gathered_depth(k, j, pix));
-                                        }
-                                    }
-                                    if (failure.failed) {
-                                        break;
-                                    }
-                                    Check(apd_upload_depths(lane.handle, (int)dep.size(), dep.data()), "apd_upload_depths");
-                                }
-                                Check(apd_run_after_depths(lane.handle), "apd_run_after_depths");
-                                const size_t slot = (size_t)(v / G);
-                                Check(apd_export_state_device(lane.handle, s.planes.as<float>(), s.weak.as<uint8_t>(), s.views.as<uint32_t>(),
-                                                              k.send.as<float>() + slot * pix),
-                                      "apd_export_state_device");
-                                s.W = LW;
-                                s.H = LH;
-                                s.valid = true;
+                                    return version[need & 1] + (size_t)j * pix;
+                                };
+                                const auto before_export = []() { return true; };  // `eligible` has seen the old map's last readers finish
+                                run_view(0, lane, pass, v, depth_of, version[it & 1] + (size_t)v * pix, before_export);
                                 {
                                     std::lock_guard<std::mutex> lock(done_m);
-                                    done_pass[v] = pass.iteration;
-                                    printf("pass %d (round %d, scale %d) view %08d done on rank %d (device %d)\n", pass.iteration, pass.level, pass.scale_size,
-                                           problem.ref_image_id, r, k.device);
+                                    --active[pi];
+                                    if (done_pass[v] == it && --remaining[pi] == 0 && it % 4 == 3) {
+                                        printf("Round: %d done\n", pass.level);
+                                    }
                                 }
                                 done_cv.notify_all();
                             }
@@ -500,25 +602,71 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                         }
                     });
                 }
+                for (std::thread &t : workers) {
+                    t.join();
+                }
+                if (failure.failed) {
+                    throw std::runtime_error(failure.what);
+                }
+                fflush(stdout);
+                first = last;
+                continue;
             }
-            for (std::thread &t : workers) {
-                t.join();
+            // Several ranks (or --rccl): a pass ends with the all-gather of its depth maps.  `lanes` host threads per rank, each with its
+            // own handle and stream; a rank's views are handed out in order.
+            for (size_t pi = first; pi < last; ++pi) {
+                const Pass &pass = plan[pi];
+                std::vector<std::thread> workers;
+                for (int r = 0; r < G; ++r) {
+                    ranks[r].next.store(0);
+                    for (int li = 0; li < level_lanes; ++li) {
+                        workers.emplace_back([&, r, li]() {
+                            Rank &k = ranks[r];
+                            Lane &lane = k.lanes[li];
+                            try {
+                                for (;;) {
+                                    const int at = k.next.fetch_add(1);
+                                    if (at >= (int)k.own.size() || failure.failed) {
+                                        break;
+                                    }
+                                    const int v = k.own[at];
+                                    // The sources' depth maps: of this pass for the sources that precede the view in the reference's order
+                                    // (they must have published; one rank only), of the pass before for the others and for the view itself.
+                                    auto depth_of = [&](size_t a, int j) -> const float * {
+                                        if (gauss_seidel && a > 0 && j < v) {
+                                            return wait_done(j, pass.iteration) ? k.send.as<float>() + (size_t)(j / G) * pix : nullptr;
+                                        }
+                                        return gathered_depth(k, j, pix);
+                                    };
+                                    run_view(r, lane, pass, v, depth_of, k.send.as<float>() + (size_t)(v / G) * pix, []() { return true; });
+                                }
+                            } catch (const std::exception &e) {
+                                failure.set(e.what());
+                                done_cv.notify_all();
+                            }
+                        });
+                    }
+                }
+                for (std::thread &t : workers) {
+                    t.join();
+                }
+                if (failure.failed) {
+                    throw std::runtime_error(failure.what);
+                }
+                // ---- every rank gets every view's depth map (the reference: depths.dmb files, APD.cpp:497-500) ----
+                std::vector<const void *> send(G);
+                std::vector<void *> recv(G);
+                for (int r = 0; r < G; ++r) {
+                    send[r] = ranks[r].send.p;
+                    recv[r] = ranks[r].recv.p;
+                }
+                Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)), "apd_exchange_allgather");
+                if (pass.iteration % 4 == 3) {
+                    printf("Round: %d done\n", pass.level);
+                }
+                fflush(stdout);
             }
-            if (failure.failed) {
-                throw std::runtime_error(failure.what);
-            }
-            // ---- every rank gets every view's depth map (the reference: depths.dmb files, APD.cpp:497-500) ----
-            std::vector<const void *> send(G);
-            std::vector<void *> recv(G);
-            for (int r = 0; r < G; ++r) {
-                send[r] = ranks[r].send.p;
-                recv[r] = ranks[r].recv.p;
-            }
-            Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)), "apd_exchange_allgather");
-            if (pass.iteration % 4 == 3) {
-                printf("Round: %d done\n", pass.level);
-            }
-            fflush(stdout);
+            first = last;
         }
         ms_passes = stage.lap() - ms_upload;
 
