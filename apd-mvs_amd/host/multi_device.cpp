@@ -549,6 +549,9 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                 auto take_task = [&](int &pi_out, int &v_out) {  // false: nothing left (or the run has failed)
                     std::unique_lock<std::mutex> lock(done_m);
                     for (;;) {
+                        if (failure.failed.load()) {
+                            return false;
+                        }
                         bool any_left = false;
                         for (int pi = 0; pi < P; ++pi) {
                             if (frontier[pi] >= V) {
@@ -562,7 +565,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                                 return true;
                             }
                         }
-                        if (!any_left || failure.failed.load()) {
+                        if (!any_left) {
                             return false;
                         }
                         done_cv.wait(lock);
