@@ -11,6 +11,7 @@
 
 #include "../../include/apd_mi355x.h"
 #include "apd_tuning.h"
+#include "apd_lab.h"
 
 namespace apd {
 
@@ -1169,6 +1170,10 @@ __device__ __forceinline__ void subpatch_issue_quad(const Homography &H, global_
         qx[k] = med3_i32(qx[k], -1, wm1);
         qy[k] = med3_i32(qy[k], -1, hm1);
     }
+    APD_LAB_SUBPATCH_ROWS(qx, qy);
+    // (Round 4 measured taking taps 0 and 1 of a row with ONE 16-byte load where they share a row segment -- 98.9 % of the rows do:
+    // L1 tag accesses per launch -24 %, launch time 49.2 -> 56.7 ms; the tag count was a proxy, a 16-byte gather keeps the address /
+    // data path of the L1 busy four times as long as a dword.  profiles/r04/ab_k910_row_segments.txt.  Nine dword gathers it is.)
     APD_STAGE();
 #pragma unroll
     for (int k = 0; k < N; ++k) {

@@ -32,6 +32,20 @@ static __device__ unsigned long long g_weak_stats[8];
         }                                                                                                                    \
         APD_WIN_COUNT((in_window) ? 0 : ((fast_recip) ? 1 : 2), 1);                                                          \
     } while (0)
+// sub-patch taps (index i * 3 + j: x offset i, y offset j; quad coordinates after the clamp): could the taps of one y offset share a
+// 16-byte row segment of the column-pair image (same row, 0 <= column step <= 6)?  [6] rows of three taps where taps 0 and 1 or
+// taps 1 and 2 could, [7] rows looked at
+#define APD_LAB_SUBPATCH_ROWS(qx, qy)                                                                      \
+    do {                                                                                                   \
+        int fits_ = 0;                                                                                     \
+        for (int j_ = 0; j_ < 3; ++j_) {                                                                   \
+            const bool a_ = qy[j_] == qy[3 + j_] && qx[3 + j_] - qx[j_] >= 0 && qx[3 + j_] - qx[j_] <= 6;  \
+            const bool b_ = qy[3 + j_] == qy[6 + j_] && qx[6 + j_] - qx[3 + j_] >= 0 && qx[6 + j_] - qx[3 + j_] <= 6; \
+            fits_ += (a_ || b_) ? 1 : 0;                                                                   \
+        }                                                                                                  \
+        APD_WEAK_COUNT(6, fits_);                                                                          \
+        APD_WEAK_COUNT(7, 3);                                                                              \
+    } while (0)
 #define APD_LAB_STATS_ACCESSOR_(name, symbol)                                                          \
     extern "C" int name(unsigned long long *out, int reset)                                            \
     {                                                                                                  \
@@ -54,6 +68,7 @@ static __device__ unsigned long long g_weak_stats[8];
 #define APD_WEAK_COUNT(i, n) ((void)0)
 #define APD_WEAK_COUNT_WAVE(i) ((void)0)
 #define APD_LAB_NCC_STATS(in_window, fast_recip) ((void)0)
+#define APD_LAB_SUBPATCH_ROWS(qx, qy) ((void)0)
 #define APD_WIN_STATS_ACCESSOR(name)
 #define APD_LAB_WEAK_STATS_ACCESSOR
 

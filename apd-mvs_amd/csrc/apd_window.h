@@ -3,7 +3,6 @@
 #pragma once
 
 #include "apd_device.h"
-#include "apd_lab.h"
 
 
 namespace apd {

@@ -92,7 +92,14 @@ __global__ __launch_bounds__(256) void gather_wide(const unsigned char *__restri
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const unsigned char *base = buf + (size_t)((wave * 7919u) % windows) * 16384u;
     const uint32_t w = 4u * DWORDS;
-    const uint32_t off = p == 0 ? lane * 128u : (p == 1 ? (lane >> 2) * 256u + (lane & 3u) * w : lane * w);
+    // patterns 3..7 (round 4): one line per lane like pattern 0, the block shifted off its natural alignment -- can a software texture
+    // fetch take a row segment that starts wherever its first tap lies?  3: +4 B (dword aligned), 4: +2 B, 5: +60 B (dword aligned,
+    // crosses a 64-byte boundary), 6: +120 B (crosses the 128-byte line), 7: +6 B
+    // patterns 8..11: 64 scattered blocks inside the wave's L1-resident 16 KB window (the regime of K9/K10's sub-patch taps: hits),
+    // 16-byte aligned, at +4, +8 and +12 bytes
+    static const uint32_t shift[8] = {0u, 0u, 0u, 4u, 2u, 60u, 120u, 6u};
+    const uint32_t off = p >= 8 ? (((lane * 2654435761u >> 18) & 0x3FF0u) % 16000u) + 4u * (uint32_t)(p - 8)
+                                : (p == 0 || p >= 3 ? lane * 128u + shift[p & 7] : (p == 1 ? (lane >> 2) * 256u + (lane & 3u) * w : lane * w));
     uint32_t acc = 0;
 #pragma unroll 8
     for (int i = 0; i < kIter; ++i) {
@@ -146,9 +153,13 @@ int main()
         const double gathers = (double)blocks * 4 * kIter;
         printf("pattern %2d  %-52s %8.3f ms  %7.2f ns per wave-level gather per CU\n", p, names[p], ms, ms * 1e6 / (gathers / 256.0));
     }
-    static const char *wide_names[3] = {"one 128-byte line per lane", "quads of lanes on 4 consecutive blocks, one line pair per quad", "lane * width (contiguous)"};
+    static const char *wide_names[12] = {"one 128-byte line per lane", "quads of lanes on 4 consecutive blocks, one line pair per quad", "lane * width (contiguous)",
+                                        "one line per lane, block at +4 B", "one line per lane, block at +2 B", "one line per lane, block at +60 B (crosses 64 B)",
+                                        "one line per lane, block at +120 B (crosses the line)", "one line per lane, block at +6 B",
+                                        "64 scattered blocks in 16 KB (L1 hits), 16-byte aligned", "64 scattered blocks in 16 KB, +4 B", "64 scattered blocks in 16 KB, +8 B",
+                                        "64 scattered blocks in 16 KB, +12 B"};
     for (int width = 2; width <= 4; width += 2) {
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < 12; ++p) {
             for (int rep = 0; rep < 2; ++rep) {
                 if (rep == 1) {
                     CHECK(hipEventRecord(e0));

@@ -40,6 +40,8 @@ for it in range(iters):
           "hypotheses 9..14: %.1f needed, %.1f executed (%.3f); sub-patches %.1f needed, %.1f executed (%.3f)"
           % (it, weak_px, 100.0 * weak_px / (W * H), s[0] / weak_px, s[1] * 64 / weak_px, s[0] / max(s[1] * 64, 1), s[2] / weak_px,
              s[3] * 64 / weak_px, s[2] / max(s[3] * 64, 1), s[4] / weak_px, s[5] * 64 / weak_px, s[4] / max(s[5] * 64, 1)))
+    if s[7] > 0:
+        print("        sub-patch rows of three taps in which two neighbouring taps lie in one 16-byte row segment: %.1f %%" % (100.0 * s[6] / s[7]))
     L.apd_debug_win_stats_weak(win, 1)
     w = [float(v) for v in win]
     lanes = max(w[0] + w[1] + w[2], 1.0)
