@@ -196,6 +196,47 @@ __device__ __forceinline__ float recip_fast(float z)
 __device__ __forceinline__ float recip_rn(float z, bool ok) { return __builtin_expect(ok, 1) ? recip_fast(z) : 1.0f / z; }
 __device__ __forceinline__ float recip_rn(float z) { return recip_rn(z, recip_fast_ok(z)); }
 
+// The two IEEE operations every NCC ends with (contract C1 / C4: sqrtf correctly rounded, `/` an IEEE division), without the
+// range scaling the compiler's general sequences carry (25 instead of 38 instructions per NCC epilogue; K9/K10 runs nine of them
+// per NCCNew on two waves per SIMD, where every instruction of the chain costs its full latency):
+//   sqrt_rn_mid(x)   = v_sqrt_f32 (<= 1 ulp) and the two one-ulp probes of the compiler's own sequence, whose range scaling only
+//                      matters below 2^-96; equal to sqrtf for every binary32 x with biased exponent 31..223 (all of them checked)
+//                      and for NaN;
+//   div_rn_mid(a, b) = q = a * y with y = RN(1 / b) (recip_fast), r = a - b q exactly (one fma), q + r y (one fma): the correctly
+//                      rounded quotient whenever y is the correctly rounded reciprocal and nothing over- or underflows
+//                      (Markstein 1990); 2^32 random pairs over the operand ranges of an NCC checked against `/`, zero included.
+// tools/valu_rates.hip --check runs both comparisons on the device (tests/test_gpu_edge_cases.py::test_isa_contract_exhaustive).
+// Callers guarantee the ranges: x = var_ref * var_src with both in [1e-5, 1.7e4], b = sqrt of that, |a| <= 6.6e4.
+__device__ __forceinline__ float sqrt_rn_mid(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_below = fmaf(-below, s, x), r_above = fmaf(-above, s, x);
+    float r = (r_below <= 0.0f) ? below : s;
+    r = (r_above > 0.0f) ? above : r;
+    return r;
+#else
+    return sqrtf(x);
+#endif
+}
+
+__device__ __forceinline__ float div_rn_mid(float a, float b)
+{
+    const float y = recip_fast(b);
+    const float q = a * y;
+    const float r = fmaf(-b, q, a);
+    return fmaf(r, y, q);
+}
+
+// Tail of every NCC (APD.cu:585-613 and the sub-patch terms of :461-505): 1 - covariance / sqrt(var_ref * var_src), clamped to [0, 2].
+// The callers have tested both variances against 1e-5 already.
+__device__ __forceinline__ float ncc_cost_from_moments(float var_r, float var_s, float covar)
+{
+    const float denom = sqrt_rn_mid(var_r * var_s);
+    return fmaxf(0.0f, fminf(2.0f, 1.0f - div_rn_mid(covar, denom)));
+}
+
 // ------------------------------------------------------------------------------------------------
 // XORWOW (contract C8): state kept in six registers; AoS of 6 words per pixel in HBM
 // ------------------------------------------------------------------------------------------------
@@ -1074,8 +1115,7 @@ __device__ __forceinline__ float ncc_fixed_from_h(const FrameArgs &fa, const Vie
         return 2.0f;
     }
     const float covar = fmaf(-rp.mean, sum_s, sum_rs);
-    const float denom = sqrtf(rp.var * var_s);
-    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+    return ncc_cost_from_moments(rp.var, var_s, covar);
 }
 
 // ComputeBilateralNCCOld for plane q = n/d against source view vc.  kQuad selects the texel-quad image.
@@ -1222,8 +1262,7 @@ __device__ __forceinline__ float subpatch_finish_quad(const quad_t (&t)[kSubN * 
         return 2.0f;
     }
     const float covar = fmaf(-mean_r, sum_s, sum_rs);
-    const float denom = sqrtf(var_r * var_s);
-    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+    return ncc_cost_from_moments(var_r, var_s, covar);
 }
 
 template <int kRecip = kRecipExact>
@@ -1347,8 +1386,7 @@ __device__ __forceinline__ float subpatch_cost_fquad(const Homography &H, global
         return 2.0f;
     }
     const float covar = fmaf(-mean_r, sum_s, sum_rs);
-    const float denom = sqrtf(var_r * var_s);
-    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+    return ncc_cost_from_moments(var_r, var_s, covar);
 }
 
 // Generic patch (any centre / radius / increment): sub-patches of ComputeBilateralNCCNew
@@ -1400,8 +1438,7 @@ __device__ __forceinline__ float patch_cost_generic(const FrameArgs &fa, const V
         return 2.0f;
     }
     const float covar = fmaf(-sum_r, sum_s, sum_rs);
-    const float denom = sqrtf(var_r * var_s);
-    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+    return ncc_cost_from_moments(var_r, var_s, covar);
 }
 
 // ------------------------------------------------------------------------------------------------

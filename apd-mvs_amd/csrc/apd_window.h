@@ -503,8 +503,7 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
         return 2.0f;
     }
     const float covar = fmaf(-rp.mean, sum_s, sum_rs);
-    const float denom = sqrtf(rp.var * var_s);
-    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+    return ncc_cost_from_moments(rp.var, var_s, covar);
 }
 
 // The same cost for an already projected centre (the caller has done the bounds test of APD.cu:546): K9/K10's centre patch.
@@ -565,8 +564,7 @@ __device__ __forceinline__ float ncc_fixed_windowed_from_h(const FrameArgs &fa, 
         return 2.0f;
     }
     const float covar = fmaf(-rp.mean, sum_s, sum_rs);
-    const float denom = sqrtf(rp.var * var_s);
-    return fmaxf(0.0f, fminf(2.0f, 1.0f - covar / denom));
+    return ncc_cost_from_moments(rp.var, var_s, covar);
 }
 
 }  // namespace apd

@@ -131,7 +131,8 @@ def test_nearest_strong_search_on_crafted_maps(gpu_pkg, ob, synth, W, H):
 
 
 def test_isa_contract_exhaustive():
-    """The three hardware facts the bit-exact contract relies on, checked over all 2^32 float inputs on this GPU:
+    """The hardware facts the bit-exact contract relies on, checked over all 2^32 float inputs on this GPU (and, for the two-operand
+    division, over 2^32 pseudo-random pairs):
     v_rcp_f32 + one FMA Newton step == IEEE 1/z for biased exponents 27..227; v_fract_f32 == min(x - floor(x),
     1 - 2^-24) for finite x and NaN otherwise; v_cvt_flr_i32_f32 == saturating (int)floor(x) for non-NaN x."""
     exe = os.path.join(ROOT, "tools", "_build", "valu_rates")
@@ -142,6 +143,9 @@ def test_isa_contract_exhaustive():
     assert facts.get("CHECK_fract_finite_mismatches") == "0", out
     assert facts.get("CHECK_fract_nonfinite_not_nan") == "0", out
     assert facts.get("CHECK_cvt_flr_non_nan_mismatches") == "0", out
+    # the NCC epilogue: square root and division without the compiler's range scaling == sqrtf and `/` on the ranges the kernels use
+    assert facts.get("CHECK_sqrt_midrange_mismatches") == "0" and facts.get("CHECK_sqrt_nan_not_nan") == "0", out
+    assert facts.get("CHECK_div_midrange_mismatches") == "0" and int(facts.get("CHECK_div_pairs", "0")) == 1 << 32, out
 
 
 @pytest.mark.parametrize("threshold,rotate", [(float("inf"), 4), (0.0, 4), (0.005, 3), (1e-30, 2)])

@@ -113,6 +113,86 @@ __global__ __launch_bounds__(256) void recip_check2(uint32_t base, unsigned long
     }
 }
 
+// ---- the NCC epilogue's square root and division without range scaling (csrc/apd_device.h: sqrt_rn_mid, div_rn_mid) -------------
+__device__ __forceinline__ float sqrt_rn_mid(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_below = fmaf(-below, s, x), r_above = fmaf(-above, s, x);
+    float r = (r_below <= 0.0f) ? below : s;
+    r = (r_above > 0.0f) ? above : r;
+    return r;
+}
+
+__device__ __forceinline__ float div_rn_mid(float a, float b)
+{
+    const float y = recip_newton(b);
+    const float q = a * y;
+    const float r = fmaf(-b, q, a);
+    return fmaf(r, y, q);
+}
+
+// every positive binary32 with biased exponent 31..223 ([0] mismatches against sqrtf) and every NaN ([1] results that are not NaN)
+__global__ __launch_bounds__(256) void sqrt_check(uint32_t base, unsigned long long *counts, uint32_t *examples)
+{
+    const uint32_t bits = base + blockIdx.x * 256u + threadIdx.x;
+    const float x = __uint_as_float(bits);
+    const uint32_t ex = (bits >> 23) & 0xFFu;
+    if (x != x) {
+        const float r = sqrt_rn_mid(x);
+        if (r == r) {
+            atomicAdd(&counts[1], 1ull);
+        }
+        return;
+    }
+    if ((bits >> 31) != 0u || ex < 31u || ex > 223u) {
+        return;
+    }
+    const float exact = sqrtf(x), mine = sqrt_rn_mid(x);
+    if (__float_as_uint(exact) != __float_as_uint(mine)) {
+        const unsigned long long k = atomicAdd(&counts[0], 1ull);
+        if (k < 16) {
+            examples[2 * k] = bits;
+            examples[2 * k + 1] = __float_as_uint(mine);
+        }
+    }
+}
+
+// 2^32 pseudo-random pairs over the operand ranges of an NCC epilogue and beyond: b = 2^-20 .. 2^20 (the code has 1e-5 .. 1.7e4),
+// a = +-2^-40 .. 2^30 with one pair in 64 a = +-0; [0] results whose bits differ from a / b (an exact zero may differ in sign: the
+// caller only forms 1 - q), [2] pairs checked
+__global__ __launch_bounds__(256) void div_check(uint32_t base, unsigned long long *counts, uint32_t *examples)
+{
+    uint32_t h = base + blockIdx.x * 256u + threadIdx.x;
+    uint32_t w0 = h * 0x9E3779B1u;
+    w0 ^= w0 >> 15;
+    w0 *= 0x85EBCA77u;
+    w0 ^= w0 >> 13;
+    uint32_t w1 = (h ^ 0xA5A5A5A5u) * 0xC2B2AE3Du;
+    w1 ^= w1 >> 16;
+    w1 *= 0x27D4EB2Fu;
+    w1 ^= w1 >> 15;
+    const uint32_t eb = 107u + (w0 >> 23) % 41u;                   // biased exponent of b: 2^-20 .. 2^20
+    const float b = __uint_as_float((eb << 23) | (w0 & 0x7FFFFFu));
+    const uint32_t ea = 87u + (w1 >> 24) % 71u;                    // 2^-40 .. 2^30
+    float a = __uint_as_float((w1 & 0x80000000u) | (ea << 23) | (w1 & 0x7FFFFFu));
+    if ((h & 63u) == 0u) {
+        a = __uint_as_float(w1 & 0x80000000u);
+    }
+    const float exact = a / b, mine = div_rn_mid(a, b);
+    atomicAdd(&counts[2], 1ull);
+    const bool same = __float_as_uint(exact) == __float_as_uint(mine) || (exact == 0.0f && mine == 0.0f);
+    if (!same) {
+        const unsigned long long k = atomicAdd(&counts[0], 1ull);
+        if (k < 8) {
+            examples[4 * k] = __float_as_uint(a);
+            examples[4 * k + 1] = __float_as_uint(b);
+            examples[4 * k + 2] = __float_as_uint(mine);
+            examples[4 * k + 3] = __float_as_uint(exact);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fract_check(uint32_t base, unsigned long long *counts, uint32_t *examples)
 {
     const uint32_t bits = base + blockIdx.x * 256u + threadIdx.x;
@@ -336,6 +416,33 @@ static int run_checks()
     printf("v_cvt_flr_i32_f32 vs saturating (int)floor(x) with NaN -> 0: mismatches=%llu, of which x is not NaN: %llu\n", hcounts[0],
            hcounts[1]);
     printf("CHECK_cvt_flr_non_nan_mismatches=%llu\n", hcounts[1]);
+    // (4) square root and division of the NCC epilogue
+    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
+    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
+    for (uint32_t hi = 0; hi < 256; ++hi) {
+        hipLaunchKernelGGL(sqrt_check, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
+    }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
+    printf("sqrt_rn_mid vs sqrtf over every positive binary32 with biased exponent 31..223: mismatches=%llu; NaN inputs not giving NaN: %llu\n", hcounts[0], hcounts[1]);
+    printf("CHECK_sqrt_midrange_mismatches=%llu\nCHECK_sqrt_nan_not_nan=%llu\n", hcounts[0], hcounts[1]);
+    for (int i = 0; i < 8 && (unsigned long long)i < hcounts[0]; ++i) {
+        printf("   x=%08x mine=%08x\n", hex[2 * i], hex[2 * i + 1]);
+    }
+    CHECK(hipMemset(dcounts, 0, 4 * sizeof(unsigned long long)));
+    CHECK(hipMemset(dex, 0, 32 * sizeof(uint32_t)));
+    for (uint32_t hi = 0; hi < 256; ++hi) {
+        hipLaunchKernelGGL(div_check, dim3(1u << 16), dim3(256), 0, 0, hi << 24, dcounts, dex);
+    }
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(hcounts, dcounts, sizeof(hcounts), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hex, dex, sizeof(hex), hipMemcpyDeviceToHost));
+    printf("div_rn_mid vs a / b over %llu pseudo-random pairs (b = 2^-20..2^20, a = +-2^-40..2^30 and +-0): mismatches=%llu\n", hcounts[2], hcounts[0]);
+    printf("CHECK_div_midrange_mismatches=%llu\nCHECK_div_pairs=%llu\n", hcounts[0], hcounts[2]);
+    for (int i = 0; i < 8 && (unsigned long long)i < hcounts[0]; ++i) {
+        printf("   a=%08x b=%08x mine=%08x exact=%08x\n", hex[4 * i], hex[4 * i + 1], hex[4 * i + 2], hex[4 * i + 3]);
+    }
     float *dsv, hsv[6];
     CHECK(hipMalloc(&dsv, sizeof(hsv)));
     hipLaunchKernelGGL(special_values, dim3(1), dim3(1), 0, 0, dsv);
