@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(256) void k_fusion_compact(RefTask task, int n, con
 }
 
 thread_local std::string g_fusion_error;
+thread_local double g_fusion_ms[3] = {0.0, 0.0, 0.0};  // last apd_fuse_views: set-up (allocations, uploads), views (kernels + point downloads), PLY file
 
 int fusion_fail(int code, const char *what, hipError_t e)
 {
@@ -298,12 +300,30 @@ int fusion_fail(int code, const char *what, hipError_t e)
 
 extern "C" const char *apd_fusion_last_error(void) { return g_fusion_error.c_str(); }
 
+extern "C" int apd_fusion_last_timing(double *setup_ms, double *views_ms, double *file_ms)
+{
+    if (setup_ms) {
+        *setup_ms = g_fusion_ms[0];
+    }
+    if (views_ms) {
+        *views_ms = g_fusion_ms[1];
+    }
+    if (file_ms) {
+        *file_ms = g_fusion_ms[2];
+    }
+    return APD_OK;
+}
+
 extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *cameras, const float *const *images, int image_channels,
                               const float *const *depths, const float *const *normals, const uint8_t *const *weaks,
                               const uint8_t *const *blocks, const int *rows, const int *cols, const int *pair_offsets, const int *pair_indices, int maps_on_device,
                               const char *ply_path, long long *num_points)
 {
     g_fusion_error.clear();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    };
     if (num_views <= 0 || !cameras || !images || !depths || !normals || !weaks || !rows || !cols || !pair_offsets || !pair_indices ||
         !ply_path || !num_points) {
         g_fusion_error = "apd_fuse_views: null argument";
@@ -333,11 +353,16 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
     std::vector<void *> owned;
     std::vector<DevView> hv(num_views);
     DevView *dviews = nullptr;
+    void *staging = nullptr;  // page-locked buffer of the point downloads
     auto cleanup = [&]() {
         for (void *p : owned) {
             hipFree(p);
         }
         owned.clear();
+        if (staging) {
+            hipHostFree(staging);
+            staging = nullptr;
+        }
     };
     auto dev_alloc = [&](size_t bytes, void **out) -> hipError_t {
         hipError_t e = hipMalloc(out, bytes > 0 ? bytes : 1);
@@ -420,7 +445,14 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
     FUS_TRY(dev_alloc(sizeof(int), &total));
     FUS_TRY(dev_alloc(max_px * 15, &records));
 
-    std::vector<uint8_t> body;  // PLY records: x y z float + diffuse_blue/green/red uchar (APD.cpp:214-254)
+    // PLY records: x y z float + diffuse_blue/green/red uchar (APD.cpp:214-254), one buffer per view (one growing vector re-allocates and
+    // copies hundreds of megabytes at Tanks&Temples scale), downloaded through one page-locked staging buffer
+    std::vector<std::vector<uint8_t>> body((size_t)num_views);
+    if (hipHostMalloc(&staging, max_px * 15 > 0 ? max_px * 15 : 1, hipHostMallocDefault) != hipSuccess) {
+        staging = nullptr;  // pageable downloads then
+    }
+    g_fusion_ms[0] = ms_since(t_begin);
+    const auto t_views = std::chrono::steady_clock::now();
     long long count = 0;
     unsigned epoch = 0;
     for (int i = 0; i < num_views; ++i) {
@@ -471,12 +503,18 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
         FUS_TRY(hipMemcpy(&npts, total, sizeof(int), hipMemcpyDeviceToHost));
         (void)rounds;
         if (npts > 0) {
-            const size_t base = body.size();
-            body.resize(base + (size_t)npts * 15);
-            FUS_TRY(hipMemcpy(body.data() + base, records, (size_t)npts * 15, hipMemcpyDeviceToHost));
+            body[i].resize((size_t)npts * 15);
+            if (staging) {
+                FUS_TRY(hipMemcpy(staging, records, (size_t)npts * 15, hipMemcpyDeviceToHost));
+                memcpy(body[i].data(), staging, (size_t)npts * 15);
+            } else {
+                FUS_TRY(hipMemcpy(body[i].data(), records, (size_t)npts * 15, hipMemcpyDeviceToHost));
+            }
             count += npts;
         }
     }
+    g_fusion_ms[1] = ms_since(t_views);
+    const auto t_file = std::chrono::steady_clock::now();
     cleanup();
     FILE *f = fopen(ply_path, "wb");
     if (!f) {
@@ -485,11 +523,15 @@ extern "C" int apd_fuse_views(int device, int num_views, const apd_camera *camer
     }
     fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
                "property uchar diffuse_blue\nproperty uchar diffuse_green\nproperty uchar diffuse_red\nend_header\n", (int)count);
-    const bool ok = body.empty() || fwrite(body.data(), 1, body.size(), f) == body.size();
+    bool ok = true;
+    for (const std::vector<uint8_t> &part : body) {
+        ok = ok && (part.empty() || fwrite(part.data(), 1, part.size(), f) == part.size());
+    }
     if (fclose(f) != 0 || !ok) {
         g_fusion_error = std::string("apd_fuse_views: short write to ") + ply_path;
         return APD_ERR_IO;
     }
     *num_points = count;
+    g_fusion_ms[2] = ms_since(t_file);
     return APD_OK;
 }

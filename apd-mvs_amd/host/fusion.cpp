@@ -347,7 +347,10 @@ void RunFusionOnDevice(FusionPrefetch *f, const std::vector<const float *> &dept
     long long count = 0;
     const int st = apd_fuse_views(f->device, V, cams.data(), f->imgs.data(), f->channels, depths.data(), normals.data(), weaks.data(),
                                   f->any_block ? f->blocks.data() : nullptr, rws.data(), cls.data(), offs.data(), idx.data(), 1, ply_path.string().c_str(), &count);
-    std::cout << "Fusion + PLY: " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_fuse).count() << " ms" << std::endl;
+    double ms_setup = 0, ms_views = 0, ms_file = 0;
+    apd_fusion_last_timing(&ms_setup, &ms_views, &ms_file);
+    std::cout << "Fusion + PLY: " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_fuse).count() << " ms (set-up "
+              << (long long)ms_setup << ", views " << (long long)ms_views << ", file " << (long long)ms_file << ")" << std::endl;
     const std::string err = st != APD_OK ? apd_fusion_last_error() : "";
     CancelFusionInputs(f);
     if (st != APD_OK) {

@@ -164,12 +164,18 @@ int DefaultLanes(size_t pixels)
 // set, their packed copies -- float quads on the coarse levels) and scratch, and at the end the gathered final maps, their
 // depth / normal split and the fusion's buffers.  Upper bound per pixel of the finest level; main() compares it with the free
 // memory before choosing this scheduler and every in-memory mode checks it again here.
-double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources)
+double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources, double *passes_out, double *final_out)
 {
     const double slots = (double)((num_views + num_ranks - 1) / num_ranks);
     const double m = (double)max_sources;
     const double passes = 4.0 * num_images + 4.0 * slots * (1.0 + num_ranks) + 4.0 + 21.0 * slots + lanes * (21.0 + 107.0 + 8.0 * (m + 1.0) + 20.5 * m);
     const double final_stage = 21.0 * slots + (num_ranks > 1 ? 17.0 * slots * num_ranks : 0.0) + 16.0 * num_views + 21.0 * num_views + 8.0 * m + 40.0;
+    if (passes_out) {
+        *passes_out = passes;
+    }
+    if (final_out) {
+        *final_out = final_stage;
+    }
     return std::max(passes, final_stage);
 }
 
@@ -241,11 +247,17 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
     const int coarsest = opt.single_level ? 1 : 1 << (round_num - 1);
     const int lanes = std::max(lanes_at(pix0), lanes_at((size_t)std::lround(W0 / (double)coarsest) * (size_t)std::lround(H0 / (double)coarsest)));
     const bool gauss_seidel = opt.in_memory;  // the reference's order of views (one rank); otherwise Jacobi over views
+    bool release_before_fusion = true;
     printf("There are %d problems needed to be processed on %d rank(s), up to %d view(s) in flight per rank!\nRound nums: %d\n", V, G, lanes, round_num);
     {
         size_t free_bytes = 0, total_bytes = 0;
-        const double need = (double)pix0 * InMemoryBytesPerPixel(N, V, G, lanes, (int)max_src);
-        if (apd_device_memory(devices[0], &free_bytes, &total_bytes) == APD_OK && need > 0.9 * (double)free_bytes) {
+        double per_px_passes = 0, per_px_final = 0;
+        const double need = (double)pix0 * InMemoryBytesPerPixel(N, V, G, lanes, (int)max_src, &per_px_passes, &per_px_final);
+        const bool have_memory = apd_device_memory(devices[0], &free_bytes, &total_bytes) == APD_OK;
+        // room for the passes' buffers AND the final maps at once: the handles, level images and depth sets are then left to the end of
+        // the process instead of being released one hipFree (= one device synchronisation) at a time before the fusion
+        release_before_fusion = !have_memory || (double)pix0 * (per_px_passes + per_px_final) > 0.8 * (double)free_bytes;
+        if (have_memory && need > 0.9 * (double)free_bytes) {
             fprintf(stderr, "%.1f GB of resident state against %.1f GB free on device %d: this folder does not fit the in-memory scheduler "
                             "(use --files, more devices or fewer views in flight: --ranks 1)\n", need / 1e9, free_bytes / 1e9, devices[0]);
             return EXIT_FAILURE;
@@ -675,22 +687,24 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
 
         // ---- before fusion: planes (world normal + depth) and weak maps of all views on every rank, view by view ----
         const size_t pix = (size_t)LW * LH;
-        for (Rank &k : ranks) {
-            for (Lane &l : k.lanes) {  // handles, level images and depth blocks are no longer needed: room for the final maps
-                if (l.handle) {
-                    apd_destroy(l.handle);
-                    l.handle = nullptr;
+        if (release_before_fusion) {
+            for (Rank &k : ranks) {
+                for (Lane &l : k.lanes) {  // handles, level images and depth blocks are no longer needed: room for the final maps
+                    if (l.handle) {
+                        apd_destroy(l.handle);
+                        l.handle = nullptr;
+                    }
+                    l.scratch_planes.release();
+                    l.scratch_weak.release();
+                    l.scratch_views.release();
                 }
-                l.scratch_planes.release();
-                l.scratch_weak.release();
-                l.scratch_views.release();
+                for (DeviceBuffer &b : k.images) {
+                    b.release();
+                }
+                k.send.release();
+                k.recv.release();
+                k.zero_depth.release();
             }
-            for (DeviceBuffer &b : k.images) {
-                b.release();
-            }
-            k.send.release();
-            k.recv.release();
-            k.zero_depth.release();
         }
         std::vector<const float *> planes_of(V, nullptr);  // on rank 0's device
         if (G == 1) {  // one rank: everything is where the fusion runs
@@ -800,19 +814,9 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         // device memory goes with the process (the reference exits at the failing call, APD.cpp:315-323)
         return EXIT_FAILURE;
     }
-    for (Rank &k : ranks) {
-        for (auto &kv : k.state) {
-            kv.second.planes.release();
-            kv.second.weak.release();
-            kv.second.views.release();
-        }
-    }
-    for (int v = 0; v < V; ++v) {
-        fuse_depth[v].release();
-        fuse_normal[v].release();
-    }
-    final_planes0.release();
-    final_weak0.release();
+    // The views' state, the final maps and (when there was room to keep them) the handles and level images stay allocated: this is the
+    // program's last act, main() leaves through _Exit, and the driver reclaims a process's device memory in one step -- released one
+    // hipFree at a time (each a device synchronisation) 152 views cost a third of a second.
     apd_exchange_destroy(exchange);
     printf("Stages: images + cameras %lld ms, device set-up %lld ms, level images (resample + upload) %lld ms, passes %lld ms, final gather + maps %lld ms, "
            "fusion %lld ms\n", ms_load, ms_setup, ms_upload, ms_passes, ms_gather, ms_fusion);

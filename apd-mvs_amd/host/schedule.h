@@ -104,7 +104,8 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems);
 // Views in flight per device by frame size, and the device bytes per pixel (finest level) the in-memory scheduler keeps resident
 // on its busiest device (host/multi_device.cpp).
 int DefaultLanes(size_t pixels);
-double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources);
+double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources, double *passes_out = nullptr,
+                             double *final_out = nullptr);
 
 // APD.h:34 with the maps already in memory (index = problem index); RunFusion reads them from the result folders instead
 struct FinalMaps {

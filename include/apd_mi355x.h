@@ -296,6 +296,9 @@ int apd_fuse_views(int device, int num_views, const apd_camera *cameras, const f
                    const uint8_t *const *blocks, const int *rows, const int *cols, const int *pair_offsets, const int *pair_indices, int maps_on_device, const char *ply_path,
                    long long *num_points);
 const char *apd_fusion_last_error(void);
+/* Where the last apd_fuse_views of this thread spent its time (ms): set-up (allocations, uploads of host maps), the views (kernels,
+ * consumption rounds, download of the points), the PLY file (release of the buffers + write). */
+int apd_fusion_last_timing(double *setup_ms, double *views_ms, double *file_ms);
 
 /* Host-side constant of K3 (GenNeighbours, APD.cu:1911 / :1946): its inlier test `dist / (depth_max - depth_min) <
  * ransac_threshold` (dist >= 0) is evaluated on the device as `dist < cut`, the same predicate for every binary32 dist because
