@@ -225,10 +225,10 @@ static bool read_gray_image_cached(const path &stem, Mat &image_float, bool shar
     return true;
 }
 
-// Runs job(0) .. job(count - 1) on up to `max_threads` host threads (0: one per core, at most 16).
+// Runs job(0) .. job(count - 1) on up to `max_threads` host threads (0: one per core, at most 32).
 void ParallelFor(size_t count, const std::function<void(size_t)> &job, unsigned max_threads)
 {
-    unsigned n = max_threads ? max_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned n = max_threads ? max_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     n = (unsigned)std::min<size_t>(n, count);
     if (n <= 1) {
         for (size_t i = 0; i < count; ++i) {
