@@ -247,6 +247,36 @@ def test_subset_run_ignores_what_an_earlier_full_run_left_on_disk(gpu_pkg, synth
     assert (dirty / "APD" / "APD.ply").read_bytes() == (clean / "APD" / "APD.ply").read_bytes() == (mem / "APD" / "APD.ply").read_bytes()
 
 
+def test_reference_order_in_memory_with_asymmetric_source_lists(gpu_pkg, synth, tmp_path):
+    """The one-rank scheduler hands out (view, pass) tasks by readiness -- its own previous pass, the maps it will read, the last
+    readers of the two-passes-old map it overwrites -- with several views in flight and no barrier between the passes of a level.
+    Source lists that are not symmetric (u lists v, v does not list u; a view nobody lists; a view listing only later views) make the
+    reader and the source relations differ.  Whatever the number of views in flight, the bytes must be those of the file-based driver."""
+    import shutil
+    W, H, nviews, seed = 1100, 64, 7, 3     # two pyramid levels: APD and geometric passes at both
+    base = tmp_path / "base"
+    base.mkdir()
+    _write_dense_folder(base, synth, W, H, nviews, jpeg=False)
+    lists = {0: [3, 5], 1: [0], 2: [6, 0, 1], 3: [2], 4: [5, 6], 5: [1, 4, 0, 2], 6: [0]}   # nobody lists 3's reader set == its sources
+    pair = "%d\n" % nviews
+    for i in range(nviews):
+        pair += "%d\n%d %s\n" % (i, len(lists[i]), " ".join("%d %.1f" % (j, 10.0 - k) for k, j in enumerate(lists[i])))
+    (base / "pair.txt").write_text(pair)
+    runs = {}
+    for name, extra in (("files", ["--files"]), ("default", []), ("two", ["--ranks", "2"]), ("seven", ["--ranks", "7"]), ("one", ["--ranks", "1"])):
+        d = tmp_path / name
+        shutil.copytree(base, d)
+        r = subprocess.run([APD_BIN, str(d), "0", "--seed", str(seed), "--iters", "1", "--keep-maps"] + extra, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        runs[name] = d
+    for name in ("default", "two", "seven", "one"):
+        for idx in range(nviews):
+            for f in ("depths.dmb", "normals.dmb", "weak.bin", "selected_views.bin"):
+                assert (runs["files"] / "APD" / ("%08d" % idx) / f).read_bytes() == (runs[name] / "APD" / ("%08d" % idx) / f).read_bytes(), (name, idx, f)
+        assert (runs["files"] / "APD" / "APD.ply").read_bytes() == (runs[name] / "APD" / "APD.ply").read_bytes(), name
+
+
 def test_multi_device_scheduler_is_rank_count_invariant(gpu_pkg, synth, tmp_path):
     """`APD folder 0,0,0` (host/multi_device.cpp: three scheduler ranks -- here all on the one GPU of the box -- views sharded
     round-robin, state resident on the device, depth maps all-gathered after every pass, planes and weak maps before the
