@@ -1,3 +1,5 @@
+#!/bin/bash
+# End-to-end part of round_final.sh alone (drop-in tests, e2e_timing, 24 and 152 views, bench.py under torchrun with one nccl rank): gpurun_out/final2/.
 mkdir -p gpurun_out/final2; cd /root/repo
 timeout 600 python -m pytest -m gpu -x -q tests/test_gpu_dropin_binary.py > gpurun_out/final2/pytest.log 2>&1; grep -E "passed|failed" gpurun_out/final2/pytest.log | tail -2
 timeout 600 tools/e2e_timing.sh both > gpurun_out/final2/e2e_timing.txt 2>&1

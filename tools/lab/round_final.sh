@@ -1,4 +1,6 @@
-# final measurement set of a round on one box: full GPU suite, counter profiles + bench lines, e2e
+#!/bin/bash
+# The measurement set a round ends with, one gpurun call: full GPU suite, counter profiles + bench lines (tools/profile_round.sh), e2e.
+# Usage (from the repo root): gpurun --timeout 3600 -- 'bash tools/lab/round_final.sh'; results under gpurun_out/final/ (copy what is to be judged into profiles/rNN/).
 mkdir -p gpurun_out/final; cd /root/repo
 (time timeout 1500 python -m pytest tests -m gpu -x -q) > gpurun_out/final/pytest.log 2>&1; grep -E "passed|failed|error" gpurun_out/final/pytest.log | tail -3
 (time timeout 1500 bash tools/profile_round.sh gpurun_out/final/profile_round r04) > gpurun_out/final/profile_round.log 2>&1; tail -32 gpurun_out/final/profile_round.log | cut -c1-220
