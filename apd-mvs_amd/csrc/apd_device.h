@@ -197,14 +197,16 @@ __device__ __forceinline__ float recip_rn(float z, bool ok) { return __builtin_e
 __device__ __forceinline__ float recip_rn(float z) { return recip_rn(z, recip_fast_ok(z)); }
 
 // The two IEEE operations every NCC ends with (contract C1 / C4: sqrtf correctly rounded, `/` an IEEE division), without the
-// range scaling the compiler's general sequences carry (25 instead of 38 instructions per NCC epilogue; K9/K10 runs nine of them
+// range scaling the compiler's general sequences carry (27 instead of 38 instructions per NCC epilogue; K9/K10 runs nine of them
 // per NCCNew on two waves per SIMD, where every instruction of the chain costs its full latency):
 //   sqrt_rn_mid(x)   = v_sqrt_f32 (<= 1 ulp) and the two one-ulp probes of the compiler's own sequence, whose range scaling only
 //                      matters below 2^-96; equal to sqrtf for every binary32 x with biased exponent 31..223 (all of them checked)
 //                      and for NaN;
-//   div_rn_mid(a, b) = q = a * y with y = RN(1 / b) (recip_fast), r = a - b q exactly (one fma), q + r y (one fma): the correctly
-//                      rounded quotient whenever y is the correctly rounded reciprocal and nothing over- or underflows
-//                      (Markstein 1990); 2^32 random pairs over the operand ranges of an NCC checked against `/`, zero included.
+//   div_rn_mid(a, b) = q0 = a * y with y = RN(1 / b) (recip_fast), then twice q <- q + (a - b q) y with the residual exact (fma): the
+//                      first step makes q a faithful rounding of a / b, and from a faithful q and the correctly rounded reciprocal
+//                      the second gives the correctly rounded quotient (Markstein 1990) as long as nothing over- or underflows --
+//                      the steps of the compiler's own sequence without its range scaling; 2^32 random pairs over the operand
+//                      ranges of an NCC checked against `/`, zero included.
 // tools/valu_rates.hip --check runs both comparisons on the device (tests/test_gpu_edge_cases.py::test_isa_contract_exhaustive).
 // Callers guarantee the ranges: x = var_ref * var_src with both in [1e-5, 1.7e4], b = sqrt of that, |a| <= 6.6e4.
 __device__ __forceinline__ float sqrt_rn_mid(float x)
@@ -224,9 +226,9 @@ __device__ __forceinline__ float sqrt_rn_mid(float x)
 __device__ __forceinline__ float div_rn_mid(float a, float b)
 {
     const float y = recip_fast(b);
-    const float q = a * y;
-    const float r = fmaf(-b, q, a);
-    return fmaf(r, y, q);
+    const float q0 = a * y;                      // within 1.5 ulp of a / b
+    const float q1 = fmaf(fmaf(-b, q0, a), y, q0);  // a faithful rounding of a / b (the residual is exact)
+    return fmaf(fmaf(-b, q1, a), y, q1);         // Markstein: faithful q1 and y = RN(1 / b) -> the correctly rounded quotient
 }
 
 // Tail of every NCC (APD.cu:585-613 and the sub-patch terms of :461-505): 1 - covariance / sqrt(var_ref * var_src), clamped to [0, 2].

@@ -127,9 +127,9 @@ __device__ __forceinline__ float sqrt_rn_mid(float x)
 __device__ __forceinline__ float div_rn_mid(float a, float b)
 {
     const float y = recip_newton(b);
-    const float q = a * y;
-    const float r = fmaf(-b, q, a);
-    return fmaf(r, y, q);
+    const float q0 = a * y;
+    const float q1 = fmaf(fmaf(-b, q0, a), y, q0);
+    return fmaf(fmaf(-b, q1, a), y, q1);
 }
 
 // every positive binary32 with biased exponent 31..223 ([0] mismatches against sqrtf) and every NaN ([1] results that are not NaN)
