@@ -575,9 +575,7 @@ def main():
         return 3
     dist = None
     if distributed:
-        if world > 1:
-            os.environ.setdefault("NCCL_DEBUG", "WARN")   # RCCL's own warnings reach the driver's log
-        dist = init_distributed(args, torch, local_rank)
+        dist = init_distributed(args, torch, local_rank)   # NCCL_DEBUG stays as the caller set it: RCCL logs to STDOUT, which is one JSON line here
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if distributed else 0)
