@@ -91,6 +91,9 @@ def lib():
     L.apd_reset.argtypes = [H, C.POINTER(Params)]
     L.apd_upload_views.argtypes = [H, C.c_int, C.POINTER(Camera), fpp, fpp]
     L.apd_upload_views_split.argtypes = [H, C.c_int, C.POINTER(Camera), fpp]
+    L.apd_image_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.apd_image_destroy.argtypes = [C.c_void_p]
+    L.apd_upload_views_shared.argtypes = [H, C.c_int, C.POINTER(Camera), fpp]
     L.apd_upload_depths.argtypes = [H, C.c_int, fpp]
     L.apd_run_before_depths.argtypes = [H]
     L.apd_run_after_depths.argtypes = [H]
@@ -171,6 +174,28 @@ _STATE_DTYPES = {
 }
 
 
+class SharedImage:
+    """apd_image_create: one W x H float image (numpy or torch, host or device) on the device, tested and packed once."""
+
+    def __init__(self, width, height, pixels, device=0):
+        if hasattr(pixels, "data_ptr"):
+            import torch
+            pixels = pixels.to(torch.float32).contiguous()
+            assert pixels.numel() == width * height
+        else:
+            pixels = np.ascontiguousarray(pixels, np.float32)
+            assert pixels.size == width * height
+        self._keep = pixels
+        p = C.c_void_p()
+        _check(lib().apd_image_create(C.byref(p), device, width, height, _ptr(pixels)))
+        self.ptr = p.value
+
+    def close(self):
+        if self.ptr:
+            lib().apd_image_destroy(self.ptr)
+            self.ptr = None
+
+
 class Handle:
     """One (reference view, pass): the C-ABI equivalent of the reference's `APD` object (APD.h:67-145)."""
 
@@ -231,6 +256,16 @@ class Handle:
         cam_arr = (Camera * n)(*cameras)
         ip = (C.c_void_p * n)(*[_ptr(a) for a in imgs])
         _check(lib().apd_upload_views_split(self._h, n, cam_arr, ip))
+        self.params.num_images = n
+
+    def upload_views_shared(self, cameras, images):
+        """apd_upload_views_shared: `images` are SharedImage objects (created once, used by any number of handles); in a geometric
+        pass the depth maps follow with upload_depths."""
+        n = len(cameras)
+        self._keep = [list(images), None]
+        cam_arr = (Camera * n)(*cameras)
+        ip = (C.c_void_p * n)(*[im.ptr for im in images])
+        _check(lib().apd_upload_views_shared(self._h, n, cam_arr, ip))
         self.params.num_images = n
 
     def upload_depths(self, depths):

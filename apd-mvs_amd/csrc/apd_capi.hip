@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -65,7 +66,8 @@ struct apd_context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // device memory
-    std::vector<float *> images;
+    std::vector<float *> images;   // the handle's own copies (apd_upload_views); views of shared images (apd_upload_views_shared) are not kept here
+    const float *ref_img = nullptr;  // reference image the kernels read: images[0] or a shared image's
     std::vector<float *> depths;
     std::vector<apd::quad_t *> quads;
     std::vector<apd::quad_t *> quads_tiled;  // second copy in 8 x 4 tiles (FIRST_INIT passes: random first iteration)
@@ -209,7 +211,7 @@ static void refresh_frame_args(apd_context *c)
     fa.k3_shift_range = shift < 1 ? 1 : shift;
     fa.k3_dist_cut = 0.0f;
     fa.k3_cut_valid = ransac_distance_cut(p.depth_max - p.depth_min, p.ransac_threshold, &fa.k3_dist_cut) ? 1 : 0;
-    fa.ref_img = c->images.empty() ? nullptr : c->images[0];
+    fa.ref_img = c->ref_img;
     fa.views = c->views_dev;
     fa.planes = c->planes;
     fa.fit_planes = c->fit_planes;
@@ -448,6 +450,52 @@ int apd_set_stream(apd_handle c, void *hip_stream)
     return APD_OK;
 }
 
+// Cameras, per-view constants and the image pointers the kernels read (own copies or shared images): the end of every upload.
+static int finish_upload(apd_context *c, int num_images, const apd_camera *cameras, const float *const *img, const apd::quad_t *const *quad,
+                         const apd::quad_t *const *tiled, const apd::fquad_t *const *fquad, bool want_depths, bool defer_depths)
+{
+    c->num_images = num_images;
+    c->params.num_images = num_images;
+    c->ref_img = img[0];
+    const apd_camera &ref = cameras[0];
+    FrameArgs &fa = c->fa;
+    memcpy(fa.K, ref.K, sizeof(fa.K));
+    memcpy(fa.R, ref.R, sizeof(fa.R));
+    memcpy(fa.t, ref.t, sizeof(fa.t));
+    memcpy(fa.c, ref.c, sizeof(fa.c));
+    fa.ifx = 1.0f / ref.K[0];
+    fa.ify = 1.0f / ref.K[4];
+    std::vector<ViewConst> vcs(num_images - 1);
+    for (int v = 0; v < num_images - 1; ++v) {
+        const apd_camera &src = cameras[v + 1];
+        ViewConst &vc = vcs[v];
+        memset(&vc, 0, sizeof(vc));
+        relative_pose(ref, src, vc.Rr, vc.tr);
+        vc.k0 = src.K[0];
+        vc.k2 = src.K[2];
+        vc.k4 = src.K[4];
+        vc.k5 = src.K[5];
+        vc.k8 = src.K[8];
+        vc.wf = (float)src.width;
+        vc.hf = (float)src.height;
+        memcpy(vc.K, src.K, sizeof(vc.K));
+        memcpy(vc.R, src.R, sizeof(vc.R));
+        memcpy(vc.t, src.t, sizeof(vc.t));
+        memcpy(vc.c, src.c, sizeof(vc.c));
+        vc.img = img[v + 1];
+        vc.depth = want_depths ? c->depths[v + 1] : nullptr;
+        vc.quad = quad[v + 1];
+        vc.quad_tiled = tiled[v + 1];
+        vc.fquad = fquad[v + 1];
+    }
+    HIP_TRY(hipMemcpyAsync(c->views_dev, vcs.data(), vcs.size() * sizeof(ViewConst), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->views_uploaded = true;
+    c->depths_pending = defer_depths;
+    refresh_frame_args(c);
+    return APD_OK;
+}
+
 // Image / camera upload shared by apd_upload_views and apd_upload_views_split.  defer_depths: a geometric pass whose depth
 // maps arrive later (apd_upload_depths): their buffers are allocated here, so that the per-view constants can point at them.
 static int upload_views_impl(apd_context *c, int num_images, const apd_camera *cameras, const float *const *images, const float *const *depths,
@@ -546,45 +594,16 @@ static int upload_views_impl(apd_context *c, int num_images, const apd_camera *c
     } else {
         c->have_tiled = false;
     }
-    c->num_images = num_images;
-    c->params.num_images = num_images;
-    const apd_camera &ref = cameras[0];
-    FrameArgs &fa = c->fa;
-    memcpy(fa.K, ref.K, sizeof(fa.K));
-    memcpy(fa.R, ref.R, sizeof(fa.R));
-    memcpy(fa.t, ref.t, sizeof(fa.t));
-    memcpy(fa.c, ref.c, sizeof(fa.c));
-    fa.ifx = 1.0f / ref.K[0];
-    fa.ify = 1.0f / ref.K[4];
-    std::vector<ViewConst> vcs(num_images - 1);
-    for (int v = 0; v < num_images - 1; ++v) {
-        const apd_camera &src = cameras[v + 1];
-        ViewConst &vc = vcs[v];
-        memset(&vc, 0, sizeof(vc));
-        relative_pose(ref, src, vc.Rr, vc.tr);
-        vc.k0 = src.K[0];
-        vc.k2 = src.K[2];
-        vc.k4 = src.K[4];
-        vc.k5 = src.K[5];
-        vc.k8 = src.K[8];
-        vc.wf = (float)src.width;
-        vc.hf = (float)src.height;
-        memcpy(vc.K, src.K, sizeof(vc.K));
-        memcpy(vc.R, src.R, sizeof(vc.R));
-        memcpy(vc.t, src.t, sizeof(vc.t));
-        memcpy(vc.c, src.c, sizeof(vc.c));
-        vc.img = c->images[v + 1];
-        vc.depth = want_depths ? c->depths[v + 1] : nullptr;
-        vc.quad = c->use_quads ? c->quads[v + 1] : nullptr;
-        vc.quad_tiled = c->have_tiled ? c->quads_tiled[v + 1] : nullptr;
-        vc.fquad = c->use_quads ? nullptr : c->fquads[v + 1];
+    std::vector<const float *> img(num_images);
+    std::vector<const apd::quad_t *> quad(num_images, nullptr), tiled(num_images, nullptr);
+    std::vector<const apd::fquad_t *> fquad(num_images, nullptr);
+    for (int i = 0; i < num_images; ++i) {
+        img[i] = c->images[i];
+        quad[i] = c->use_quads ? c->quads[i] : nullptr;
+        tiled[i] = c->have_tiled ? c->quads_tiled[i] : nullptr;
+        fquad[i] = c->use_quads ? nullptr : c->fquads[i];
     }
-    HIP_TRY(hipMemcpyAsync(c->views_dev, vcs.data(), vcs.size() * sizeof(ViewConst), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->views_uploaded = true;
-    c->depths_pending = defer_depths;
-    refresh_frame_args(c);
-    return APD_OK;
+    return finish_upload(c, num_images, cameras, img.data(), quad.data(), tiled.data(), fquad.data(), want_depths, defer_depths);
 }
 
 static int check_upload_args(apd_context *c, int num_images, const apd_camera *cameras, const float *const *images, const char *who)
@@ -617,6 +636,160 @@ int apd_upload_views_split(apd_handle c, int num_images, const apd_camera *camer
         return rc;
     }
     return upload_views_impl(c, num_images, cameras, images, nullptr, c->params.geom_consistency != 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared images: a level image of a view is the reference image of one (view, pass) and a source of ten others, pass after pass.
+// apd_upload_views copies every image into the handle and packs the sources again each time (8 MB + a pack kernel + a range
+// check per image and (view, pass) at 1920 x 1080); a scheduler that keeps the level images on the device creates each of them
+// ONCE here -- float plane, 8-bit test, 2-byte column pairs or float texel quads, the tiled copy on first demand -- and hands
+// the handles pointers.  Read-only once created; the lazy copies are made under the image's mutex and finished before it is
+// released.
+// ---------------------------------------------------------------------------------------------
+struct apd_image {
+    int device = 0, W = 0, H = 0;
+    float *img = nullptr;
+    apd::quad_t *pairs = nullptr, *tiled = nullptr;
+    apd::fquad_t *fquads = nullptr;
+    bool is_u8 = false;
+    std::mutex m;
+};
+
+static int image_ensure(apd_image *im, int what /* 0 pairs, 1 tiled, 2 float quads */, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(im->m);
+    hipError_t e = hipSuccess;
+    if (what == 0 && !im->pairs) {
+        HIP_TRY(hipMalloc(&im->pairs, apd::quad_image_bytes(im->W, im->H)));
+        e = apd::launch_pack_quads(im->img, im->W, im->H, im->pairs, s);
+    } else if (what == 1 && !im->tiled) {
+        HIP_TRY(hipMalloc(&im->tiled, apd::quad_tiled_bytes(im->W, im->H)));
+        e = apd::launch_pack_quads_tiled(im->img, im->W, im->H, im->tiled, s);
+    } else if (what == 2 && !im->fquads) {
+        HIP_TRY(hipMalloc(&im->fquads, (size_t)(im->W + 1) * (im->H + 1) * sizeof(apd::fquad_t)));
+        e = apd::launch_pack_fquads(im->img, im->W, im->H, im->fquads, s);
+    } else {
+        return APD_OK;
+    }
+    if (e != hipSuccess) {
+        return fail(APD_ERR_HIP, "packing a shared image failed: %s", hipGetErrorString(e));
+    }
+    HIP_TRY(hipStreamSynchronize(s));  // other handles may read the copy as soon as the mutex is free
+    return APD_OK;
+}
+
+int apd_image_create(apd_image_t *out, int device, int width, int height, const float *pixels)
+{
+    if (!out || !pixels || width <= 0 || height <= 0 || width > 16384 || height > 16384) {
+        return fail(APD_ERR_INVALID, "apd_image_create: bad argument");
+    }
+    if (device >= 0) {
+        HIP_TRY(hipSetDevice(device));
+    }
+    apd_image *im = new apd_image();
+    *out = nullptr;
+    hipGetDevice(&im->device);
+    im->W = width;
+    im->H = height;
+    const size_t n = (size_t)width * height;
+    int *flag = nullptr;
+    int all_u8 = 1;
+    hipError_t e = hipMalloc(&im->img, n * sizeof(float));
+    e = e != hipSuccess ? e : hipMemcpy(im->img, pixels, n * sizeof(float), hipMemcpyDefault);
+    e = e != hipSuccess ? e : hipMalloc(&flag, sizeof(int));
+    e = e != hipSuccess ? e : hipMemcpy(flag, &all_u8, sizeof(int), hipMemcpyHostToDevice);
+    e = e != hipSuccess ? e : apd::launch_check_u8(im->img, (int)n, flag, nullptr);
+    e = e != hipSuccess ? e : hipMemcpy(&all_u8, flag, sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(flag);
+    if (e != hipSuccess) {
+        apd_image_destroy(im);
+        return fail(APD_ERR_HIP, "apd_image_create: %s", hipGetErrorString(e));
+    }
+    im->is_u8 = all_u8 != 0;
+    const int rc = image_ensure(im, im->is_u8 ? 0 : 2, nullptr);
+    if (rc != APD_OK) {
+        apd_image_destroy(im);
+        return rc;
+    }
+    *out = im;
+    return APD_OK;
+}
+
+const float *apd_image_pixels(apd_image_t im) { return im ? im->img : nullptr; }
+
+int apd_image_destroy(apd_image_t im)
+{
+    if (!im) {
+        return APD_OK;
+    }
+    hipSetDevice(im->device);
+    hipFree(im->img);
+    hipFree(im->pairs);
+    hipFree(im->tiled);
+    hipFree(im->fquads);
+    delete im;
+    return APD_OK;
+}
+
+int apd_upload_views_shared(apd_handle c, int num_images, const apd_camera *cameras, const apd_image_t *images)
+{
+    if (!c || !cameras || !images || num_images < 2) {
+        return fail(APD_ERR_INVALID, "apd_upload_views_shared: bad argument");
+    }
+    if (num_images > APD_MAX_IMAGES) {
+        return fail(APD_ERR_TOO_MANY, "Can't process so much images: %d", num_images);  // APD.cpp:428-431
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    bool all_u8 = true;
+    for (int i = 0; i < num_images; ++i) {
+        if (!images[i] || images[i]->W != c->W || images[i]->H != c->H || images[i]->device != c->device) {
+            return fail(APD_ERR_INVALID, "apd_upload_views_shared: image %d is missing, of another size or on another device than the handle", i);
+        }
+        if (cameras[i].width != c->W || cameras[i].height != c->H) {
+            return fail(APD_ERR_INVALID, "apd_upload_views_shared: camera %d is %dx%d, handle is %dx%d", i, cameras[i].width, cameras[i].height, c->W, c->H);
+        }
+        all_u8 = all_u8 && images[i]->is_u8;
+    }
+    c->use_quads = all_u8 && c->options[APD_OPT_SOURCE_QUADS] != 0;
+    const int tiled_mode = c->options[APD_OPT_TILED_COPY];
+    c->have_tiled = c->use_quads && (tiled_mode == 2 || (tiled_mode == 1 && c->params.state == APD_FIRST_INIT));
+    const bool geom = c->params.geom_consistency != 0;
+    const size_t n = (size_t)c->W * c->H;
+    if (geom) {  // the depth maps follow with apd_upload_depths: their buffers are the handle's own
+        if (c->depths.size() < (size_t)num_images) {
+            c->depths.resize((size_t)num_images, nullptr);
+        }
+        for (int i = 0; i < num_images; ++i) {
+            if (!c->depths[i]) {
+                HIP_TRY(hipMalloc(&c->depths[i], n * sizeof(float)));
+            }
+        }
+    }
+    std::vector<const float *> img(num_images);
+    std::vector<const apd::quad_t *> quad(num_images, nullptr), tiled(num_images, nullptr);
+    std::vector<const apd::fquad_t *> fquad(num_images, nullptr);
+    for (int i = 0; i < num_images; ++i) {
+        img[i] = images[i]->img;
+        if (i == 0) {
+            continue;
+        }
+        int rc = APD_OK;
+        if (c->use_quads) {
+            rc = image_ensure(images[i], 0, c->stream);
+            quad[i] = images[i]->pairs;
+            if (rc == APD_OK && c->have_tiled) {
+                rc = image_ensure(images[i], 1, c->stream);
+                tiled[i] = images[i]->tiled;
+            }
+        } else {
+            rc = image_ensure(images[i], 2, c->stream);
+            fquad[i] = images[i]->fquads;
+        }
+        if (rc != APD_OK) {
+            return rc;
+        }
+    }
+    return finish_upload(c, num_images, cameras, img.data(), quad.data(), tiled.data(), fquad.data(), geom, geom);
 }
 
 int apd_upload_depths(apd_handle c, int num_images, const float *const *depths)

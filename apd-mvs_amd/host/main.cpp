@@ -69,6 +69,8 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.late_fusion_inputs = true;
         } else if (a == "--clean-exit") {
             o.clean_exit = true;
+        } else if (a == "--copy-images") {
+            o.copy_images = true;
         } else if (a == "--jacobi") {
             o.jacobi = true;
         } else if (a == "--in-memory") {
@@ -230,7 +232,7 @@ int main(int argc, char **argv)
     const auto t_start = std::chrono::steady_clock::now();
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
-        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl] [--late-fusion-inputs] [--clean-exit]\n");
+        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl] [--late-fusion-inputs] [--copy-images] [--clean-exit]\n");
         return EXIT_FAILURE;
     }
     if (opt.devices.empty()) {

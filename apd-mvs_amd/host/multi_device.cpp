@@ -106,7 +106,7 @@ struct Rank {
     std::vector<int> own;                // view indices, ascending
     std::vector<Lane> lanes;
     std::vector<char> needs;             // image i is the reference or a source of one of this rank's views
-    std::vector<DeviceBuffer> images;    // level image of every needed view
+    std::vector<apd_image_t> images;     // level image of every needed view, shared by the rank's handles (apd_image_create: uploaded, tested, packed once)
     DeviceBuffer send, recv;             // depth blocks of the all-gather (float): this pass's own maps / every view's of the pass before
     DeviceBuffer zero_depth;             // a source-only view has no estimate
     std::unordered_map<int, ResidentView> state;
@@ -290,12 +290,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                     k.needs[index_of_id.at(s)] = 1;
                 }
             }
-            k.images.resize(N);
-            for (int i = 0; i < N; ++i) {
-                if (k.needs[i]) {
-                    k.images[i].alloc(k.device, pix0 * sizeof(float));
-                }
-            }
+            k.images.assign(N, nullptr);
             k.send.alloc(k.device, (size_t)slots * pix0 * sizeof(float));
             k.recv.alloc(k.device, (size_t)G * slots * pix0 * sizeof(float));
             k.zero_depth.alloc(k.device, pix0 * sizeof(float));
@@ -379,7 +374,9 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                         Rank &k = ranks[r];
                         for (int i = 0; i < N; ++i) {
                             if (k.needs[i]) {
-                                Check(apd_device_memcpy(k.device, k.images[i].p, level[i].ptr<float>(), level_bytes), "image upload");
+                                apd_image_destroy(k.images[i]);  // the level before
+                                k.images[i] = nullptr;
+                                Check(apd_image_create(&k.images[i], k.device, LW, LH, level[i].ptr<float>()), "apd_image_create");
                             }
                         }
                     } catch (const std::exception &e) {
@@ -438,12 +435,20 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             void *stream = nullptr;
             Check(apd_get_stream(lane.handle, &stream), "apd_get_stream");
             std::vector<Camera> vc;
-            std::vector<const float *> img;
+            std::vector<apd_image_t> img;
             for (int j : order) {
                 vc.push_back(cams[j]);
-                img.push_back(k.images[j].as<float>());
+                img.push_back(k.images[j]);
             }
-            Check(apd_upload_views_split(lane.handle, (int)order.size(), vc.data(), img.data()), "apd_upload_views_split");
+            if (opt.copy_images) {  // A/B: every handle copies, tests and packs its images itself
+                std::vector<const float *> raw;
+                for (apd_image_t im : img) {
+                    raw.push_back(apd_image_pixels(im));
+                }
+                Check(apd_upload_views_split(lane.handle, (int)order.size(), vc.data(), raw.data()), "apd_upload_views_split");
+            } else {
+                Check(apd_upload_views_shared(lane.handle, (int)order.size(), vc.data(), img.data()), "apd_upload_views_shared");
+            }
             ResidentView &s = k.state[v];
             if (pass.state != FIRST_INIT) {  // prior state of the previous pass (APD.cpp:552-581), resampled if the level changed
                 if (!s.valid) {
@@ -698,8 +703,9 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                     l.scratch_weak.release();
                     l.scratch_views.release();
                 }
-                for (DeviceBuffer &b : k.images) {
-                    b.release();
+                for (apd_image_t &im : k.images) {
+                    apd_image_destroy(im);
+                    im = nullptr;
                 }
                 k.send.release();
                 k.recv.release();

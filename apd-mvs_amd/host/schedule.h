@@ -25,6 +25,7 @@ struct Options {
     int iters = 3;          // PatchMatchParams::max_iterations of every pass (reference: 3)
     int max_src = 0;        // > 0: keep only the first N sources of each pair.txt entry (they are sorted by score)
     bool single_level = false, keep_maps = false, no_fusion = false;
+    bool copy_images = false;         // --copy-images: handles copy and pack their images per (view, pass) instead of sharing the level images (A/B)
     bool clean_exit = false;          // --clean-exit: return from main() instead of _Exit (exit handlers run: profilers)
     bool late_fusion_inputs = false;  // --late-fusion-inputs: colour decode + upload after the passes instead of behind them (A/B measurements)
 };

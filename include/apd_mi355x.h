@@ -155,6 +155,19 @@ int apd_upload_depths(apd_handle h, int num_images, const float *const *depths);
 int apd_run_before_depths(apd_handle h);
 int apd_run_after_depths(apd_handle h);
 
+/* Shared images.  A pyramid-level image of a view is the reference image of one (view, pass) and a source of ten others, pass after
+ * pass; apd_upload_views copies it into the handle, tests it for 8-bit content and packs it again every time.  A scheduler that
+ * keeps the level images on the device creates each one ONCE (pixels: width x height floats, host or device; the float plane, the
+ * 8-bit test, the packed copy the kernels gather from -- further copies on first demand) and uploads views by reference:
+ * apd_upload_views_shared == apd_upload_views_split without the copies (images[0] the reference view; every image of the handle's
+ * size and on its device; in a geometric pass the depth maps follow with apd_upload_depths).  An image may serve any number of
+ * handles on any threads at once and must outlive the passes that use it.  Same bits as the copying uploads. */
+typedef struct apd_image *apd_image_t;
+int apd_image_create(apd_image_t *out, int device, int width, int height, const float *pixels);
+int apd_image_destroy(apd_image_t image);
+const float *apd_image_pixels(apd_image_t image);   /* the float plane on the device (e.g. for a copying apd_upload_views of the same image) */
+int apd_upload_views_shared(apd_handle h, int num_images, const apd_camera *cameras, const apd_image_t *images);
+
 /* Prior state of a previous pass (APD.cpp:552-581, 643-661): planes = (world normal xyz, depth w),
  * selected-view bitmasks and weak map.  Any pointer may be NULL: planes/views zero, weak = all STRONG
  * (APD.cpp:541-547).  Builds the weak index map of APD.cpp:526-537. */

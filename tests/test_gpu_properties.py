@@ -265,3 +265,44 @@ def test_split_pass_around_the_depth_maps_changes_no_bit(gpu_pkg, ob, synth, use
     common.assert_state_equal(gpu_pkg, h, o, "split geometric pass, use_APD=%d" % use_apd)
     h.close()
     o.close()
+
+
+def test_shared_images_give_the_bits_of_copied_ones(gpu_pkg, ob, synth):
+    """apd_image_create + apd_upload_views_shared (level images created once on the device and handed to many handles by reference)
+    == apd_upload_views (every handle copies, tests and packs its images) == the oracle: a FIRST_INIT pass (tiled copies on demand), an
+    APD pass and a geometric pass, 8-bit and float images, two handles sharing the images at the same time."""
+    W, H, N = 96, 72, 4
+    for float_images in (False, True):
+        sc, imgs = common.scene_inputs(synth, W, H, N, seed=5, textureless=0.25)
+        if float_images:
+            imgs = [(im * np.float32(0.731) + np.float32(2.5)).astype(np.float32) for im in imgs]
+        cams = [gpu_pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+        shared = [gpu_pkg.SharedImage(W, H, im) for im in imgs]
+        depths = common.fake_depth_maps(W, H, N + 1)
+        passes = [dict(state=0, use_APD=0, weak_peak_radius=6), dict(state=1, use_APD=1, weak_peak_radius=6, rotate_time=2),
+                  dict(state=2, use_APD=1, weak_peak_radius=4, geom_consistency=1)]
+        prior = None
+        ha = gpu_pkg.Handle(W, H, gpu_pkg.default_params(**common.base_params(sc, N)))
+        hb = gpu_pkg.Handle(W, H, gpu_pkg.default_params(**common.base_params(sc, N)))
+        for pi, extra in enumerate(passes):
+            p = common.base_params(sc, N, seed=21 + pi, **extra)
+            o = common.make_oracle(ob, sc, imgs, N, p, depths=depths if extra.get("geom_consistency") else None, prior=prior)
+            o.run()
+            for h in (ha, hb):      # both handles read the same shared images, one after the other launching, both in flight
+                h.reset(gpu_pkg.default_params(**p))
+                h.upload_views_shared(cams, shared)
+                if prior is not None:
+                    h.upload_prior(*prior)
+                h.run_before_depths()
+            for h in (ha, hb):
+                if extra.get("geom_consistency"):
+                    h.upload_depths(depths)
+                h.run_after_depths()
+                common.assert_state_equal(gpu_pkg, h, o, "shared images, %s, pass %d" % ("float" if float_images else "8-bit", pi))
+            planes, weak, views = ha.download()
+            prior = common.postprocess(planes, weak, views, p["depth_min"], p["depth_max"])
+            o.close()
+        ha.close()
+        hb.close()
+        for im in shared:
+            im.close()

@@ -37,9 +37,11 @@ def run_case(case):
     # with several views in flight drives it
     recycle = bool(rng.rand() < 0.5)
     split = bool(rng.rand() < 0.5)
+    share = bool(split and rng.rand() < 0.5)   # images created once on the device (apd_image_create) and uploaded by reference
     label = "case %d: %dx%d N=%d textureless=%.2f iters=%d %s%s%s" % (case, W, H, N, tl, iters, "float" if float_images else "8-bit",
-                                                                    " recycled" if recycle else "", " split" if split else "")
+                                                                    " recycled" if recycle else "", (" shared" if share else " split") if split else "")
     cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
+    shared = [pkg.SharedImage(W, H, im) for im in imgs] if share else None
     h = None
     try:
         for pi, extra in enumerate(passes):
@@ -49,7 +51,9 @@ def run_case(case):
                 h = pkg.Handle(W, H, pkg.default_params(**p), device=0)
             else:
                 h.reset(pkg.default_params(**p))
-            if split:
+            if share:
+                h.upload_views_shared(cams, shared)
+            elif split:
                 h.upload_views_split(cams, imgs)
             else:
                 h.upload_views(cams, imgs, deps if geom else None)
@@ -77,6 +81,8 @@ def run_case(case):
     finally:
         if h is not None:
             h.close()
+        for im in shared or []:
+            im.close()
     return label
 
 
