@@ -159,16 +159,17 @@ int DefaultLanes(size_t pixels)
     return pixels <= ((size_t)1 << 20) ? 6 : (pixels <= ((size_t)4 << 20) ? 4 : (pixels <= ((size_t)12 << 20) ? 2 : 1));
 }
 
-// Device bytes an in-memory run keeps resident on its busiest device (rank 0 also fuses): level images, the two sets of
-// depth maps, every owned view's state, per lane the handle's own arrays (state 107 B/px, images + depth maps of the view
-// set, their packed copies -- float quads on the coarse levels) and scratch, and at the end the gathered final maps, their
-// depth / normal split and the fusion's buffers.  Upper bound per pixel of the finest level; main() compares it with the free
-// memory before choosing this scheduler and every in-memory mode checks it again here.
+// Device bytes an in-memory run keeps resident on its busiest device (rank 0 also fuses): the shared level images (float plane +
+// packed copies: 8.5 B/px each at the finest level), the two sets of depth maps, every owned view's state, per lane the
+// resampling scratch and a handle's own arrays (state 107 B/px, WEAK lists and neighbour table, the depth maps of a geometric
+// pass) -- and at the end the gathered final maps, their depth / normal split and the fusion's buffers.  Upper bound per pixel of
+// the finest level; main() compares it with the free memory before choosing this scheduler and every in-memory mode checks it
+// again here.
 double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources, double *passes_out, double *final_out)
 {
     const double slots = (double)((num_views + num_ranks - 1) / num_ranks);
     const double m = (double)max_sources;
-    const double passes = 4.0 * num_images + 4.0 * slots * (1.0 + num_ranks) + 4.0 + 21.0 * slots + lanes * (21.0 + 107.0 + 8.0 * (m + 1.0) + 20.5 * m);
+    const double passes = 8.5 * num_images + 4.0 * slots * (1.0 + num_ranks) + 4.0 + 21.0 * slots + lanes * (21.0 + 107.0 + 25.0 + 4.0 * (m + 1.0));
     const double final_stage = 21.0 * slots + (num_ranks > 1 ? 17.0 * slots * num_ranks : 0.0) + 16.0 * num_views + 21.0 * num_views + 8.0 * m + 40.0;
     if (passes_out) {
         *passes_out = passes;
