@@ -183,11 +183,12 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
     }
 
     // Two phases.  The classification below is WEAK whenever the lowest local minimum lies more than weak_peak_radius
-    // samples from the centre or costs more than 0.5 (:2120): if every sample within the radius costs more than 0.5, the
-    // pixel is WEAK wherever that minimum is, and the other samples are never needed.  Phase 0 therefore scores the
-    // chunks that cover [RADIUS - weak_peak_radius, RADIUS + weak_peak_radius] against every selected view; lanes that are
-    // WEAK by that argument write their result and drop out, and phase 1 scores the remaining chunks for the others
-    // (a wave of a textureless region ends after phase 0).  Every sample still adds its views in view order.
+    // samples from the centre or costs more than 0.5 (:2120).  So a pixel without a local minimum of at most 0.5 WITHIN the
+    // radius is WEAK whatever the other samples cost: either its lowest minimum lies outside the radius (or there is none:
+    // min_peak = 0), or it lies inside and costs more than 0.5.  Phase 0 therefore scores the chunks that cover
+    // [RADIUS - weak_peak_radius, RADIUS + weak_peak_radius] against every selected view; lanes that are WEAK by that
+    // argument write their result and drop out, and phase 1 scores the remaining chunks for the others (a wave of a
+    // textureless region ends after phase 0).  Every sample still adds its views in view order.
     const int wr = min(max(fa.weak_peak_radius, 0), RADIUS);
     const int centre_lo = ((RADIUS - wr) / APD_K14_CHUNK) * APD_K14_CHUNK;                        // first sample of the first centre chunk
     const int centre_hi = (APD_K14_CENTRE_FIRST && fa.early_out) ? ((RADIUS + wr) / APD_K14_CHUNK + 1) * APD_K14_CHUNK : 0;  // one past the last centre chunk
@@ -336,17 +337,34 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
             }
         }
         if (phase == 0) {
-            if (alive) {
-                bool all_high = true;
+            if (alive && wr < RADIUS) {
+                // Is there a sample within the radius that costs at most 0.5 and can still be a local minimum?  A neighbour that
+                // phase 0 has not scored (one step outside the centre chunks) counts as "may be higher".
+                bool candidate = false;
+                float below = 2.0f, here = 2.0f;
+                bool below_known = false;
+                const int first = max(RADIUS - wr - 1, centre_lo);
+                const int last = min(RADIUS + wr + 1, centre_hi - 1);
 #pragma unroll 1
-                for (int i = RADIUS - wr; i <= RADIUS + wr; ++i) {
-                    if ((in_range >> i) & 1ull) {
+                for (int i = first; i <= last + 1; ++i) {
+                    // `above` = clamped cost of sample i (:2093), `here` = i - 1, `below` = i - 2
+                    float above = 2.0f;
+                    const bool above_known = i <= last;
+                    if (above_known && ((in_range >> i) & 1ull)) {
                         const float p_cost = pc[i] / weight_normal;
-                        const float c = (2.0f > p_cost) ? p_cost : 2.0f;  // the clamp of :2093
-                        all_high = all_high && (c > 0.5f);
+                        above = (2.0f > p_cost) ? p_cost : 2.0f;
                     }
+                    const int j = i - 1;  // the sample under test
+                    if (j >= max(RADIUS - wr, 2) && j <= min(RADIUS + wr, NP - 3) && j >= first) {  // the peak search covers 2 .. NP - 3 (:2104)
+                        const bool lower_ok = !below_known || below > here;
+                        const bool upper_ok = !above_known || above > here;
+                        candidate = candidate || (lower_ok && upper_ok && !(here > 0.5f));
+                    }
+                    below = here;
+                    below_known = j >= first;
+                    here = above;
                 }
-                if (all_high) {
+                if (!candidate) {
                     fa.weak_info[center] = APD_WEAK;
                     alive = false;
                 }
