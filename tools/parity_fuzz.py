@@ -30,6 +30,9 @@ def run_case(case):
     passes = [dict(state=0, use_APD=0, weak_peak_radius=6),
               dict(state=1, use_APD=1, weak_peak_radius=6, rotate_time=2, ransac_threshold=0.01 - 0.00125),
               dict(state=2, use_APD=1, weak_peak_radius=4, rotate_time=4, ransac_threshold=0.01 - 0.0025, geom_consistency=1)]
+    if rng.rand() < 0.5:  # the schedule's other radii (main.cpp:176-186: 6, 4, 2, 2) and values no schedule uses (K14's peak test, its end samples)
+        for q in passes:
+            q["weak_peak_radius"] = int(rng.choice([2, 2, 2, 4, 0, 1, 3, 5, 12, 29, 30, 40]))
     prior = None
     # how the HIP side is driven (the oracle always runs the plain schedule): one handle per pass (the reference's object per
     # view and pass), or ONE handle recycled with apd_reset for all three passes; the whole pass in one call, or split around the
@@ -38,8 +41,9 @@ def run_case(case):
     recycle = bool(rng.rand() < 0.5)
     split = bool(rng.rand() < 0.5)
     share = bool(split and rng.rand() < 0.5)   # images created once on the device (apd_image_create) and uploaded by reference
-    label = "case %d: %dx%d N=%d textureless=%.2f iters=%d %s%s%s" % (case, W, H, N, tl, iters, "float" if float_images else "8-bit",
-                                                                    " recycled" if recycle else "", (" shared" if share else " split") if split else "")
+    label = "case %d: %dx%d N=%d textureless=%.2f iters=%d radii=%s %s%s%s" % (case, W, H, N, tl, iters, "/".join(str(q["weak_peak_radius"]) for q in passes),
+                                                                             "float" if float_images else "8-bit", " recycled" if recycle else "",
+                                                                             (" shared" if share else " split") if split else "")
     cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
     shared = [pkg.SharedImage(W, H, im) for im in imgs] if share else None
     h = None
