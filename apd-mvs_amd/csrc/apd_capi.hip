@@ -671,10 +671,13 @@ static int image_ensure(apd_image *im, int what /* 0 pairs, 1 tiled, 2 float qua
     } else {
         return APD_OK;
     }
-    if (e != hipSuccess) {
+    e = e != hipSuccess ? e : hipStreamSynchronize(s);  // other handles may read the copy as soon as the mutex is free
+    if (e != hipSuccess) {  // a copy that was not made must not look ready to the next caller
+        void **made = what == 0 ? (void **)&im->pairs : what == 1 ? (void **)&im->tiled : (void **)&im->fquads;
+        hipFree(*made);
+        *made = nullptr;
         return fail(APD_ERR_HIP, "packing a shared image failed: %s", hipGetErrorString(e));
     }
-    HIP_TRY(hipStreamSynchronize(s));  // other handles may read the copy as soon as the mutex is free
     return APD_OK;
 }
 
