@@ -13,9 +13,15 @@ all-gathered over RCCL after the timed region, as they would be before fusion.
 127.0.0.1) unless it is already running under a launcher (WORLD_SIZE set); it refuses to run when fewer than N devices are
 visible instead of quietly measuring fewer.
 
+The same line carries a `workloads` block: every other BASELINE.json config timed in this process after the headline (SUB_WORKLOADS:
+configs[1] at 6 and 3 iterations, configs[2] with adaptive patches and K9/K10's roofline, the configs[4] shape, 1080p frames, a
+pass of the sharded scheduler with its depth exchange inside the timed region) and whole `apd_run` passes (PASS_WORKLOADS: K1..K15
+with K14 / K15 against their own counter profile).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -157,7 +163,7 @@ class SweepWorkload:
 
     def __init__(self, ctx, name, max_iters, opts=(), seed=12345, views_per_gpu=1):
         pkg, torch, np = ctx.pkg, ctx.torch, ctx.np
-        self.ctx, self.name, self.opts, self.seed = ctx, name, list(opts), seed
+        self.ctx, self.name, self.opts, self.seed, self.max_iters = ctx, name, list(opts), seed, max_iters
         (self.W, self.H, self.N), self.apd_mode = resolve_workload(name)
         W, H, N = self.W, self.H, self.N
         t0 = time.perf_counter()
@@ -249,6 +255,8 @@ class SweepWorkload:
         gathered = None
         pass_allgather_ms = None
 
+        gc.collect()   # a collection of the interpreter inside a 40 ms region would be timed as this rank's work
+        gc.disable()
         ctx.barrier(hs)
         t0 = time.perf_counter()
         hs[0].run_sweeps(0, 1, sync=False)
@@ -278,6 +286,7 @@ class SweepWorkload:
         first_iter_s = t_first - t0
         elapsed, first_iter_s = ctx.max_over_ranks([elapsed, first_iter_s])
         rank_ms_per_step = ctx.gather_scalar(t_rank / steps * 1e3)
+        gc.enable()
         prof = hs[0].profile()
         for h in hs:
             h.profile_enable(False)
@@ -350,6 +359,68 @@ class SweepWorkload:
             "pass_allgather_ms": None if pass_allgather_ms is None else round(pass_allgather_ms, 3),
             "pass_allgather_inside_timed_region": bool(pass_exchange),
             "quality_within_1pct_depth": round(within, 4),
+            "setup_s": round(self.setup_s, 2),
+        }
+
+    def measure_whole_pass(self, passes, warmup):
+        """Times whole `apd_run` calls = APD::RunPatchMatch (APD.cu:2408-2470) on the first owned view: K1..K5, the three sweep
+        iterations, K11..K13, K14 (DepthToWeak) and K15 (LocalRefine) of a REFINE_INIT + APD pass -- the state the reference's
+        schedule runs at the full frame size (main.cpp:172-190).  The prior state is uploaded before every pass, outside the timed
+        region (the in-memory scheduler hands it over device to device)."""
+        ctx, pkg, torch = self.ctx, self.ctx.pkg, self.ctx.torch
+        assert self.apd_mode and self.max_iters == PASS_ITERATIONS and len(self.handles) == 1
+        W, H, N = self.W, self.H, self.N
+        h, prior = self.handles[0], self.priors[0]
+        for _ in range(warmup):
+            h.upload_prior(*prior)
+            h.run()
+        h.profile_enable(True)
+        h.profile_reset()
+        per_pass = []
+        gc.collect()
+        gc.disable()
+        ctx.barrier([h])
+        t_region = time.perf_counter()
+        t_run = 0.0
+        for _ in range(passes):
+            h.upload_prior(*prior)   # not timed
+            ctx.barrier([h])
+            t0 = time.perf_counter()
+            h.run()
+            h.synchronize()
+            torch.cuda.synchronize()
+            t_own = time.perf_counter() - t0
+            if ctx.distributed:
+                ctx.dist.barrier()
+            per_pass.append(ctx.max_over_ranks([time.perf_counter() - t0])[0])
+            t_run += t_own
+        region_s = time.perf_counter() - t_region
+        gc.enable()
+        prof = h.profile()
+        h.profile_enable(False)
+        elapsed = sum(per_pass)
+        rank_ms = ctx.gather_scalar(t_run / passes * 1e3)
+        kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0] / passes, 3) for k, v in sorted(prof.items())}
+        total_kernel = sum(kernel_ms.values())
+        mpix = W * H / 1e6
+        return {
+            "value": round(ctx.world * mpix * PASS_ITERATIONS * passes / elapsed, 4), "unit": "Mpix*iter/s",
+            "passes": passes, "warmup_passes": warmup, "iterations_per_pass": PASS_ITERATIONS,
+            "ms_per_pass": round(elapsed / passes * 1e3, 3), "timed_region_ms": round(elapsed * 1e3, 3),
+            "wall_with_prior_uploads_ms": round(region_s * 1e3, 1),
+            "Mpix_per_s_whole_pass": round(ctx.world * mpix * passes / elapsed, 3),
+            "config": {"workload": self.name, "width": W, "height": H, "num_src": N, "state": "REFINE_INIT+APD", "views_per_gpu": 1,
+                       "weak_fraction": round(self.weak_fraction, 4),
+                       "parallelism": "views sharded, %d rank(s)" % ctx.world, "backend": "nccl" if ctx.distributed else "single process",
+                       "options": self.opts,
+                       "timed_region": "apd_run = APD::RunPatchMatch (APD.cu:2408-2470): K1..K5, %d sweep iterations, K11..K13, K14, K15; "
+                                       "prior state uploaded before each pass, outside the region" % PASS_ITERATIONS},
+            "roofline": None,
+            "kernel_ms_per_pass": kernel_ms,
+            "share_of_kernel_time": {k: round(v / total_kernel, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])[:6]} if total_kernel > 0 else None,
+            "pass_kernels": {"K14": pass_kernel_roofline(pkg, prof, pkg.K14, "k14", self.name, passes, self.opts, self.seed),
+                             "K15": pass_kernel_roofline(pkg, prof, pkg.K15, "k15", self.name, passes, self.opts, self.seed)},
+            "rank_ms_per_pass": [round(v, 3) for v in rank_ms],
             "setup_s": round(self.setup_s, 2),
         }
 
@@ -500,6 +571,59 @@ SUB_WORKLOADS = [
 ]
 
 
+# Whole passes: (key, workload, passes, warm-up passes).  Measured right after the sweep sub-lines of the same workload, on the same
+# resident handle; K14 / K15 -- which the sweep metric never times and which are two fifths of an end-to-end run -- get the driver's
+# clock and a VALU-issue roofline from their own counter profile (tools/profile_bench.py, APD_PROFILE_PASS_KEY).
+PASS_ITERATIONS = 3   # PatchMatchParams::max_iterations of the reference (main.h:85)
+PASS_WORKLOADS = [
+    ("configs2_pipes_apd_whole_pass", "eth3d_pipes_fullres_10src_apd", 2, 1),
+]
+
+
+def pass_kernel_roofline(pkg, prof, kid, kernel_key, workload, passes, opts, seed):
+    """K14 / K15 inside a whole pass: live launch time (HIP events on the handle's stream) and, from the committed counter profile
+    of the same whole-pass command (profiles/rNN/pmc_pass_<workload>_p<passes>.json), VALU instructions and memory-side bytes per
+    launch.  Both kernels are vector-ALU issue bound: the fraction is taken against that peak."""
+    ms, n = prof.get(kid, (0.0, 0))
+    avg_ms = ms / max(n, 1)
+    out = {"bound": "valu-issue", "kernel": pkg.KERNEL_NAMES[kid], "avg_launch_ms": round(avg_ms, 3), "launches": n, "achieved": None,
+           "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwave-inst/s", "frac": None, "traffic": None, "hbm": None, "pmc_source": None}
+    pmc = load_pass_profile(workload, kernel_key, opts, seed)
+    if pmc is None or avg_ms <= 0:
+        out["pmc_note"] = "no committed whole-pass counter profile (pmc_pass_*.json) for workload=%s options=%s seed=%d" % (workload, list(opts), seed)
+        return out
+    achieved = pmc["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
+    hbm_gbps = pmc["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+    out.update({"achieved": round(achieved, 1), "frac": round(achieved / VALU_PEAK_GINST, 4), "traffic": pmc["hbm_bytes_per_launch"],
+                "valu_insts_per_launch": pmc["valu_insts_per_launch"],
+                "hbm": {"achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4),
+                        "bytes_per_launch": pmc["hbm_bytes_per_launch"], "note": "2 x FETCH_SIZE + WRITE_SIZE per launch"},
+                "pmc_source": pmc["source"], "pmc_launch_ms": pmc["launch_ms"], "pmc_launches": pmc["launches"]})
+    return out
+
+
+def load_pass_profile(workload, kernel_key, options=(), seed=12345):
+    """Newest profiles/rNN/pmc_pass_<workload>_p*.json (tools/profile_bench.py with APD_PROFILE_PASS_KEY): per-launch means of K14 /
+    K15 over the timed passes.  Every timed pass starts from the same prior and seed, so its launches are the same work."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_pass_*.json"))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        cfg = rec.get("config", {})
+        k = rec.get("kernels", {}).get(kernel_key)
+        if cfg.get("workload") != workload or list(cfg.get("options", [])) != list(options) or cfg.get("seed", 12345) != seed or not k:
+            continue
+        if k.get("valu_insts_per_launch") is None or k.get("hbm_bytes_per_launch") is None:
+            continue
+        best = {"valu_insts_per_launch": k["valu_insts_per_launch"], "hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
+                "launch_ms": k.get("launch_ms"), "launches": k.get("launches_timed"), "source": os.path.relpath(path, ROOT)}
+    return best
+
+
 class stdout_to_stderr:
     """RCCL prints a version banner on STDOUT when its first communicator is built ("RCCL version : ...", "Librccl path : ...").
     This program's stdout is ONE JSON line: file descriptor 1 points at stderr while the process group is set up."""
@@ -607,6 +731,13 @@ def main():
         line["n_gpus"] = world
         line["scaling"] = "weak"
         workloads[key] = line
+        for pkey, pname, passes, pwarm in PASS_WORKLOADS:
+            if pname == name and vpg == 1 and pkey not in workloads and w.max_iters == PASS_ITERATIONS and \
+                    (not args.only_workloads or pkey in args.only_workloads):
+                pline = w.measure_whole_pass(passes, pwarm)
+                pline["n_gpus"] = world
+                pline["scaling"] = "weak"
+                workloads[pkey] = pline
     for old in cache.values():
         old.close()
     cache.clear()

@@ -55,6 +55,13 @@ def test_sub_workload_table_names_every_baseline_config():
     assert bench.resolve_workload("eth3d_pipes_fullres_10src_apd")[1] is True and "eth3d_pipes_fullres_10src_apd" in by_wl
     assert (8, False) in by_wl["synthetic_4096x3072_16src"]
     assert any(exch for _, exch in by_wl["tt_family_1080p_10src"])
+    # whole passes (apd_run, K1..K15): measured on the resident handle of a sweep sub-line of the same workload at the reference's 3 iterations
+    assert bench.PASS_ITERATIONS == 3 and len(bench.PASS_WORKLOADS) >= 1
+    for key, name, passes, warm in bench.PASS_WORKLOADS:
+        assert key not in keys and passes >= 1 and warm >= 0
+        assert bench.resolve_workload(name)[1] is True   # the state the reference runs at the full frame size: REFINE_INIT + APD
+        assert any(steps == bench.PASS_ITERATIONS for steps, _ in by_wl[name])
+        assert max(steps for steps, _ in by_wl[name]) == bench.PASS_ITERATIONS   # the handle's max_iterations is the pass's
 
 
 def test_refuses_more_gpus_than_visible():

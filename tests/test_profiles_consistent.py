@@ -53,3 +53,21 @@ def test_profiles_of_other_options_or_seeds_are_never_borrowed():
     assert bench.load_pmc_profile("no_such_workload", 6, 1, "k67") is None
     got = bench.load_pmc_profile("eth3d_office_fullres_8src", 6, 1, "k67")
     assert got is not None and got["extrapolated_launches"] == 0 and got["valu_insts_per_launch"] > 1e9
+
+
+def test_whole_pass_profile_is_found_and_gives_fractions_below_one():
+    """K14 / K15 of bench.py's whole-pass sub-line: the committed pmc_pass_*.json of the workload, per-launch means over its timed
+    passes; with the launch time the profile itself recorded both fractions are fractions.  Nothing is borrowed across options / seeds."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for key, name, passes, _ in bench.PASS_WORKLOADS:
+        for kk in ("k14", "k15"):
+            got = bench.load_pass_profile(name, kk)
+            assert got is not None, (name, kk)
+            assert got["launches"] == passes and got["launch_ms"] > 0
+            t = got["launch_ms"] * 1e-3
+            assert 0.2 < got["valu_insts_per_launch"] / t / 1e9 / bench.VALU_PEAK_GINST < 1.0
+            assert 0.0 < got["hbm_bytes_per_launch"] / t / 1e9 / bench.HBM_PEAK_GBPS < 1.0
+        assert bench.load_pass_profile(name, "k14", options=["fast_rcp=1"]) is None
+        assert bench.load_pass_profile(name, "k14", seed=99) is None
+    assert bench.load_pass_profile("no_such_workload", "k14") is None

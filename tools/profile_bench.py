@@ -52,6 +52,10 @@ EXTRA_PASSES = {
             "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_INT32", "SQ_INST_LEVEL_LDS", "SQ_INST_LEVEL_VMEM"],
 }
 SWEEP_KERNELS = {"k67": "k67", "k910": "k910_update_weak"}
+# APD_PROFILE_PASS_KEY=<key of bench.PASS_WORKLOADS>: the whole-pass sub-line of that key instead of a sweep.  The command becomes
+# bench.py --steps 1 --warmup 0 --only-workloads <sweep key of the workload> --only-workloads <key>; K14 / K15 launch once per pass,
+# so the timed launches are the last `passes` dispatches of each; output pmc_pass_<workload>_p<passes>.json / .csv.
+PASS_KERNELS = {"k14": "k14w_depth_to_weak", "k15": "k15w_local_refine"}
 
 
 def flag(flags, name, default):
@@ -63,6 +67,18 @@ def main():
     steps, warmup = flag(flags, "--steps", 6), flag(flags, "--warmup", 1)
     workload = flag(flags, "--workload", "eth3d_office_fullres_8src")
     tag = "%s_s%d_w%d" % (workload, steps, warmup)
+    pass_key = os.environ.get("APD_PROFILE_PASS_KEY")
+    kernels_of_interest, tail = SWEEP_KERNELS, ["--no-cpu-baseline", "--no-workloads"]
+    n_timed = 2 * steps
+    if pass_key:
+        sys.path.insert(0, ROOT)
+        import bench
+        _, workload, n_timed, _ = [e for e in bench.PASS_WORKLOADS if e[0] == pass_key][0]
+        sweep_key = [e[0] for e in bench.SUB_WORKLOADS if e[1] == workload and e[5] == 1 and e[2] == bench.PASS_ITERATIONS][0]
+        flags = ["--steps", "1", "--warmup", "0"]   # the headline before the sub-lines: one iteration of the default workload
+        tail = ["--no-cpu-baseline", "--only-workloads", sweep_key, "--only-workloads", pass_key]
+        kernels_of_interest = PASS_KERNELS
+        tag = "%s_p%d" % (workload, n_timed)
     os.makedirs(out_dir, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     per_dispatch = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel key -> counter -> [values in launch order]
@@ -74,7 +90,7 @@ def main():
         raw = os.path.join("/tmp", "apd_prof_%s_%s" % (tag, name))
         subprocess.call(["rm", "-rf", raw])
         cmd = ["rocprofv3"] + prof_flags + ["--output-format", "csv", "-d", raw, "-o", name, "--", sys.executable,
-                                           os.path.join(ROOT, "bench.py")] + flags + ["--no-cpu-baseline", "--no-workloads"]
+                                           os.path.join(ROOT, "bench.py")] + flags + tail
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, timeout=300)  # a counter name rocprofv3 does not know can hang it
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
@@ -86,14 +102,14 @@ def main():
         for path in glob.glob(os.path.join(raw, "**", "*kernel_trace.csv"), recursive=True):
             rows = sorted(csv.DictReader(open(path)), key=lambda r_: int(r_["Start_Timestamp"]))
             for r_ in rows:
-                for key, sub in SWEEP_KERNELS.items():
+                for key, sub in kernels_of_interest.items():
                     if sub in r_["Kernel_Name"]:
                         per_dispatch[key]["duration_ns@" + name].append(float(r_["End_Timestamp"]) - float(r_["Start_Timestamp"]))
         for path in glob.glob(os.path.join(raw, "**", "*counter_collection.csv"), recursive=True):
             rows = list(csv.DictReader(open(path)))
             rows.sort(key=lambda r_: int(r_.get("Dispatch_Id", 0)))
             for r_ in rows:
-                for key, sub in SWEEP_KERNELS.items():
+                for key, sub in kernels_of_interest.items():
                     if sub in r_["Kernel_Name"]:
                         per_dispatch[key][r_["Counter_Name"]].append(float(r_["Counter_Value"]))
                         meta[key] = {"kernel_name": r_["Kernel_Name"], "grid": r_["Grid_Size"], "workgroup": r_["Workgroup_Size"],
@@ -112,8 +128,11 @@ def main():
            "method": "rocprofv3 --kernel-trace + one --pmc pass per counter group; timed launches = last 2*steps dispatches of the kernel; "
                      "FETCH_SIZE in KiB doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE in KiB as reported",
            "kernels": {}}
+    if pass_key:
+        out["config"].update({"pass_key": pass_key, "passes": n_timed, "steps": None, "warmup": None})
+        out["method"] = ("rocprofv3 --kernel-trace + one --pmc pass per counter group over bench.py's whole-pass sub-line; timed launches = the "
+                         "last `passes` dispatches of K14 / K15 (one launch per apd_run); FETCH_SIZE in KiB doubled, WRITE_SIZE in KiB as reported")
     for key, counters in per_dispatch.items():
-        n_timed = 2 * steps
         k = dict(meta.get(key, {}))
         k["launches_timed"] = n_timed
         k["per_dispatch_timed"] = {}
@@ -153,9 +172,10 @@ def main():
         for key, k in out["kernels"].items():
             print(key, json.dumps(k["mean_over_timed_launches"]))
         return 0
-    with open(os.path.join(out_dir, "pmc_bench_%s.json" % tag), "w") as f:
+    stem = "pmc_pass_%s" if pass_key else "pmc_bench_%s"
+    with open(os.path.join(out_dir, (stem + ".json") % tag), "w") as f:
         json.dump(out, f, indent=1)
-    with open(os.path.join(out_dir, "pmc_bench_%s.csv" % tag), "w", newline="") as f:
+    with open(os.path.join(out_dir, (stem + ".csv") % tag), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "counter", "timed_launch_index", "value"])
         w.writerows(rows_csv)

@@ -14,7 +14,9 @@ run_profile eth3d_office_fullres_8src 24
 run_profile eth3d_pipes_fullres_10src_apd 6
 run_profile synthetic_4096x3072_16src 8
 run_profile tt_family_1080p_10src 24
-mkdir -p profiles/$ROUND && cp "$OUT"/pmc_bench_*.json profiles/$ROUND/   # where they will be committed; bench.py looks under profiles/*/
+# whole passes (K14 / K15): the sub-lines of bench.PASS_WORKLOADS
+APD_PROFILE_PASS_KEY=configs2_pipes_apd_whole_pass timeout 1500 python tools/profile_bench.py "$OUT" > "$OUT/profile_whole_pass.log" 2>&1 || echo "whole-pass profile failed" >> "$OUT/errors.txt"
+mkdir -p profiles/$ROUND && cp "$OUT"/pmc_bench_*.json "$OUT"/pmc_pass_*.json profiles/$ROUND/   # where they will be committed; bench.py looks under profiles/*/
 # the two lines of the round: the default command and the driver's; each carries the `workloads` block (every BASELINE config)
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_driver_s20_w5.json" 2>/dev/null
@@ -29,6 +31,8 @@ d = json.loads(open(sys.argv[1]).readline())
 def show(tag, v):
     r = v.get("roofline") or {}
     print("%-46s %8.2f Mpix*iter/s  %-16s frac %-7s %s ms/launch  src %s" % (tag, v["value"], r.get("bound"), r.get("frac"), r.get("avg_launch_ms"), r.get("pmc_source")))
+    for kn, kr in sorted((v.get("pass_kernels") or {}).items()):
+        print("%-46s %8s %-16s frac %-7s %s ms/launch  src %s" % ("      " + kn, "", kr.get("bound"), kr.get("frac"), kr.get("avg_launch_ms"), kr.get("pmc_source")))
 show(sys.argv[1].split("/")[-1], d)
 for k, v in (d.get("workloads") or {}).items():
     show("  " + k, v)

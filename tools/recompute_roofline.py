@@ -120,6 +120,28 @@ def check_k910(tag, roof, k, problems, profiled_steps):
         achieved / TAG_PEAK, traffic / t / 1e9 / HBM, insts / t / 1e9 / PEAK, n, t * 1e3, mean("duration_ns@trace") * 1e-6)
 
 
+def check_pass_kernel(tag, roof, k, problems):
+    """K14 / K15 of a whole-pass sub-line: one launch per timed pass, every pass the same work."""
+    pd = k["per_dispatch_timed"]
+    mean = lambda c: sum(pd[c]) / len(pd[c])
+    insts = mean("SQ_INSTS_VALU")
+    traffic = mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024
+    t = roof["avg_launch_ms"] * 1e-3
+    achieved = insts / t / 1e9
+    for what, got, want, rel in (
+            ("valu_insts_per_launch", roof["valu_insts_per_launch"], insts, 1e-9),
+            ("achieved", roof["achieved"], achieved, 1e-3),
+            ("frac", roof["frac"], achieved / PEAK, 1e-3),
+            ("traffic", roof["traffic"], traffic, 1e-9),
+            ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
+            ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03)):
+        if not close(got, want, rel):
+            problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
+    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1:
+        problems.append("%s: a fraction above 1" % tag)
+    return "frac %.4f hbm %.4f (%.3f ms live, %.3f ms in the trace)" % (achieved / PEAK, traffic / t / 1e9 / HBM, t * 1e3, mean("duration_ns@trace") * 1e-6)
+
+
 def sub_lines(name, line):
     """The line itself and every sub-line of its `workloads` block (round 4: every BASELINE config in one process)."""
     yield name, line
@@ -138,6 +160,19 @@ def check(directory):
         except ValueError:
             continue
         for tag, line in sub_lines(os.path.basename(path), top):
+            for kname, kroof in sorted((line.get("pass_kernels") or {}).items()):   # whole-pass sub-lines: K14 / K15 against their own profile
+                if kroof.get("achieved") is None:
+                    continue
+                prof_path = os.path.join(ROOT, kroof.get("pmc_source") or "")
+                if not kroof.get("pmc_source") or not os.path.exists(prof_path):
+                    problems.append("%s %s: cites counters but %r is not committed" % (tag, kname, kroof.get("pmc_source")))
+                    continue
+                prof = json.load(open(prof_path))
+                if prof["config"]["workload"] != line["config"]["workload"] or list(prof["config"].get("options", [])) != list(line["config"].get("options", [])):
+                    problems.append("%s %s: profile %s is of another workload or other options" % (tag, kname, kroof["pmc_source"]))
+                    continue
+                lines += 1
+                print("%-36s %s  %s %s" % (tag, line["config"]["workload"], kname, check_pass_kernel(tag + " " + kname, kroof, prof["kernels"][kname.lower()], problems)))
             roof = line.get("roofline")
             if not roof or roof.get("achieved") is None:
                 continue
