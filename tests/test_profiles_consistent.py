@@ -71,3 +71,19 @@ def test_whole_pass_profile_is_found_and_gives_fractions_below_one():
         assert bench.load_pass_profile(name, "k14", options=["fast_rcp=1"]) is None
         assert bench.load_pass_profile(name, "k14", seed=99) is None
     assert bench.load_pass_profile("no_such_workload", "k14") is None
+
+
+def test_pass_kernel_roofline_without_a_profile_reports_null_fields():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Pkg:
+        K14 = 14
+        KERNEL_NAMES = {14: "DepthToWeak"}
+    live = {14: (600.0, 2)}   # two launches, 300 ms each
+    r = bench.pass_kernel_roofline(Pkg, live, Pkg.K14, "k14", "no_such_workload", 2, (), 12345)
+    assert r["avg_launch_ms"] == 300.0 and r["achieved"] is None and r["frac"] is None and r["traffic"] is None and "pmc_note" in r
+    name = bench.PASS_WORKLOADS[0][1]
+    r = bench.pass_kernel_roofline(Pkg, live, Pkg.K14, "k14", name, 2, (), 12345)
+    assert r["pmc_source"].startswith("profiles/") and 0.0 < r["frac"] < 1.0 and 0.0 < r["hbm"]["frac"] < 1.0
+    assert abs(r["achieved"] - r["valu_insts_per_launch"] / 0.3 / 1e9) < 0.1
