@@ -25,19 +25,20 @@ def _lookat_rotation(center, target):
 class Scene:
     """Cameras + images (+ reference ground-truth depth) of one reference view and its sources."""
 
-    def __init__(self, width, height, num_src, images, K, R, t, depth_min, depth_max, gt_depth):
+    def __init__(self, width, height, num_src, images, K, R, t, depth_min, depth_max, gt_depth, view_depths=None):
         self.width, self.height, self.num_src = width, height, num_src
         self.images = images  # list of float32 [H, W] torch tensors with integer grey values
         self.K, self.R, self.t = K, R, t  # lists of float32 numpy (9,), (9,), (3,)
         self.depth_min, self.depth_max = depth_min, depth_max
         self.gt_depth = gt_depth  # float32 [H, W] torch tensor (z-depth in the reference camera)
+        self.view_depths = view_depths  # with keep_view_depths: the same for EVERY view (what a converged geometric pass reads of its sources)
 
     def images_numpy(self):
         return [im.detach().cpu().numpy() for im in self.images]
 
 
 def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, baseline=0.06,
-               ref_view=0, device="cpu", noise=1.5):
+               ref_view=0, device="cpu", noise=1.5, keep_view_depths=False):
     """Render view `ref_view` of a ring of cameras as the reference and `num_src` neighbours.
 
     textureless: fraction (0..~0.4) of the surface covered by low-texture rectangles.
@@ -81,6 +82,7 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
     ys, xs = torch.meshgrid(torch.arange(height, device=dev, dtype=dt), torch.arange(width, device=dev, dtype=dt), indexing="ij")
     images, Ks, Rs, ts = [], [], [], []
     gt_depth = None
+    view_depths = [] if keep_view_depths else None
     for k in range(num_src + 1):
         Rm, c = rots[k], centers[k]
         Rt = torch.tensor(Rm.T, device=dev, dtype=dt)
@@ -98,6 +100,8 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
         P = [cc[i] + best_s * dw[i] for i in range(3)]
         if k == 0:
             gt_depth = best_s.to(torch.float32)  # camera-frame z: ray has z=1 in camera coordinates
+        if keep_view_depths:
+            view_depths.append(best_s.to(torch.float32))
         X, Y = P[0], P[1]
         tex = torch.zeros_like(X)
         for q in range(4):
@@ -120,4 +124,4 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
         Ks.append(K.astype(np.float32))
         Rs.append(Rm.reshape(9).astype(np.float32))
         ts.append((-Rm @ c).astype(np.float32))
-    return Scene(width, height, num_src, images, Ks, Rs, ts, 1.0, 4.0, gt_depth)
+    return Scene(width, height, num_src, images, Ks, Rs, ts, 1.0, 4.0, gt_depth, view_depths)

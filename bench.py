@@ -169,12 +169,17 @@ class SweepWorkload:
         t0 = time.perf_counter()
         self.handles, self.priors, self.gt = [], [], []
         self.weak_fraction = 0.0
+        self.pass_inputs, self.geom = None, None
         for slot in range(views_per_gpu):
             # every rank owns different reference views of the same camera ring (round-robin, as the schedulers shard them)
             view = ctx.rank + slot * ctx.world
-            sc = ctx.synth.make_scene(W, H, N, seed=0, ref_view=view, device=ctx.dev, textureless=0.2 if self.apd_mode else 0.0)
+            keep = views_per_gpu == 1 and any(e[1] == name and e[4] == "geometric" for e in PASS_WORKLOADS)   # a geometric whole pass follows
+            sc = ctx.synth.make_scene(W, H, N, seed=0, ref_view=view, device=ctx.dev, textureless=0.2 if self.apd_mode else 0.0,
+                                      keep_view_depths=keep)
             cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
             dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
+            if keep:
+                self.pass_inputs = {"cams": cams, "images": list(sc.images), "depths": list(sc.view_depths), "dmin": dmin, "dmax": dmax}
             prior = None
             if not self.apd_mode:
                 params = pkg.default_params(num_images=N + 1, depth_min=dmin, depth_max=dmax, use_APD=0,
@@ -229,8 +234,11 @@ class SweepWorkload:
     def close(self):
         for h in self.handles:
             h.close()
+        if self.geom is not None:
+            self.geom[0].close()
         self.handles = []
         self.priors = []
+        self.pass_inputs, self.geom = None, None
         self.ctx.torch.cuda.empty_cache()
 
     def measure(self, steps, warmup, pass_exchange=False):
@@ -362,15 +370,42 @@ class SweepWorkload:
             "setup_s": round(self.setup_s, 2),
         }
 
-    def measure_whole_pass(self, passes, warmup):
+    def geometric_handle(self):
+        """The pass that follows the photometric one at a level (main.cpp:191-213): REFINE_ITER + APD + geometric consistency,
+        weak_peak_radius 4.  Prior = the state one (untimed) photometric pass leaves, post-processed as ProcessProblem does
+        (main.cpp:105-115); depth maps of the sources = the analytic depth of every source view, i.e. what converged neighbours hold."""
+        if self.geom is None:
+            ctx, pkg, np = self.ctx, self.ctx.pkg, self.ctx.np
+            pi = self.pass_inputs
+            h = self.handles[0]
+            h.upload_prior(*self.priors[0])
+            h.run()
+            planes, weak, views = h.download()
+            bad = (planes[..., 3] < np.float32(pi["dmin"])) | (planes[..., 3] > np.float32(pi["dmax"]))
+            planes[..., 3][bad] = 0
+            weak[bad] = pkg.UNKNOWN
+            params = pkg.default_params(num_images=self.N + 1, depth_min=pi["dmin"], depth_max=pi["dmax"], use_APD=1, state=pkg.REFINE_ITER,
+                                        geom_consistency=1, max_iterations=PASS_ITERATIONS, weak_peak_radius=4, rotate_time=4,
+                                        ransac_threshold=0.01 - 0.00125 * 3, seed=self.seed + 2)
+            hg = pkg.Handle(self.W, self.H, params, device=ctx.dev.index)
+            apply_options(hg, self.opts)
+            hg.upload_views(pi["cams"], pi["images"], pi["depths"])
+            self.geom = (hg, (planes, views, weak), float((weak == pkg.WEAK).mean()))
+        return self.geom
+
+    def measure_whole_pass(self, passes, warmup, kind="photometric"):
         """Times whole `apd_run` calls = APD::RunPatchMatch (APD.cu:2408-2470) on the first owned view: K1..K5, the three sweep
-        iterations, K11..K13, K14 (DepthToWeak) and K15 (LocalRefine) of a REFINE_INIT + APD pass -- the state the reference's
-        schedule runs at the full frame size (main.cpp:172-190).  The prior state is uploaded before every pass, outside the timed
-        region (the in-memory scheduler hands it over device to device)."""
+        iterations, K11..K13, K14 (DepthToWeak) and K15 (LocalRefine) of a REFINE_INIT + APD pass (kind "photometric") or of the
+        REFINE_ITER + APD + geometric-consistency pass that follows it three times per level (kind "geometric") -- the states the
+        reference's schedule runs at the full frame size (main.cpp:172-213).  The prior state is uploaded before every pass, outside
+        the timed region (the in-memory scheduler hands it over device to device)."""
         ctx, pkg, torch = self.ctx, self.ctx.pkg, self.ctx.torch
         assert self.apd_mode and self.max_iters == PASS_ITERATIONS and len(self.handles) == 1
         W, H, N = self.W, self.H, self.N
-        h, prior = self.handles[0], self.priors[0]
+        if kind == "geometric":
+            h, prior, weak_fraction = self.geometric_handle()
+        else:
+            h, prior, weak_fraction = self.handles[0], self.priors[0], self.weak_fraction
         for _ in range(warmup):
             h.upload_prior(*prior)
             h.run()
@@ -409,8 +444,10 @@ class SweepWorkload:
             "ms_per_pass": round(elapsed / passes * 1e3, 3), "timed_region_ms": round(elapsed * 1e3, 3),
             "wall_with_prior_uploads_ms": round(region_s * 1e3, 1),
             "Mpix_per_s_whole_pass": round(ctx.world * mpix * passes / elapsed, 3),
-            "config": {"workload": self.name, "width": W, "height": H, "num_src": N, "state": "REFINE_INIT+APD", "views_per_gpu": 1,
-                       "weak_fraction": round(self.weak_fraction, 4),
+            "config": {"workload": self.name, "width": W, "height": H, "num_src": N,
+                       "state": "REFINE_ITER+APD+geom_consistency" if kind == "geometric" else "REFINE_INIT+APD", "views_per_gpu": 1,
+                       "weak_fraction": round(weak_fraction, 4),
+                       "source_depth_maps": "analytic depth of every source view (converged neighbours)" if kind == "geometric" else None,
                        "parallelism": "views sharded, %d rank(s)" % ctx.world, "backend": "nccl" if ctx.distributed else "single process",
                        "options": self.opts,
                        "timed_region": "apd_run = APD::RunPatchMatch (APD.cu:2408-2470): K1..K5, %d sweep iterations, K11..K13, K14, K15; "
@@ -418,8 +455,8 @@ class SweepWorkload:
             "roofline": None,
             "kernel_ms_per_pass": kernel_ms,
             "share_of_kernel_time": {k: round(v / total_kernel, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])[:6]} if total_kernel > 0 else None,
-            "pass_kernels": {"K14": pass_kernel_roofline(pkg, prof, pkg.K14, "k14", self.name, passes, self.opts, self.seed),
-                             "K15": pass_kernel_roofline(pkg, prof, pkg.K15, "k15", self.name, passes, self.opts, self.seed)},
+            "pass_kernels": {"K14": pass_kernel_roofline(pkg, prof, pkg.K14, "k14", self.name, kind, self.opts, self.seed),
+                             "K15": pass_kernel_roofline(pkg, prof, pkg.K15, "k15", self.name, kind, self.opts, self.seed)},
             "rank_ms_per_pass": [round(v, 3) for v in rank_ms],
             "setup_s": round(self.setup_s, 2),
         }
@@ -575,12 +612,13 @@ SUB_WORKLOADS = [
 # resident handle; K14 / K15 -- which the sweep metric never times and which are two fifths of an end-to-end run -- get the driver's
 # clock and a VALU-issue roofline from their own counter profile (tools/profile_bench.py, APD_PROFILE_PASS_KEY).
 PASS_ITERATIONS = 3   # PatchMatchParams::max_iterations of the reference (main.h:85)
-PASS_WORKLOADS = [
-    ("configs2_pipes_apd_whole_pass", "eth3d_pipes_fullres_10src_apd", 2, 1),
+PASS_WORKLOADS = [   # (key, workload, timed passes, warm-up passes, kind)
+    ("configs2_pipes_apd_whole_pass", "eth3d_pipes_fullres_10src_apd", 2, 1, "photometric"),
+    ("configs2_pipes_apd_geometric_pass", "eth3d_pipes_fullres_10src_apd", 2, 1, "geometric"),
 ]
 
 
-def pass_kernel_roofline(pkg, prof, kid, kernel_key, workload, passes, opts, seed):
+def pass_kernel_roofline(pkg, prof, kid, kernel_key, workload, kind, opts, seed):
     """K14 / K15 inside a whole pass: live launch time (HIP events on the handle's stream) and, from the committed counter profile
     of the same whole-pass command (profiles/rNN/pmc_pass_<workload>_p<passes>.json), VALU instructions and memory-side bytes per
     launch.  Both kernels are vector-ALU issue bound: the fraction is taken against that peak."""
@@ -588,9 +626,10 @@ def pass_kernel_roofline(pkg, prof, kid, kernel_key, workload, passes, opts, see
     avg_ms = ms / max(n, 1)
     out = {"bound": "valu-issue", "kernel": pkg.KERNEL_NAMES[kid], "avg_launch_ms": round(avg_ms, 3), "launches": n, "achieved": None,
            "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwave-inst/s", "frac": None, "traffic": None, "hbm": None, "pmc_source": None}
-    pmc = load_pass_profile(workload, kernel_key, opts, seed)
+    pmc = load_pass_profile(workload, kernel_key, opts, seed, kind)
     if pmc is None or avg_ms <= 0:
-        out["pmc_note"] = "no committed whole-pass counter profile (pmc_pass_*.json) for workload=%s options=%s seed=%d" % (workload, list(opts), seed)
+        out["pmc_note"] = "no committed whole-pass counter profile (pmc_pass_*.json) for workload=%s kind=%s options=%s seed=%d" % (
+            workload, kind, list(opts), seed)
         return out
     achieved = pmc["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
     hbm_gbps = pmc["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
@@ -602,7 +641,7 @@ def pass_kernel_roofline(pkg, prof, kid, kernel_key, workload, passes, opts, see
     return out
 
 
-def load_pass_profile(workload, kernel_key, options=(), seed=12345):
+def load_pass_profile(workload, kernel_key, options=(), seed=12345, kind="photometric"):
     """Newest profiles/rNN/pmc_pass_<workload>_p*.json (tools/profile_bench.py with APD_PROFILE_PASS_KEY): per-launch means of K14 /
     K15 over the timed passes.  Every timed pass starts from the same prior and seed, so its launches are the same work."""
     import glob
@@ -616,6 +655,8 @@ def load_pass_profile(workload, kernel_key, options=(), seed=12345):
         cfg = rec.get("config", {})
         k = rec.get("kernels", {}).get(kernel_key)
         if cfg.get("workload") != workload or list(cfg.get("options", [])) != list(options) or cfg.get("seed", 12345) != seed or not k:
+            continue
+        if cfg.get("pass_kind", "photometric") != kind:
             continue
         if k.get("valu_insts_per_launch") is None or k.get("hbm_bytes_per_launch") is None:
             continue
@@ -731,10 +772,10 @@ def main():
         line["n_gpus"] = world
         line["scaling"] = "weak"
         workloads[key] = line
-        for pkey, pname, passes, pwarm in PASS_WORKLOADS:
+        for pkey, pname, passes, pwarm, pkind in PASS_WORKLOADS:
             if pname == name and vpg == 1 and pkey not in workloads and w.max_iters == PASS_ITERATIONS and \
                     (not args.only_workloads or pkey in args.only_workloads):
-                pline = w.measure_whole_pass(passes, pwarm)
+                pline = w.measure_whole_pass(passes, pwarm, pkind)
                 pline["n_gpus"] = world
                 pline["scaling"] = "weak"
                 workloads[pkey] = pline

@@ -57,9 +57,10 @@ def test_sub_workload_table_names_every_baseline_config():
     assert any(exch for _, exch in by_wl["tt_family_1080p_10src"])
     # whole passes (apd_run, K1..K15): measured on the resident handle of a sweep sub-line of the same workload at the reference's 3 iterations
     assert bench.PASS_ITERATIONS == 3 and len(bench.PASS_WORKLOADS) >= 1
-    for key, name, passes, warm in bench.PASS_WORKLOADS:
+    assert {e[4] for e in bench.PASS_WORKLOADS} == {"photometric", "geometric"}   # both pass kinds of a level (main.cpp:172-213)
+    for key, name, passes, warm, kind in bench.PASS_WORKLOADS:
         assert key not in keys and passes >= 1 and warm >= 0
-        assert bench.resolve_workload(name)[1] is True   # the state the reference runs at the full frame size: REFINE_INIT + APD
+        assert bench.resolve_workload(name)[1] is True   # the states the reference runs at the full frame size: REFINE_INIT / REFINE_ITER + APD
         assert any(steps == bench.PASS_ITERATIONS for steps, _ in by_wl[name])
         assert max(steps for steps, _ in by_wl[name]) == bench.PASS_ITERATIONS   # the handle's max_iterations is the pass's
 

@@ -60,10 +60,10 @@ def test_whole_pass_profile_is_found_and_gives_fractions_below_one():
     passes; with the launch time the profile itself recorded both fractions are fractions.  Nothing is borrowed across options / seeds."""
     sys.path.insert(0, ROOT)
     import bench
-    for key, name, passes, _ in bench.PASS_WORKLOADS:
+    for key, name, passes, _, kind in bench.PASS_WORKLOADS:
         for kk in ("k14", "k15"):
-            got = bench.load_pass_profile(name, kk)
-            assert got is not None, (name, kk)
+            got = bench.load_pass_profile(name, kk, kind=kind)
+            assert got is not None, (name, kk, kind)
             assert got["launches"] == passes and got["launch_ms"] > 0
             t = got["launch_ms"] * 1e-3
             assert 0.2 < got["valu_insts_per_launch"] / t / 1e9 / bench.VALU_PEAK_GINST < 1.0
@@ -81,9 +81,9 @@ def test_pass_kernel_roofline_without_a_profile_reports_null_fields():
         K14 = 14
         KERNEL_NAMES = {14: "DepthToWeak"}
     live = {14: (600.0, 2)}   # two launches, 300 ms each
-    r = bench.pass_kernel_roofline(Pkg, live, Pkg.K14, "k14", "no_such_workload", 2, (), 12345)
+    r = bench.pass_kernel_roofline(Pkg, live, Pkg.K14, "k14", "no_such_workload", "photometric", (), 12345)
     assert r["avg_launch_ms"] == 300.0 and r["achieved"] is None and r["frac"] is None and r["traffic"] is None and "pmc_note" in r
     name = bench.PASS_WORKLOADS[0][1]
-    r = bench.pass_kernel_roofline(Pkg, live, Pkg.K14, "k14", name, 2, (), 12345)
+    r = bench.pass_kernel_roofline(Pkg, live, Pkg.K14, "k14", name, "photometric", (), 12345)
     assert r["pmc_source"].startswith("profiles/") and 0.0 < r["frac"] < 1.0 and 0.0 < r["hbm"]["frac"] < 1.0
     assert abs(r["achieved"] - r["valu_insts_per_launch"] / 0.3 / 1e9) < 0.1

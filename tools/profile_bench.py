@@ -73,12 +73,12 @@ def main():
     if pass_key:
         sys.path.insert(0, ROOT)
         import bench
-        _, workload, n_timed, _ = [e for e in bench.PASS_WORKLOADS if e[0] == pass_key][0]
+        _, workload, n_timed, _, pass_kind = [e for e in bench.PASS_WORKLOADS if e[0] == pass_key][0]
         sweep_key = [e[0] for e in bench.SUB_WORKLOADS if e[1] == workload and e[5] == 1 and e[2] == bench.PASS_ITERATIONS][0]
         flags = ["--steps", "1", "--warmup", "0"]   # the headline before the sub-lines: one iteration of the default workload
         tail = ["--no-cpu-baseline", "--only-workloads", sweep_key, "--only-workloads", pass_key]
         kernels_of_interest = PASS_KERNELS
-        tag = "%s_p%d" % (workload, n_timed)
+        tag = "%s_p%d%s" % (workload, n_timed, "" if pass_kind == "photometric" else "_" + pass_kind)
     os.makedirs(out_dir, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     per_dispatch = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel key -> counter -> [values in launch order]
@@ -129,7 +129,7 @@ def main():
                      "FETCH_SIZE in KiB doubled (gfx950 counts 128-B requests as 64 B), WRITE_SIZE in KiB as reported",
            "kernels": {}}
     if pass_key:
-        out["config"].update({"pass_key": pass_key, "passes": n_timed, "steps": None, "warmup": None})
+        out["config"].update({"pass_key": pass_key, "pass_kind": pass_kind, "passes": n_timed, "steps": None, "warmup": None})
         out["method"] = ("rocprofv3 --kernel-trace + one --pmc pass per counter group over bench.py's whole-pass sub-line; timed launches = the "
                          "last `passes` dispatches of K14 / K15 (one launch per apd_run); FETCH_SIZE in KiB doubled, WRITE_SIZE in KiB as reported")
     for key, counters in per_dispatch.items():

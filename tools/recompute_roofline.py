@@ -168,7 +168,9 @@ def check(directory):
                     problems.append("%s %s: cites counters but %r is not committed" % (tag, kname, kroof.get("pmc_source")))
                     continue
                 prof = json.load(open(prof_path))
-                if prof["config"]["workload"] != line["config"]["workload"] or list(prof["config"].get("options", [])) != list(line["config"].get("options", [])):
+                want_kind = "geometric" if "geom" in line["config"].get("state", "") else "photometric"
+                if prof["config"]["workload"] != line["config"]["workload"] or list(prof["config"].get("options", [])) != list(line["config"].get("options", [])) \
+                        or prof["config"].get("pass_kind", "photometric") != want_kind:
                     problems.append("%s %s: profile %s is of another workload or other options" % (tag, kname, kroof["pmc_source"]))
                     continue
                 lines += 1
