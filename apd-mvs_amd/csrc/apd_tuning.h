@@ -86,6 +86,7 @@
 #endif
 #ifndef APD_K14W_WAVES
 #define APD_K14W_WAVES 4  // ms at 4096x3072, 8 views: 4 waves/SIMD (128 VGPRs, 18 spilled) 140.6, 3 waves 150.1
+                          // the (sample, lane)-pair variant, 6200x4130, 10 views: 4 waves (42 spilled) 295.2 / 361.3 ms (photometric / geometric pass), 3 waves (164 VGPRs, none) 306.9 / 388.7 (profiles/r04/ab_k14_pairs_waves.txt)
 #endif
 #ifndef APD_K15W_WAVES
 #define APD_K15W_WAVES 3  // 4 waves/SIMD (100 VGPRs spilled) 30.5, 3 waves 27.1
