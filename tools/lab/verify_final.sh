@@ -7,6 +7,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 d=/tmp/tt24; rm -rf $d; mkdir -p $d
 python tools/make_synthetic_dense.py $d --width 1920 --height 1080 --views 24 --src 10 --textureless 0.2 --jpeg > /dev/null
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_tt24 -o tt24 -- /root/repo/apd-mvs_amd/_build/APD $d 0 --seed 7 --clean-exit > /tmp/tt24_prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tt24 -o tt24 -- /root/repo/apd-mvs_amd/_build/APD $d 0 --seed 7 --clean-exit > /tmp/tt24_prof.log 2>&1
 f=$(find /tmp/prof_tt24 -name "*kernel_stats.csv" | head -1); cp "$f" /root/repo/$O/kernel_stats_e2e_tt24_final.csv; head -8 /root/repo/$O/kernel_stats_e2e_tt24_final.csv | cut -c1-160
 grep -E "Stages" /tmp/tt24_prof.log
