@@ -1,6 +1,6 @@
 """Randomised bit-exact parity sweep: HIP path vs CPU oracle over random sizes, view counts, scenes and seeds through the
 three pass kinds (FIRST_INIT, REFINE_INIT + APD, REFINE_ITER + APD + geometric term), 8-bit and float images, compared
-after every pass (all state arrays).  Usage: python tools/parity_fuzz.py [cases] [first_seed]"""
+after every pass (all state arrays).  Usage: [APD_FUZZ_SCALE=3] python tools/parity_fuzz.py [cases] [first_seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +15,8 @@ import common
 def run_case(case):
     """One random configuration through the three pass kinds; raises AssertionError on the first differing state array."""
     rng = np.random.RandomState(1000 + case)
-    W, H = int(rng.randint(36, 260)), int(rng.randint(30, 180))
+    scale = float(os.environ.get("APD_FUZZ_SCALE", "1"))  # larger frames: more tiles, supertiles and list blocks per launch (the oracle takes scale^2 longer)
+    W, H = int(rng.randint(36, 260) * scale), int(rng.randint(30, 180) * scale)
     N = int(rng.randint(1, 10))
     if rng.rand() < 0.25:  # ten and more sources: other kernel instantiations (NMAX = 12 / 16 / 32, K14 walking (sample, lane) pairs)
         N = int(rng.randint(10, 19))
