@@ -154,9 +154,14 @@ struct StageClock {
 // three 8.29, four 7.92, six 8.00, eight 8.08 in the reference's order; 2 % at 6200 x 4130).
 }  // namespace
 
+// Views in flight per rank by level size.  Above 12 Mpix one view fills the device: two in flight at 6200 x 4130 run the passes in 15.71 s
+// instead of 15.80 (profiles/r04/ab_lanes_25mpix.txt) for twice the handle memory.
+#ifndef APD_LANES_ABOVE_12MPIX
+#define APD_LANES_ABOVE_12MPIX 1
+#endif
 int DefaultLanes(size_t pixels)
 {
-    return pixels <= ((size_t)1 << 20) ? 6 : (pixels <= ((size_t)4 << 20) ? 4 : (pixels <= ((size_t)12 << 20) ? 2 : 1));
+    return pixels <= ((size_t)1 << 20) ? 6 : (pixels <= ((size_t)4 << 20) ? 4 : (pixels <= ((size_t)12 << 20) ? 2 : APD_LANES_ABOVE_12MPIX));
 }
 
 // Device bytes an in-memory run keeps resident on its busiest device (rank 0 also fuses): the shared level images (float plane +
