@@ -760,25 +760,49 @@ def main():
     workloads = {}
     t_subs = time.perf_counter()
     cache = {(args.workload, 1): wl}
+    def guarded(key, fn):
+        """A sub-line that fails must not take the headline with it: in a single process its entry becomes {"error": ...} and the
+        block goes on.  Under a process group every rank must reach the same collectives, so there a failure stays fatal."""
+        try:
+            line = fn()
+        except Exception as e:  # noqa: BLE001 -- reported in the line
+            if distributed:
+                raise
+            gc.enable()
+            sys.stderr.write("bench.py: sub-line %s failed: %r\n" % (key, e))
+            workloads[key] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+            return False
+        line["n_gpus"] = world
+        line["scaling"] = "weak"
+        workloads[key] = line
+        return True
+
     for key, name, steps, warmup, pass_exchange, vpg in subs:
         w = cache.get((name, vpg))
         if w is None:
             for old in cache.values():   # one workload resident at a time: the next one gets the whole device
                 old.close()
             cache.clear()
-            w = SweepWorkload(ctx, name, max([max(s[2], s[3]) for s in subs if s[1] == name and s[5] == vpg]), (), args.seed, views_per_gpu=vpg)
+            try:
+                w = SweepWorkload(ctx, name, max([max(s[2], s[3]) for s in subs if s[1] == name and s[5] == vpg]), (), args.seed, views_per_gpu=vpg)
+            except Exception as e:  # noqa: BLE001
+                if distributed:
+                    raise
+                sys.stderr.write("bench.py: workload %s could not be set up: %r\n" % (name, e))
+                workloads[key] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+                continue
             cache[(name, vpg)] = w
-        line = w.measure(steps, warmup, pass_exchange=pass_exchange)
-        line["n_gpus"] = world
-        line["scaling"] = "weak"
-        workloads[key] = line
+        if not guarded(key, lambda: w.measure(steps, warmup, pass_exchange=pass_exchange)):
+            cache.pop((name, vpg), None)   # its state is unknown: the next sub-line of this workload builds a fresh one
+            try:
+                w.close()
+            except Exception:  # noqa: BLE001
+                pass
+            continue
         for pkey, pname, passes, pwarm, pkind in PASS_WORKLOADS:
             if pname == name and vpg == 1 and pkey not in workloads and w.max_iters == PASS_ITERATIONS and \
                     (not args.only_workloads or pkey in args.only_workloads):
-                pline = w.measure_whole_pass(passes, pwarm, pkind)
-                pline["n_gpus"] = world
-                pline["scaling"] = "weak"
-                workloads[pkey] = pline
+                guarded(pkey, lambda: w.measure_whole_pass(passes, pwarm, pkind))
     for old in cache.values():
         old.close()
     cache.clear()
