@@ -638,10 +638,23 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                 first = last;
                 continue;
             }
-            // Several ranks (or --rccl): a pass ends with the all-gather of its depth maps.  `lanes` host threads per rank, each with its
-            // own handle and stream; a rank's views are handed out in order.
-            for (size_t pi = first; pi < last; ++pi) {
-                const Pass &pass = plan[pi];
+            // Several ranks (or --rccl): a pass ends with the all-gather of its depth maps (the reference: depths.dmb files, APD.cpp:497-500),
+            // but only the halves that READ depth maps wait for it.  A rank's (pass, view) tasks of the level go out in order to its
+            // `lanes` host threads (handle + stream each); a lane that finds pass p handed out starts the first views of pass p + 1 --
+            // their first halves need nothing but the view's own state -- while the last views of pass p finish and their maps are
+            // exchanged; the thread that finishes the last view of a pass (over all ranks) runs the exchange.  No wait can point at a task
+            // nobody holds: whoever holds a task of pass p + 1 knows every task of pass p of its rank to be handed out, and a task of
+            // pass p waits only for the exchange of pass p - 1, whose views were all handed out earlier still.
+            {
+                const int P = (int)(last - first);
+                const int first_iteration = plan[first].iteration;
+                std::vector<int> remaining(P, V);
+                int exchanged = first_iteration - 1;  // the newest iteration whose maps every rank holds (under done_m)
+                auto wait_exchange = [&](int iteration) {  // false: the run has failed
+                    std::unique_lock<std::mutex> lock(done_m);
+                    done_cv.wait(lock, [&]() { return exchanged >= iteration || failure.failed.load(); });
+                    return !failure.failed.load();
+                };
                 std::vector<std::thread> workers;
                 for (int r = 0; r < G; ++r) {
                     ranks[r].next.store(0);
@@ -649,22 +662,54 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                         workers.emplace_back([&, r, li]() {
                             Rank &k = ranks[r];
                             Lane &lane = k.lanes[li];
+                            const int own = (int)k.own.size();
                             try {
                                 for (;;) {
                                     const int at = k.next.fetch_add(1);
-                                    if (at >= (int)k.own.size() || failure.failed) {
+                                    if (at >= P * own || failure.failed) {
                                         break;
                                     }
-                                    const int v = k.own[at];
+                                    const int pi = at / own, v = k.own[at % own];
+                                    const Pass &pass = plan[first + (size_t)pi];
+                                    const int it = pass.iteration;
+                                    if (pi > 0 && !wait_done(v, it - 1)) {  // the view's own previous pass (another lane may still hold it)
+                                        break;
+                                    }
                                     // The sources' depth maps: of this pass for the sources that precede the view in the reference's order
-                                    // (they must have published; one rank only), of the pass before for the others and for the view itself.
+                                    // (they must have published; one rank only), of the pass before -- once exchanged -- for the others and
+                                    // for the view itself.
                                     auto depth_of = [&](size_t a, int j) -> const float * {
                                         if (gauss_seidel && a > 0 && j < v) {
-                                            return wait_done(j, pass.iteration) ? k.send.as<float>() + (size_t)(j / G) * pix : nullptr;
+                                            return wait_done(j, it) ? k.send.as<float>() + (size_t)(j / G) * pix : nullptr;
                                         }
-                                        return gathered_depth(k, j, pix);
+                                        return wait_exchange(it - 1) ? gathered_depth(k, j, pix) : nullptr;
                                     };
-                                    run_view(r, lane, pass, v, depth_of, k.send.as<float>() + (size_t)(v / G) * pix, []() { return true; });
+                                    // the export overwrites the view's block of `send`: the exchange of the pass before must have read it
+                                    const auto before_export = [&]() { return pi == 0 || wait_exchange(it - 1); };
+                                    run_view(r, lane, pass, v, depth_of, k.send.as<float>() + (size_t)(v / G) * pix, before_export);
+                                    bool run_exchange = false;
+                                    {
+                                        std::lock_guard<std::mutex> lock(done_m);
+                                        run_exchange = done_pass[v] == it && --remaining[pi] == 0;
+                                    }
+                                    if (run_exchange) {  // every view of this pass, on every rank, has exported
+                                        std::vector<const void *> send(G);
+                                        std::vector<void *> recv(G);
+                                        for (int q = 0; q < G; ++q) {
+                                            send[q] = ranks[q].send.p;
+                                            recv[q] = ranks[q].recv.p;
+                                        }
+                                        Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)),
+                                              "apd_exchange_allgather");
+                                        {
+                                            std::lock_guard<std::mutex> lock(done_m);
+                                            exchanged = it;
+                                            if (it % 4 == 3) {
+                                                printf("Round: %d done\n", pass.level);
+                                            }
+                                        }
+                                        done_cv.notify_all();
+                                    }
                                 }
                             } catch (const std::exception &e) {
                                 failure.set(e.what());
@@ -678,17 +723,6 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                 }
                 if (failure.failed) {
                     throw std::runtime_error(failure.what);
-                }
-                // ---- every rank gets every view's depth map (the reference: depths.dmb files, APD.cpp:497-500) ----
-                std::vector<const void *> send(G);
-                std::vector<void *> recv(G);
-                for (int r = 0; r < G; ++r) {
-                    send[r] = ranks[r].send.p;
-                    recv[r] = ranks[r].recv.p;
-                }
-                Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)), "apd_exchange_allgather");
-                if (pass.iteration % 4 == 3) {
-                    printf("Round: %d done\n", pass.level);
                 }
                 fflush(stdout);
             }
