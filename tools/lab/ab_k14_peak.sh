@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of K14's phase-0 test: tools/_build/libapd_old.so (every sample within the radius above 0.5) against the built library
 # (no local minimum of at most 0.5 within the radius).  Per-kernel pass timing at 4096x3072 / 8 sources and 24 views of 1080p end to end.
+# The 'old' library is a build of the commit before the change, copied to tools/_build/libapd_old.so (git-ignored, travels with the snapshot).
 mkdir -p gpurun_out/k14peak; cd /root/repo; O=gpurun_out/k14peak
 timeout 900 python -m pytest -m gpu -x -q tests/test_gpu_parity.py tests/test_gpu_properties.py tests/test_gpu_fullsize_parity.py > $O/pytest.log 2>&1; tail -2 $O/pytest.log
 cp apd-mvs_amd/_build/libapd_mi355x.so /tmp/new.so

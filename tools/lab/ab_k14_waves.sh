@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of K14's launch bounds in the (sample, lane)-pair variant (ten and more sources): 4 waves per SIMD (128 VGPRs, 42 spilled) against
 # 3 (164 VGPRs, none): the whole-pass sub-lines of bench.py on configs[2].
+# tools/_build/libapd_k14w3.so = the library linked with apd_kernels_k1415w.hip compiled with -DAPD_K14W_WAVES=3 (git-ignored, travels with the snapshot).
 O=gpurun_out/k14waves; mkdir -p $O; cd /root/repo
 cp apd-mvs_amd/_build/libapd_mi355x.so /tmp/cur.so
 for which in cur w3 cur w3; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the multi-rank scheduler: APD_l2 = passes separated by a join + all-gather (the scheduler before), APD = tasks of a level
 # handed out across passes, only depth-reading halves wait for the exchange.  24 views of 1080p, device lists on one device (peer copies) and --rccl.
+# apd-mvs_amd/_build/APD_l2 = a build of host/multi_device.cpp of the commit before the change (git-ignored, travels with the snapshot).
 O=gpurun_out/overlap; mkdir -p $O; cd /root/repo
 timeout 900 python -m pytest -m gpu -x -q tests/test_gpu_dropin_binary.py > $O/pytest.log 2>&1; tail -2 $O/pytest.log
 d=/tmp/tt24; rm -rf $d; mkdir -p $d
