@@ -156,6 +156,9 @@ struct StageClock {
 
 // Views in flight per rank by level size.  Above 12 Mpix one view fills the device: two in flight at 6200 x 4130 run the passes in 15.71 s
 // instead of 15.80 (profiles/r04/ab_lanes_25mpix.txt) for twice the handle memory.
+#ifndef APD_GS_LANES_PER_PASS
+#define APD_GS_LANES_PER_PASS 2  // lanes that may work on one geometric pass in the reference's order (its second halves form a chain); 24 x 1080p passes: 1: 8.16 s, 2: 7.95, 3: 7.89, 9: 7.99 (profiles/r04/ab_gs_lanes_per_pass_tt24.txt)
+#endif
 #ifndef APD_LANES_ABOVE_12MPIX
 #define APD_LANES_ABOVE_12MPIX 1
 #endif
@@ -557,7 +560,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                         }
                     }
                     if (pass.geom_consistency) {
-                        if (gauss_seidel && active[pi] >= 2) {
+                        if (gauss_seidel && active[pi] >= APD_GS_LANES_PER_PASS) {
                             return false;
                         }
                         for (int s_id : problems[v].src_image_ids) {
