@@ -98,6 +98,8 @@ def parse_args(argv=None):
                          "tiled_copy k67_windows k1415_windows.  Reported in config.options")
     ap.add_argument("--no-workloads", action="store_true", help="headline only: skip the `workloads` block (the other BASELINE configs)")
     ap.add_argument("--only-workloads", action="append", default=[], metavar="KEY", help="restrict the `workloads` block to these keys")
+    ap.add_argument("--full-line", action="store_true",
+                    help="tooling only (tools/ab.sh, tools/profile_round.sh): print the full block as the stdout line instead of the compact one")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher / collective plumbing only, on CPU with gloo: no PatchMatch work is done or reported "
                          "(value is null); used by tests/test_bench_launcher.py to cover the --gpus N spawn path without GPUs")
@@ -846,10 +848,83 @@ def main():
                               "both sides, MAX over ranks, whole-job value): ms_per_step x steps of all lines lies inside this process's wall time",
             "wall_s": {"sub_workloads": round(subs_s, 1), "process": round(time.perf_counter() - t_main, 1)},
         }
-        print(json.dumps(out), flush=True)
+        emit(out, full_line=args.full_line)
     if distributed:
         dist.destroy_process_group()
     return 0
+
+
+COMPACT_LINE_MAX_BYTES = 2000   # the driver keeps a bounded tail of stdout (BENCH_r04.parsed was null with a 24 KB line)
+FULL_BLOCK_FILE = "bench_workloads.json"
+
+
+def compact_roofline(r):
+    """The roofline object of the stdout line: numbers only, notes stay in the full block."""
+    if not r:
+        return None
+    alg = r.get("algorithmic") or {}
+    hbm = r.get("hbm") or {}
+    return {"bound": r.get("bound"), "kernel": str(r.get("kernel", "")).split(" ")[0], "achieved": r.get("achieved"), "peak": r.get("peak"),
+            "unit": r.get("unit"), "frac": r.get("frac"), "traffic": None if r.get("traffic") is None else int(r["traffic"]),
+            "avg_launch_ms": r.get("avg_launch_ms"), "launches": r.get("launches"), "hbm_frac": hbm.get("frac"),
+            "algorithmic_GBps": alg.get("GBps"), "pmc_source": r.get("pmc_source")}
+
+
+def compact_workloads(workloads):
+    """{key: [value, ms_per_step or ms_per_pass, roofline fraction of the line's dominant kernel]}; a failed sub-line is [null, null, null]."""
+    out = {}
+    for key, w in workloads.items():
+        if w.get("value") is None:
+            out[key] = [None, None, None]
+            continue
+        ms = w.get("ms_per_pass", w.get("ms_per_step"))
+        roof = w.get("roofline")
+        if roof is None and w.get("pass_kernels"):   # whole passes: K14, the largest kernel of the pass
+            roof = w["pass_kernels"].get("K14")
+        if roof is None and w.get("weak_path"):
+            roof = (w["weak_path"] or {}).get("roofline")
+        out[key] = [w["value"], ms, None if not roof else roof.get("frac")]
+    return out
+
+
+def compact_line(out):
+    """The ONE stdout line: headline + roofline + cpu_baseline + one triple per sub-workload, at most COMPACT_LINE_MAX_BYTES bytes.
+    Everything else of `out` is in FULL_BLOCK_FILE and on stderr."""
+    cfg = out["config"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "width", "height", "num_src", "state")}
+    if "backend" in cfg and out.get("selftest"):
+        line["config"]["backend"] = cfg["backend"]
+    line["roofline"] = compact_roofline(out.get("roofline"))
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                                "sample": cb.get("sample_short", cb["sample"])[:96]}
+    line["workloads"] = compact_workloads(out.get("workloads") or {})
+    line["workloads_fields"] = ["value", "ms_per_step|ms_per_pass", "frac"]
+    line["full_block"] = FULL_BLOCK_FILE
+    if out.get("selftest"):
+        line["selftest"] = True
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text.encode()) <= COMPACT_LINE_MAX_BYTES, "bench.py: the stdout line grew to %d bytes (limit %d)" % (len(text.encode()), COMPACT_LINE_MAX_BYTES)
+    return text
+
+
+def emit(out, full_line=False):
+    """Full block -> FULL_BLOCK_FILE (next to bench.py, and under gpurun_out/ when that exists) and stderr; compact line -> the LAST and
+    only line of stdout."""
+    text = compact_line(out)   # a line that does not fit is a bug: fail before anything is printed
+    full = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, FULL_BLOCK_FILE), "w") as f:
+                    f.write(full + "\n")
+            except OSError as e:
+                sys.stderr.write("bench.py: could not write %s: %r\n" % (os.path.join(d, FULL_BLOCK_FILE), e))
+    sys.stderr.write("bench.py full block: " + full + "\n")
+    sys.stderr.flush()
+    print(full if full_line else text, flush=True)
 
 
 def apply_options(h, opts):
@@ -1034,7 +1109,8 @@ def run_cpu_baseline(args, num_src, np):
     o.close()
     return {"value": round(w * hgt * iters / dt / 1e6, 5), "unit": "Mpix*iter/s", "cores": int(cores), "kind": "port",
             "sample": "%dx%d frame of the same synthetic scene, %d src views, iterations 0..%d of a fresh pass (iteration 0 included, "
-                      "as in the GPU line), %.1f s" % (w, hgt, num_src, iters - 1, dt)}
+                      "as in the GPU line), %.1f s" % (w, hgt, num_src, iters - 1, dt),
+            "sample_short": "%dx%d, %d src, iterations 0..%d, %.1f s" % (w, hgt, num_src, iters - 1, dt)}
 
 
 if __name__ == "__main__":

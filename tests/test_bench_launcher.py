@@ -115,3 +115,42 @@ def test_committed_counter_profiles_give_roofline_fractions_below_one():
     # never borrowed is a profile of another workload, of other options or of another seed
     assert bench.load_pmc_profile("eth3d_pipes_fullres_10src", 6, 1, "k67") is None
     assert bench.load_pmc_profile("eth3d_office_fullres_8src", 6, 1, "k67", options=["early_out=0"]) is None
+
+
+def test_compact_line_fits_a_bounded_reader_and_equals_the_full_block():
+    """The stdout line of bench.py is a digest of the full block (bench_workloads.json): at most 2,000 bytes whatever the block holds,
+    every number equal to the block's.  Checked on the committed full blocks of rounds 4 and 5 (24 KB each)."""
+    import glob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]", "bench_*.json")))
+    assert len(paths) >= 2
+    for path in paths:
+        full = json.loads(open(path).readline())
+        if "workloads" not in full:
+            continue
+        text = bench.compact_line(full)
+        assert len(text.encode()) <= bench.COMPACT_LINE_MAX_BYTES <= 2000 and "\n" not in text
+        c = json.loads(text)
+        assert c["value"] == full["value"] and c["steps"] == full["steps"] and c["ms_per_step"] == full["ms_per_step"]
+        assert c["metric"] == full["metric"] and c["config"]["workload"] == full["config"]["workload"]
+        r, fr = c["roofline"], full["roofline"]
+        assert (r["frac"], r["achieved"], r["peak"], r["avg_launch_ms"], r["launches"]) == (fr["frac"], fr["achieved"], fr["peak"], fr["avg_launch_ms"], fr["launches"])
+        assert r["traffic"] == int(fr["traffic"]) and r["hbm_frac"] == fr["hbm"]["frac"] and r["pmc_source"] == fr["pmc_source"]
+        if full.get("cpu_baseline"):
+            assert c["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and c["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
+        assert set(c["workloads"]) == set(full["workloads"])
+        for key, (value, ms, frac) in c["workloads"].items():
+            w = full["workloads"][key]
+            assert value == w["value"] and ms == w.get("ms_per_pass", w.get("ms_per_step")), (path, key)
+    # a block that cannot fit is refused before anything is printed
+    fat = json.loads(open(paths[0]).readline())
+    fat["workloads"] = {"k%03d_%s" % (i, "x" * 40): {"value": 1.0, "ms_per_step": 1.0} for i in range(60)}
+    try:
+        bench.compact_line(fat)
+    except AssertionError as e:
+        assert "limit" in str(e)
+    else:
+        raise AssertionError("a 60-entry block fitted into the compact line?")

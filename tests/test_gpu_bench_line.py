@@ -1,6 +1,8 @@
-"""The driver's command, shortened: `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` must print ONE JSON line whose `workloads`
-block holds every sub-line of bench.SUB_WORKLOADS and bench.PASS_WORKLOADS with a value (no {"error": ...} entry), the whole-pass
-lines with K14 / K15 inside their timed region and a roofline from their committed counter profiles."""
+"""The driver's command, shortened: `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` must print ONE compact JSON line of at
+most bench.COMPACT_LINE_MAX_BYTES bytes (the driver reads a bounded tail of stdout: BENCH_r04.parsed was null with a 24 KB line) and
+write the full block to bench_workloads.json, whose `workloads` block holds every sub-line of bench.SUB_WORKLOADS and
+bench.PASS_WORKLOADS with a value (no {"error": ...} entry), the whole-pass lines with K14 / K15 inside their timed region and a
+roofline from their committed counter profiles; every compact value equals the full block's."""
 import importlib.util
 import json
 import os
@@ -23,7 +25,20 @@ def test_default_line_carries_every_sub_line():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]   # stdout is the one JSON line
-    d = json.loads(lines[0])
+    assert len(lines[0].encode()) <= bench.COMPACT_LINE_MAX_BYTES == 2000, len(lines[0])
+    c = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "workloads"):
+        assert k in c, k
+    assert c["roofline"]["frac"] > 0 and c["roofline"]["bound"] and c["roofline"]["pmc_source"] and c["roofline"]["traffic"] > 0
+    d = json.load(open(os.path.join(ROOT, bench.FULL_BLOCK_FILE)))
+    assert "bench.py full block: " in r.stderr
+    assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
+    assert c["roofline"]["avg_launch_ms"] == d["roofline"]["avg_launch_ms"] and c["config"]["workload"] == d["config"]["workload"]
+    assert set(c["workloads"]) == set(d["workloads"])
+    for key, (value, ms, frac) in c["workloads"].items():
+        full = d["workloads"][key]
+        assert value == full["value"] and ms == full.get("ms_per_pass", full.get("ms_per_step")), key
     assert d["metric"].startswith("Mpix*iterations/sec") and d["value"] > 0 and d["steps"] == 2 and d["n_gpus"] == 1
     assert d["config"]["workload"] == bench.DEFAULT_WORKLOAD and d["roofline"]["avg_launch_ms"] > 0
     w = d["workloads"]

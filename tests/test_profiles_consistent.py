@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 
-@pytest.mark.parametrize("round_dir", ["r02", "r03", "r04"])
+@pytest.mark.parametrize("round_dir", ["r02", "r03", "r04", "r05"])
 def test_roofline_fields_follow_from_the_committed_counters(round_dir):
     d = os.path.join(ROOT, "profiles", round_dir)
     import glob

@@ -4,7 +4,7 @@ WL=${TUNE_WORKLOAD:-synthetic_4096x3072_8src}
 ARGS="--workload $WL --steps ${TUNE_STEPS:-3} --warmup 1 --no-cpu-baseline"
 for e in "$@"; do
   echo "== options: [$e] workload $WL"
-  timeout 600 python bench.py --no-workloads $ARGS $e 2>/dev/null | python -c "
+  timeout 600 python bench.py --full-line --no-workloads $ARGS $e 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.readline())
 w=d.get('weak_path') or {}
 it=d.get('iterations') or {}

@@ -3,7 +3,7 @@
 # committed for, then the bench lines themselves -- made AFTER their profiles, in the same checkout, so that every roofline
 # field follows from the committed counters (tools/recompute_roofline.py).  Usage: tools/profile_round.sh <out_dir> [round, e.g. r04]
 OUT=${1:-gpurun_out/profile_round}
-ROUND=${2:-r04}
+ROUND=${2:-r05}
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
@@ -20,8 +20,10 @@ for key in configs2_pipes_apd_whole_pass configs2_pipes_apd_geometric_pass; do
 done
 mkdir -p profiles/$ROUND && cp "$OUT"/pmc_bench_*.json "$OUT"/pmc_pass_*.json profiles/$ROUND/   # where they will be committed; bench.py looks under profiles/*/
 # the two lines of the round: the default command and the driver's; each carries the `workloads` block (every BASELINE config)
-python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_driver_s20_w5.json" 2>/dev/null
+# stdout of each command = the compact line the driver parses (line_*.json, <= 2000 bytes); the full block is bench_workloads.json
+python bench.py > "$OUT/line_default.json" 2> "$OUT/bench_default.err"; cp bench_workloads.json "$OUT/bench_default.json"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/line_driver_s20_w5.json" 2>/dev/null; cp bench_workloads.json "$OUT/bench_driver_s20_w5.json"
+wc -c "$OUT"/line_*.json
 # the rocprofv3 --kernel-trace --stats summary of the driver's command, workloads block included
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/apd_trace_driver -o trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_driver_traced.json" 2> "$OUT/trace_driver.err"
 find /tmp/apd_trace_driver -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bench_driver_s20_w5_with_workloads.csv" \;

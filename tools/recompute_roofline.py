@@ -17,7 +17,9 @@ tools/profile_bench.py from separate rocprofv3 --pmc passes), re-derives
 
 (for an APD workload, whose `roofline` is the weak sweep's against the L1 tag pipeline: TCP_TOTAL_CACHE_ACCESSES per launch / live
 launch time / (256 CUs x 2.4 GHz x 1.85 accesses per clock), its `strong_path` block like a K6/K7 roofline) and compares them
-with what the line says.  Exits non-zero on any mismatch; tests/test_profiles_consistent.py runs it."""
+with what the line says.  Since round 5 bench.py's stdout is a compact line (line_<name>.json, at most 2,000 bytes: what the driver
+parses) and the full block lies beside it (bench_<name>.json = bench_workloads.json of the same run): every number of the compact
+line must be the full block's.  Exits non-zero on any mismatch; tests/test_profiles_consistent.py runs it."""
 import glob
 import json
 import os
@@ -204,6 +206,44 @@ def check(directory):
     return problems, lines
 
 
+def check_compact_lines(directory, problems):
+    """line_<name>.json (bench.py's stdout) against bench_<name>.json (the full block of the same run)."""
+    n = 0
+    for path in sorted(glob.glob(os.path.join(directory, "line_*.json"))):
+        text = [ln for ln in open(path).read().splitlines() if ln.startswith("{")]
+        tag = os.path.basename(path)
+        full_path = os.path.join(directory, "bench_" + tag[len("line_"):])
+        if len(text) != 1 or not os.path.exists(full_path):
+            problems.append("%s: %d JSON lines, full block %s" % (tag, len(text), "present" if os.path.exists(full_path) else "missing"))
+            continue
+        if len(text[0].encode()) > 2000:
+            problems.append("%s: %d bytes (the driver's reader is bounded: <= 2000)" % (tag, len(text[0].encode())))
+        c, full = json.loads(text[0]), json.loads(open(full_path).readline())
+        pairs = [(k, c.get(k), full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling")]
+        pairs += [("config." + k, c["config"].get(k), full["config"].get(k)) for k in ("workload", "width", "height", "num_src", "state")]
+        r, fr = c.get("roofline") or {}, full.get("roofline") or {}
+        pairs += [("roofline." + k, r.get(k), fr.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "pmc_source")]
+        pairs += [("roofline.traffic", r.get("traffic"), None if fr.get("traffic") is None else int(fr["traffic"])),
+                  ("roofline.hbm_frac", r.get("hbm_frac"), (fr.get("hbm") or {}).get("frac")),
+                  ("roofline.algorithmic_GBps", r.get("algorithmic_GBps"), (fr.get("algorithmic") or {}).get("GBps"))]
+        cb, fcb = c.get("cpu_baseline") or {}, full.get("cpu_baseline") or {}
+        pairs += [("cpu_baseline." + k, cb.get(k), fcb.get(k)) for k in ("value", "cores", "kind")]
+        if set(c.get("workloads") or {}) != set(full.get("workloads") or {}):
+            problems.append("%s: the compact line's sub-lines are not the full block's" % tag)
+        for key, triple in (c.get("workloads") or {}).items():
+            w = (full.get("workloads") or {}).get(key) or {}
+            roof = w.get("roofline") or (w.get("pass_kernels") or {}).get("K14") or (w.get("weak_path") or {}).get("roofline") or {}
+            pairs += [("workloads.%s.value" % key, triple[0], w.get("value")),
+                      ("workloads.%s.ms" % key, triple[1], w.get("ms_per_pass", w.get("ms_per_step"))),
+                      ("workloads.%s.frac" % key, triple[2], roof.get("frac"))]
+        bad = [(k, a, b) for k, a, b in pairs if a != b]
+        for k, a, b in bad:
+            problems.append("%s: %s is %r in the compact line, %r in the full block" % (tag, k, a, b))
+        n += 1
+        print("%-36s %d bytes, %d fields equal to %s" % (tag, len(text[0].encode()), len(pairs) - len(bad), os.path.basename(full_path)))
+    return n
+
+
 def newest_round():
     rounds = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]")) if glob.glob(os.path.join(d, "bench_*.json")))
     return rounds[-1] if rounds else os.path.join(ROOT, "profiles", "r02")
@@ -212,6 +252,7 @@ def newest_round():
 def main():
     directory = sys.argv[1] if len(sys.argv) > 1 else newest_round()   # the newest round that holds bench lines, like bench.py's profile choice
     problems, lines = check(directory)
+    check_compact_lines(directory, problems)
     for p in problems:
         print("MISMATCH " + p)
     if lines == 0:

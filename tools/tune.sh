@@ -6,7 +6,7 @@ ARGS="--workload $WL --steps ${TUNE_STEPS:-3} --warmup 1 --no-cpu-baseline"
 for f in "$@"; do
   APD_EXTRA_FLAGS="$f" python apd-mvs_amd/build.py --force > /tmp/build.log 2>&1 || { echo "BUILD FAILED for $f"; tail -5 /tmp/build.log; continue; }
   echo "== flags: [$f] workload $WL"
-  timeout 600 python bench.py --no-workloads $ARGS 2>/dev/null | python -c "
+  timeout 600 python bench.py --full-line --no-workloads $ARGS 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.readline())
 w=d.get('weak_path') or {}
 it=d.get('iterations') or {}
