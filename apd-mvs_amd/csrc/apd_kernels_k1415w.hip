@@ -100,11 +100,21 @@ __device__ __forceinline__ SrcWindow fw_stage(const FrameArgs &fa, const ViewCon
 // K14
 // ------------------------------------------------------------------------------------------------
 
-// kPairs: the kernel may walk the (sample, lane) pairs of a chunk instead of its samples (see the chunk loop).  Carrying that
+// Loop order: chunk of depth samples outermost, views inside.  The window count is the same in either order (one per view and
+// chunk); with the views innermost the accumulated costs of the chunk's samples live in registers (a vector indexed by the
+// wave-uniform sample counter: v_movrel, no scratch) and every finished cost -- divided by the weight sum and clamped, :2093 -- is
+// written ONCE to the per-lane profile the peak search reads.  Rounds 2-4 ran the views outermost and read-modified-wrote the
+// 61-entry profile in scratch memory once per view: 158 / 218 GB of write-back per launch at 6200x4130 with 10 sources for 25.6 MB
+// of output (profiles/r04/pmc_pass_*).  Every sample still adds its views in view order: same bits.
+//
+// kPairs: the kernel may walk the (sample, lane) pairs of a chunk instead of its samples (see the view loop).  Carrying that
 // second loop costs the sample loop registers (4096x3072, 8 sources: 119.6 -> 124.0 ms; float images 34.5 -> 40.1 at 2048x1536),
 // so the launcher picks it where views are selected sparsely enough for it to pay: from ten sources on (15 draws over N views;
 // K14 ms at 2048x1536, photometric / geometric pass: N = 10 38.0 / 47.4 -> 38.4 / 44.3, N = 12 46.3 / 58.3 -> 44.3 / 51.2,
 // N = 16 61.6 / 76.6 -> 51.9 / 59.8).
+static_assert(APD_K14_CHUNK == 4 || APD_K14_CHUNK == 8 || APD_K14_CHUNK == 16, "the chunk's accumulators are a register vector");
+typedef float k14_chunk_t __attribute__((ext_vector_type(APD_K14_CHUNK)));
+
 template <bool kQuad, bool kPairs>
 __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32) void k14w_depth_to_weak(FrameArgs fa)
 {
@@ -119,6 +129,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
     const int min_margin = 6;
     const int center = px + py * W;
     constexpr int RADIUS = 30, NP = 2 * RADIUS + 1;
+    constexpr int NP_PAD = ((NP + APD_K14_CHUNK - 1) / APD_K14_CHUNK) * APD_K14_CHUNK;
 
     // lanes without depth samples to score stay in the wave: every lane helps to stage the windows
     bool alive = px < W && py < H;
@@ -127,8 +138,8 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
     ViewWeights<32> vw;
     vw.clear();
     float weight_normal = 1.0f;
-    float pw[NP];   // plane distance of depth sample i; NaN-free marker for "outside [depth_min, depth_max]": in_range bit
-    float pc[NP];   // accumulated cost of depth sample i
+    float base_line = 0.0f, disp = 0.0f;
+    float pc[NP_PAD];   // finished cost of depth sample i: MIN(2, sum / weight_normal), 2 outside [depth_min, depth_max]; written once
     uint64_t in_range = 0;
     if (alive) {
         if (px < min_margin || py < min_margin || px >= W - min_margin || py >= H - min_margin) {
@@ -146,7 +157,6 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
     if (alive) {
         sel = fa.selected_views[center];
         vw.load(fa, center);
-        float base_line;
         const int valid = fw_baseline_and_weight(fa, sel, vw, base_line, weight_normal);
         if (valid == 0) {
             fa.weak_info[center] = APD_UNKNOWN;
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
         } else {
             // cost_now of :2022-2051 is computed by the reference but never used by K14's classification
             base_line /= (float)valid;
-            const float disp = fa.K[0] * base_line / origin.w;
+            disp = fa.K[0] * base_line / origin.w;
             // Samples 0 and NP - 1 are never read: the peak search covers i = 2 .. NP - 3 and looks at i - 1 and i + 1 (:2104-2115),
             // and pc[min_peak] of :2120 can only be pc[0] when no peak was found, where abs(0 - 30) > weak_peak_radius has already
             // decided (for every radius below 30; with a larger one the two samples are scored like the rest).  Two of 61 NCC
@@ -163,14 +173,11 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
 #pragma unroll 1
             for (int i = 0; i < NP; ++i) {
                 const float p_depth = fa.K[0] * base_line / (disp + (float)(i - RADIUS));
-                pc[i] = 0.0f;
-                pw[i] = 1.0f;
                 if (skip_ends && (i == 0 || i == NP - 1)) {
                     continue;
                 }
                 if (!(p_depth < fa.depth_min || p_depth > fa.depth_max)) {
                     in_range |= 1ull << i;
-                    pw[i] = distance_to_origin(fa, px, py, p_depth, origin.x, origin.y, origin.z);
                 }
             }
         }
@@ -188,152 +195,139 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
     // min_peak = 0), or it lies inside and costs more than 0.5.  Phase 0 therefore scores the chunks that cover
     // [RADIUS - weak_peak_radius, RADIUS + weak_peak_radius] against every selected view; lanes that are WEAK by that
     // argument write their result and drop out, and phase 1 scores the remaining chunks for the others (a wave of a
-    // textureless region ends after phase 0).  Every sample still adds its views in view order.
+    // textureless region ends after phase 0).
     const int wr = min(max(fa.weak_peak_radius, 0), RADIUS);
     const int centre_lo = ((RADIUS - wr) / APD_K14_CHUNK) * APD_K14_CHUNK;                        // first sample of the first centre chunk
     const int centre_hi = (APD_K14_CENTRE_FIRST && fa.early_out) ? ((RADIUS + wr) / APD_K14_CHUNK + 1) * APD_K14_CHUNK : 0;  // one past the last centre chunk
 #pragma unroll 1
     for (int phase = (APD_K14_CENTRE_FIRST && fa.early_out) ? 0 : 1; phase < 2; ++phase) {
 #pragma unroll 1
-        for (int v = 0; v < fa.num_src; ++v) {
-            const bool use = alive && bit_test(sel, (unsigned)v) != 0;
-            if (__builtin_amdgcn_ballot_w64(use) == 0) {
+        for (int c0 = 0; c0 < NP; c0 += APD_K14_CHUNK) {
+            const bool centre_chunk = c0 >= centre_lo && c0 < centre_hi;
+            if (centre_chunk != (phase == 0)) {
                 continue;
             }
-            const ViewConst &vc = view_const(fa, v);
-            const float wv = (float)vw.get(v);
-#pragma unroll 1
-            for (int c0 = 0; c0 < NP; c0 += APD_K14_CHUNK) {
-                const bool centre_chunk = c0 >= centre_lo && c0 < centre_hi;
-                if (centre_chunk != (phase == 0)) {
-                    continue;
-                }
-                const int c1 = min(c0 + APD_K14_CHUNK, NP);
-                if (__builtin_amdgcn_ballot_w64(use && ((in_range >> c0) & ((1ull << (c1 - c0)) - 1ull)) != 0) == 0) {
-                    continue;  // nobody has a sample to score in this chunk
+            const int c1 = min(c0 + APD_K14_CHUNK, NP);
+            const int n = c1 - c0;
+            const unsigned chunk_bits = (unsigned)((in_range >> c0) & ((1ull << n) - 1ull));
+            k14_chunk_t acc = 0.0f, pwc = 1.0f;   // weighted cost sums and plane distances of samples c0 .. c1 - 1
+            if (__builtin_amdgcn_ballot_w64(alive && chunk_bits != 0) != 0) {   // else nobody has a sample to score in this chunk
+#pragma unroll
+                for (int j = 0; j < APD_K14_CHUNK; ++j) {
+                    if ((chunk_bits >> j) & 1u) {   // the depth of the first loop, computed again: same operands, same bits
+                        const float p_depth = fa.K[0] * base_line / (disp + (float)(c0 + j - RADIUS));
+                        pwc[j] = distance_to_origin(fa, px, py, p_depth, origin.x, origin.y, origin.z);
+                    }
                 }
                 const int mid = (c0 + c1) >> 1;
-                const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use && ((in_range >> mid) & 1ull) != 0, px, py, origin, pw[mid]);
-                // A lane scores a view only if its pixel selected it (6.5 of 8 views on the synthetic 8-source scenes, 8.8 of 16 on the
-                // 16-source one, fewer on real ones), and a wave runs an NCC for a depth sample if ANY lane does.  When every lane of
-                // the view has every sample of the chunk (the regular case: all in [depth_min, depth_max]) the n x U (sample, lane)
-                // pairs of the chunk can be walked 64 at a time, sample-major: pair idx is sample idx / U of the lane of rank idx % U
-                // (rank -> lane through one ds_permute), its worker fetches that lane's ray, plane distance and reference
-                // moments through ds_bpermute, scores the pair from the owner's pixel position against the same window and
-                // reference tile (both belong to the wave), and the owner pulls the cost back with another ds_bpermute and
-                // adds it to pc[] in view order as before: ceil(n U / 64) wave-level NCCs per chunk instead of n, same
-                // operands, same bits.  A slot of pairs costs about a tenth more than a slot of one sample (the fetches, the
-                // pull, the arrays of the chunk), so this path is taken when it saves two slots of the chunk, or one when every
-                // NCC also pays the geometric term.  K14 ms at 2048x1536, photometric / geometric pass: 16 sources (U = 35 of 64)
-                // 61.6 / 76.6 -> 51.9 / 59.8; with 8 sources (U = 52) a chunk saves one slot at best and stays on the sample loop.
-                const int n = c1 - c0;
-                const unsigned long long um = __builtin_amdgcn_ballot_w64(use);
-                const int U = __builtin_popcountll(um);
-                const unsigned chunk_bits = (unsigned)((in_range >> c0) & ((1ull << n) - 1ull));
-                bool regular = false;
-                if constexpr (kPairs) {
-                    regular = ((n * U + 63) >> 6) + (fa.geom_consistency ? 1 : 2) <= n &&
-                              __builtin_amdgcn_ballot_w64(use && chunk_bits != ((1u << n) - 1u)) == 0;
-                }
-                if (kPairs && regular) {
-                    const int lane_id = threadIdx.x & 63;
-                    const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
-                    int rank_to_lane;
-                    {  // a full permutation: owners take ranks 0..U-1, the other lanes U..63
-                        const unsigned long long nm = ~um;
-                        const int other_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
-                        const int target = use ? my_rank : U + other_rank;
-                        rank_to_lane = __builtin_amdgcn_ds_permute(target << 2, lane_id);
+#pragma unroll 1
+                for (int v = 0; v < fa.num_src; ++v) {
+                    const bool use = alive && bit_test(sel, (unsigned)v) != 0;
+                    if (__builtin_amdgcn_ballot_w64(use && chunk_bits != 0) == 0) {
+                        continue;
                     }
-                    float pwc[APD_K14_CHUNK], tcj[APD_K14_CHUNK];
+                    const ViewConst &vc = view_const(fa, v);
+                    const float wv = (float)vw.get(v);
+                    const SrcWindow w = fw_stage<kQuad>(fa, vc, win, use && ((chunk_bits >> (mid - c0)) & 1u) != 0, px, py, origin, pwc[mid - c0]);
+                    // A lane scores a view only if its pixel selected it (6.5 of 8 views on the synthetic 8-source scenes, 8.8 of 16 on the
+                    // 16-source one, fewer on real ones), and a wave runs an NCC for a depth sample if ANY lane does.  When every lane of
+                    // the view has every sample of the chunk (the regular case: all in [depth_min, depth_max]) the n x U (sample, lane)
+                    // pairs of the chunk can be walked 64 at a time, sample-major: pair idx is sample idx / U of the lane of rank idx % U
+                    // (rank -> lane through one ds_permute), its worker fetches that lane's ray, plane distance and reference
+                    // moments through ds_bpermute, scores the pair from the owner's pixel position against the same window and
+                    // reference tile (both belong to the wave), and the owner pulls the cost back with another ds_bpermute and
+                    // adds it to its sum in view order as before: ceil(n U / 64) wave-level NCCs per chunk instead of n, same
+                    // operands, same bits.  A slot of pairs costs about a tenth more than a slot of one sample (the fetches, the
+                    // pull), so this path is taken when it saves two slots of the chunk, or one when every
+                    // NCC also pays the geometric term.  K14 ms at 2048x1536, photometric / geometric pass: 16 sources (U = 35 of 64)
+                    // 61.6 / 76.6 -> 51.9 / 59.8; with 8 sources (U = 52) a chunk saves one slot at best and stays on the sample loop.
+                    const unsigned long long um = __builtin_amdgcn_ballot_w64(use);
+                    const int U = __builtin_popcountll(um);
+                    bool regular = false;
+                    if constexpr (kPairs) {
+                        regular = ((n * U + 63) >> 6) + (fa.geom_consistency ? 1 : 2) <= n &&
+                                  __builtin_amdgcn_ballot_w64(use && chunk_bits != ((1u << n) - 1u)) == 0;
+                    }
+                    if (kPairs && regular) {
+                        const int lane_id = threadIdx.x & 63;
+                        const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                        int rank_to_lane;
+                        {  // a full permutation: owners take ranks 0..U-1, the other lanes U..63
+                            const unsigned long long nm = ~um;
+                            const int other_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
+                            const int target = use ? my_rank : U + other_rank;
+                            rank_to_lane = __builtin_amdgcn_ds_permute(target << 2, lane_id);
+                        }
+                        const int total = n * U;
+#pragma unroll 1
+                        for (int first = 0; first < total; first += 64) {
+                            const int idx = first + lane_id;
+                            const bool valid = idx < total;
+                            int j = 0;
 #pragma unroll
-                    for (int j = 0; j < APD_K14_CHUNK; ++j) {
-                        pwc[j] = (j < n) ? pw[c0 + j] : 1.0f;
-                        tcj[j] = 0.0f;
-                    }
-                    const int total = n * U;
-#pragma unroll 1
-                    for (int first = 0; first < total; first += 64) {
-                        const int idx = first + lane_id;
-                        const bool valid = idx < total;
-                        int j = 0;
-#pragma unroll
-                        for (int k = 1; k < APD_K14_CHUNK; ++k) {
-                            j += (k < n && k * U <= idx) ? 1 : 0;
-                        }
-                        const int owner = __shfl(rank_to_lane, valid ? idx - j * U : 0);
-                        const int j_lo = first / U, j_hi = (min(total, first + 64) - 1) / U;
-                        float w_item = 1.0f;
-#pragma unroll 1
-                        for (int jj = j_lo; jj <= j_hi; ++jj) {
-                            const float v_ = __shfl(pwc[jj], owner);
-                            if (j == jj) {
-                                w_item = v_;
+                            for (int k = 1; k < APD_K14_CHUNK; ++k) {
+                                j += (k < n && k * U <= idx) ? 1 : 0;
                             }
-                        }
-                        const float4 pl = make_float4(__shfl(origin.x, owner), __shfl(origin.y, owner), __shfl(origin.z, owner), w_item);
-                        RefPatchLds<kFwPitch> orp;
-                        orp.mean = __shfl(rp.mean, owner);
-                        orp.var = __shfl(rp.var, owner);
-                        const int olx = (wave_id & 1) * 8 + (owner & 7), oly = (wave_id >> 1) * 8 + (owner >> 3);
-                        orp.base = &tile[oly * kFwPitch + olx];
-                        const int opx = blockIdx.x * kFwTile + olx, opy = blockIdx.y * kFwTile + oly;
-                        float tc = 0.0f;
-                        if (valid) {
-                            float qx, qy, qz;
-                            plane_q(pl, qx, qy, qz);
-                            tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, orp, opx, opy, qx, qy, qz);
-                            if (fa.geom_consistency) {
-                                tc += fa.geom_factor * geom_cost(fa, vc, opx, opy, pl);
-                            }
-                        }
-                        // owners collect: pair (jj, my_rank) sits in slot (jj U + my_rank) / 64 at lane (jj U + my_rank) % 64
+                            const int owner = __shfl(rank_to_lane, valid ? idx - j * U : 0);
+                            const int j_lo = first / U, j_hi = (min(total, first + 64) - 1) / U;
+                            float w_item = 1.0f;
 #pragma unroll 1
-                        for (int jj = j_lo; jj <= j_hi; ++jj) {
-                            const int at = jj * U + my_rank;
-                            const float c = __shfl(tc, at & 63);
-                            if (use && (at >> 6) == (first >> 6)) {
-                                tcj[jj] = c;
+                            for (int jj = j_lo; jj <= j_hi; ++jj) {
+                                const float v_ = __shfl(pwc[jj], owner);
+                                if (j == jj) {
+                                    w_item = v_;
+                                }
                             }
-                        }
-                    }
-                    if (use) {
-#pragma unroll
-                        for (int j = 0; j < APD_K14_CHUNK; ++j) {
-                            if (j < n) {
-                                pc[c0 + j] += tcj[j] * wv;
-                            }
-                        }
-                    }
-                } else {
-                    // pw[] and pc[] are indexed dynamically and live in scratch memory: the two reads of sample i + 1 are issued
-                    // before sample i is scored instead of stalling its start and its end
-                    float pw_next = pw[c0], pc_next = pc[c0];
-#pragma unroll 1
-                    for (int i = c0; i < c1; ++i) {
-                        const float pw_i = APD_K14_PREFETCH ? pw_next : pw[i], pc_i = APD_K14_PREFETCH ? pc_next : 0.0f;
-                        if (APD_K14_PREFETCH && i + 1 < c1) {
-                            pw_next = pw[i + 1];
-                            pc_next = pc[i + 1];
-                        }
-                        if (use && ((in_range >> i) & 1ull)) {
-                            float4 pl = origin;
-                            pl.w = pw_i;
-                            float qx, qy, qz;
-                            plane_q(pl, qx, qy, qz);
+                            const float4 pl = make_float4(__shfl(origin.x, owner), __shfl(origin.y, owner), __shfl(origin.z, owner), w_item);
+                            RefPatchLds<kFwPitch> orp;
+                            orp.mean = __shfl(rp.mean, owner);
+                            orp.var = __shfl(rp.var, owner);
+                            const int olx = (wave_id & 1) * 8 + (owner & 7), oly = (wave_id >> 1) * 8 + (owner >> 3);
+                            orp.base = &tile[oly * kFwPitch + olx];
+                            const int opx = blockIdx.x * kFwTile + olx, opy = blockIdx.y * kFwTile + oly;
                             float tc = 0.0f;
-                            tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
-                            if (fa.geom_consistency) {
-                                tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
+                            if (valid) {
+                                float qx, qy, qz;
+                                plane_q(pl, qx, qy, qz);
+                                tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, orp, opx, opy, qx, qy, qz);
+                                if (fa.geom_consistency) {
+                                    tc += fa.geom_factor * geom_cost(fa, vc, opx, opy, pl);
+                                }
                             }
-                            if (APD_K14_PREFETCH) {
-                                pc[i] = pc_i + tc * wv;
-                            } else {
-                                pc[i] += tc * wv;
+                            // owners collect: pair (jj, my_rank) sits in slot (jj U + my_rank) / 64 at lane (jj U + my_rank) % 64
+#pragma unroll 1
+                            for (int jj = j_lo; jj <= j_hi; ++jj) {
+                                const int at = jj * U + my_rank;
+                                const float c = __shfl(tc, at & 63);
+                                const float a = acc[jj];
+                                acc[jj] = (use && (at >> 6) == (first >> 6)) ? a + c * wv : a;
+                            }
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int j = 0; j < n; ++j) {
+                            const float pw_j = pwc[j], a = acc[j];
+                            if (use && ((chunk_bits >> j) & 1u)) {
+                                float4 pl = origin;
+                                pl.w = pw_j;
+                                float qx, qy, qz;
+                                plane_q(pl, qx, qy, qz);
+                                float tc = 0.0f;
+                                tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
+                                if (fa.geom_consistency) {
+                                    tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
+                                }
+                                acc[j] = a + tc * wv;
                             }
                         }
                     }
                 }
+            }
+            // the chunk's samples are complete: :2093
+#pragma unroll
+            for (int j = 0; j < APD_K14_CHUNK; ++j) {
+                const float p_cost = acc[j] / weight_normal;
+                pc[c0 + j] = ((chunk_bits >> j) & 1u) ? ((2.0f > p_cost) ? p_cost : 2.0f) : 2.0f;  // MIN(2.0f, p_cost): NaN -> 2
             }
         }
         if (phase == 0) {
@@ -344,16 +338,12 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                 float below = 2.0f, here = 2.0f;
                 bool below_known = false;
                 const int first = max(RADIUS - wr - 1, centre_lo);
-                const int last = min(RADIUS + wr + 1, centre_hi - 1);
+                const int last = min(RADIUS + wr + 1, min(centre_hi, NP) - 1);
 #pragma unroll 1
                 for (int i = first; i <= last + 1; ++i) {
-                    // `above` = clamped cost of sample i (:2093), `here` = i - 1, `below` = i - 2
-                    float above = 2.0f;
+                    // `above` = cost of sample i, `here` = i - 1, `below` = i - 2
                     const bool above_known = i <= last;
-                    if (above_known && ((in_range >> i) & 1ull)) {
-                        const float p_cost = pc[i] / weight_normal;
-                        above = (2.0f > p_cost) ? p_cost : 2.0f;
-                    }
+                    const float above = above_known ? pc[i] : 2.0f;
                     const int j = i - 1;  // the sample under test
                     if (j >= max(RADIUS - wr, 2) && j <= min(RADIUS + wr, NP - 3) && j >= first) {  // the peak search covers 2 .. NP - 3 (:2104)
                         const bool lower_ok = !below_known || below > here;
@@ -377,28 +367,28 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
     if (!alive) {
         return;
     }
-#pragma unroll 1
-    for (int i = 0; i < NP; ++i) {
-        if ((in_range >> i) & 1ull) {
-            const float p_cost = pc[i] / weight_normal;
-            pc[i] = (2.0f > p_cost) ? p_cost : 2.0f;  // MIN(2.0f, p_cost): NaN -> 2
-        } else {
-            pc[i] = 2.0f;
-        }
-    }
     uint64_t peaks = 0;
     int peak_count = 0, min_peak = 0;
     float min_cost = 2.0f;
-    for (int i = 2; i < NP - 2; ++i) {
-        if (pc[i - 1] > pc[i] && pc[i + 1] > pc[i]) {
-            peaks |= 1ull << i;
-            peak_count++;
-            if (pc[i] < min_cost) {
-                min_peak = i;
-                min_cost = pc[i];
+    {
+        float lower = pc[1], here = pc[2];
+#pragma unroll 1
+        for (int i = 2; i < NP - 2; ++i) {
+            const float upper = pc[i + 1];
+            if (lower > here && upper > here) {
+                peaks |= 1ull << i;
+                peak_count++;
+                if (here < min_cost) {
+                    min_peak = i;
+                    min_cost = here;
+                }
             }
+            lower = here;
+            here = upper;
         }
     }
+    // pc[min_peak] is min_cost when a peak was found; without one min_peak = 0 is more than weak_peak_radius away from RADIUS for
+    // every radius below 30, and with a larger radius sample 0 was scored like the rest
     if (abs(min_peak - RADIUS) > fa.weak_peak_radius || pc[min_peak] > 0.5f) {
         fa.weak_info[center] = APD_WEAK;
         return;
@@ -408,6 +398,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
         return;
     }
     float var = 0.0f;
+#pragma unroll 1
     for (int i = 2; i < NP - 2; ++i) {
         if (((peaks >> i) & 1ull) && i != min_peak) {
             const float dist = pc[i] - min_cost;
