@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                             if (valid) {
                                 float qx, qy, qz;
                                 plane_q(pl, qx, qy, qz);
-                                tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, orp, opx, opy, qx, qy, qz);
+                                tc += ncc_fixed_windowed<kQuad, kFwWinPitch, false, false, true>(fa, vc, w, orp, opx, opy, qx, qy, qz);
                                 if (fa.geom_consistency) {
                                     tc += fa.geom_factor * geom_cost(fa, vc, opx, opy, pl);
                                 }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                                 float qx, qy, qz;
                                 plane_q(pl, qx, qy, qz);
                                 float tc = 0.0f;
-                                tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
+                                tc += ncc_fixed_windowed<kQuad, kFwWinPitch, false, false, true>(fa, vc, w, rp, px, py, qx, qy, qz);
                                 if (fa.geom_consistency) {
                                     tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
                                 }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
             float qx, qy, qz;
             plane_q(pl, qx, qy, qz);
             float tc = 0.0f;
-            tc += ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
+            tc += ncc_fixed_windowed<kQuad, kFwWinPitch, false, false, true>(fa, vc, w, rp, px, py, qx, qy, qz);
             if (fa.geom_consistency) {
                 tc += fa.geom_factor * geom_cost(fa, vc, px, py, pl);
             }
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
                 pl.w = pw[i];
                 float qx, qy, qz;
                 plane_q(pl, qx, qy, qz);
-                const float c = ncc_fixed_windowed<kQuad, kFwWinPitch>(fa, vc, w, rp, px, py, qx, qy, qz);
+                const float c = ncc_fixed_windowed<kQuad, kFwWinPitch, false, false, true>(fa, vc, w, rp, px, py, qx, qy, qz);
                 float a = acc[i];
                 a += c * wv;
                 if (fa.geom_consistency) {

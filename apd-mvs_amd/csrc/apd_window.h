@@ -375,15 +375,36 @@ __device__ __forceinline__ void win_row_lerp(const WinTaps<typename WinEntry<kQu
 // ncc_fixed_moments (fast reciprocal) reading the window.
 // cX / cY: positions of the four corner samples {(x0,y0), (x0,y1), (x1,y0), (x1,y1)} from the caller's window test; rows 0 and
 // kPatchN - 1 take their end samples from there instead of computing them a second time (APD_WIN_CORNER_REUSE=0: recompute).
-template <bool kQuad, int kPitch, bool kApprox, typename Ref>
+// kLocal (K14 / K15): the sample coordinates are formed inside the body, by exact binary32 additions to the patch's first
+// coordinate taken through an opaque copy -- (float)(px - 5) + 2 i is the integer (float)(px + 2 i - 5) of the other form, bit for
+// bit.  Without it the compiler shares these twelve conversions with the global-path body and with the corner test, hoists them
+// out of K14's sample / view / chunk loops and, at 128 registers, spills them: the body then opens three rows with a scratch
+// reload and `s_waitcnt vmcnt(0)` (a memory round trip per row, profiles/r05/k14_body_spills.txt).
+__device__ __forceinline__ float opaque_f32(float v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <bool kQuad, int kPitch, bool kApprox, bool kLocal = false, typename Ref>
 __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homography &H, int px, int py, int addr0, float &sum_s,
                                                    float &sum_ss, float &sum_rs, const float (&cX)[4], const float (&cY)[4])
 {
     constexpr bool kReuse = APD_WIN_CORNER_REUSE != 0;
     float yf[kPatchN];
+    float x_first = 0.0f;
+    if constexpr (kLocal) {
+        x_first = opaque_f32((float)(px - kPatchRadius));
+        const float y_first = opaque_f32((float)(py - kPatchRadius));
 #pragma unroll
-    for (int j = 0; j < kPatchN; ++j) {
-        yf[j] = (float)(py + kPatchStep * j - kPatchRadius);
+        for (int j = 0; j < kPatchN; ++j) {
+            yf[j] = y_first + (float)(kPatchStep * j);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kPatchN; ++j) {
+            yf[j] = (float)(py + kPatchStep * j - kPatchRadius);
+        }
     }
     sum_s = 0.0f;
     sum_ss = 0.0f;
@@ -394,7 +415,7 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
     float a[2][kPatchN], b[2][kPatchN];
     WinTaps<typename WinEntry<kQuad>::type> t[2][kPatchN];
     {
-        const float xf = (float)(px - kPatchRadius);
+        const float xf = kLocal ? x_first : (float)(px - kPatchRadius);
         win_row_issue<kQuad, kPitch, kApprox, kReuse>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf,
                                                       addr0, a[0], b[0], t[0], cX[0], cY[0], cX[1], cY[1]);
     }
@@ -410,11 +431,11 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
         }
         APD_STAGE();
         if (i + 2 < kPatchN) {
-            const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
+            const float xf = kLocal ? x_first + (float)(kPatchStep * (i + 1)) : (float)(px + kPatchStep * (i + 1) - kPatchRadius);
             win_row_issue<kQuad, kPitch, kApprox>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf,
                                                   addr0, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1]);
         } else if (i + 1 < kPatchN) {
-            const float xf = (float)(px + kPatchStep * (i + 1) - kPatchRadius);
+            const float xf = kLocal ? x_first + (float)(kPatchStep * (i + 1)) : (float)(px + kPatchStep * (i + 1) - kPatchRadius);
             win_row_issue<kQuad, kPitch, kApprox, kReuse>(H, fmaf(H.h[0], xf, H.h[2]), fmaf(H.h[3], xf, H.h[5]), fmaf(H.h[6], xf, H.h[8]), yf,
                                                           addr0, a[(i + 1) & 1], b[(i + 1) & 1], t[(i + 1) & 1], cX[2], cY[2], cX[3], cY[3]);
         }
@@ -448,7 +469,7 @@ __device__ __forceinline__ void corner_position(const Homography &H, float xf, f
 
 // ComputeBilateralNCCOld (APD.cu:530-614) for plane q = n/d against source view vc, window first.
 // kApprox: tolerance mode (bare v_rcp_f32 everywhere, no IEEE body); see quad_row_issue
-template <bool kQuad, int kPitch = kWinW, bool kTiled = false, bool kApprox = false, typename Ref>
+template <bool kQuad, int kPitch = kWinW, bool kTiled = false, bool kApprox = false, bool kLocal = false, typename Ref>
 __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const ViewConst &vc, const SrcWindow &w, const Ref &rp, int px,
                                                     int py, float qx, float qy, float qz)
 {
@@ -486,7 +507,7 @@ __device__ __forceinline__ float ncc_fixed_windowed(const FrameArgs &fa, const V
     const bool fast_body = __builtin_amdgcn_ballot_w64(!fast_recip) == 0;
     float sum_s, sum_ss, sum_rs;
     if (in_window) {
-        ncc_window_moments<kQuad, kPitch, kApprox>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs, cX, cY);
+        ncc_window_moments<kQuad, kPitch, kApprox, kLocal>(rp, H, px, py, w.addr0, sum_s, sum_ss, sum_rs, cX, cY);
     } else if constexpr (kApprox) {
         ncc_fixed_moments<kQuad, kRecipApprox, kTiled, Ref>(fa, vc, rp, H, px, py, sum_s, sum_ss, sum_rs);
     } else if (__builtin_expect(fast_body, 1)) {

@@ -4,6 +4,11 @@ SURVEY.md section 8(d): analytic scene rendered by exact ray/plane intersection,
 `K = [f 0 cx; 0 f cy; 0 0 1]`, `f = 0.9 W`, procedural texture (sum of four sinusoid products) with
 optional textureless rectangles + per-view noise, quantised to 8 bit like a decoded JPEG
 (APD.cpp:410-413 reads uint8 and converts to float).  Works on CPU or GPU torch tensors.
+
+The default scene (two slanted Lambertian planes every source sees completely) is the best case of the path's shortcuts.  HARD is
+the other end, still analytic: slanted slabs floating in front of the planes (depth steps, occlusions: a source sees the
+background where the reference sees a slab and the other way round), a per-view gain / offset, a wider camera ring whose
+sources aim off the target so that parts of the reference frame project outside a source (APD.cu:546-548 returns 2.0 there).
 """
 import math
 
@@ -37,11 +42,18 @@ class Scene:
         return [im.detach().cpu().numpy() for im in self.images]
 
 
+HARD = dict(clutter=14, gain=0.10, baseline=0.10, aim_jitter=0.30)
+
+
 def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, baseline=0.06,
-               ref_view=0, device="cpu", noise=1.5, keep_view_depths=False):
+               ref_view=0, device="cpu", noise=1.5, keep_view_depths=False, clutter=0, gain=0.0, aim_jitter=0.0):
     """Render view `ref_view` of a ring of cameras as the reference and `num_src` neighbours.
 
     textureless: fraction (0..~0.4) of the surface covered by low-texture rectangles.
+    clutter: number of slanted rectangular slabs at depths 1.25..1.85 in front of the planes (depth steps + occlusions).
+    gain: per-view photometric change, grey = 128 + (1 + g) * texture + 64 * o with g, o uniform in [-gain, gain] (the reference view keeps g = o = 0).
+    aim_jitter: every source looks at the target displaced by up to this many scene units in x and y (sources lose overlap).
+    `make_scene(..., **HARD)` is the hard preset of the bench's *_hard workloads and of the parity tests that use it.
     """
     rng = np.random.RandomState(seed)
     f = 0.9 * width
@@ -61,7 +73,11 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
             rad = baseline * (1 + (j % 3)) * (0.5 if k == 0 else 1.0)
             c = np.array([rad * math.cos(ang), rad * math.sin(ang), 0.02 * math.sin(1.3 * j)])
         centers.append(c)
-        rots.append(_lookat_rotation(c, target) if (rotate and not (k == 0 and ref_view == 0)) else np.eye(3))
+        aim = target
+        if aim_jitter > 0 and k > 0:
+            jr = np.random.RandomState(7919 * seed + 31 * j + 3)
+            aim = target + np.array([jr.uniform(-aim_jitter, aim_jitter), jr.uniform(-aim_jitter, aim_jitter), 0.0])
+        rots.append(_lookat_rotation(c, aim) if (rotate and not (k == 0 and ref_view == 0)) else np.eye(3))
     # texture parameters (wavelengths in reference pixels at depth 2)
     pix = 2.0 / f
     lam = np.array([5.0, 9.0, 17.0, 31.0]) * pix
@@ -76,6 +92,20 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
             x0 = rng.uniform(-0.8, 0.8 - side) * (width / f)
             y0 = rng.uniform(-0.8, 0.8 - side) * (height / f)
             rects.append((x0, y0, x0 + side, y0 + side * height / width))
+    # slabs: (normal, d, x0, x1, y0, y1, texture shift x, y); a bounded piece of the plane n.P + d = 0
+    slabs = []
+    half_w, half_h = 0.5 * width / f, 0.5 * height / f   # half extent of the frame per unit depth
+    for _ in range(int(clutter)):
+        z = rng.uniform(1.25, 1.85)
+        sx, sy = rng.uniform(0.05, 0.22) * 2 * half_w * z, rng.uniform(0.05, 0.22) * 2 * half_h * z
+        mx, my = rng.uniform(-0.95, 0.95) * half_w * z, rng.uniform(-0.95, 0.95) * half_h * z
+        n = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 1.0])
+        d = -float(n @ np.array([mx, my, z]))
+        slabs.append((n, d, mx - 0.5 * sx, mx + 0.5 * sx, my - 0.5 * sy, my + 0.5 * sy, rng.uniform(-3, 3), rng.uniform(-3, 3)))
+    gains = [(0.0, 0.0)]
+    for k in range(1, num_src + 1):
+        gr = np.random.RandomState(104729 * seed + 13 * (ref_view + k) + 1)
+        gains.append((gr.uniform(-gain, gain), gr.uniform(-gain, gain)) if gain > 0 else (0.0, 0.0))
 
     dev = torch.device(device)
     dt = torch.float64
@@ -97,12 +127,26 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
             s = num / den
             s = torch.where(s > 1e-6, s, torch.full_like(s, 1e9))
             best_s = s if best_s is None else torch.minimum(best_s, s)
+        shift_x = shift_y = None
+        for (n, d, x0, x1, y0, y1, ox, oy) in slabs:
+            num = -(float(n @ c) + d)
+            den = n[0] * dw[0] + n[1] * dw[1] + n[2] * dw[2]
+            s = num / den
+            hx, hy = cc[0] + s * dw[0], cc[1] + s * dw[1]
+            hit = (s > 1e-6) & (hx >= x0) & (hx <= x1) & (hy >= y0) & (hy <= y1) & (s < best_s)
+            best_s = torch.where(hit, s, best_s)
+            if shift_x is None:
+                shift_x, shift_y = torch.zeros_like(best_s), torch.zeros_like(best_s)
+            shift_x = torch.where(hit, torch.full_like(shift_x, ox), shift_x)
+            shift_y = torch.where(hit, torch.full_like(shift_y, oy), shift_y)
         P = [cc[i] + best_s * dw[i] for i in range(3)]
         if k == 0:
             gt_depth = best_s.to(torch.float32)  # camera-frame z: ray has z=1 in camera coordinates
         if keep_view_depths:
             view_depths.append(best_s.to(torch.float32))
         X, Y = P[0], P[1]
+        if shift_x is not None:   # a slab carries the same procedural texture, displaced: no continuation across its edge
+            X, Y = X + shift_x, Y + shift_y
         tex = torch.zeros_like(X)
         for q in range(4):
             u = X * math.cos(phi[q]) + Y * math.sin(phi[q])
@@ -114,6 +158,8 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
             inside = (X >= x0) & (X <= x1) & (Y >= y0) & (Y <= y1)
             scale = torch.where(inside, torch.full_like(scale, 0.03), scale)
         img = 128.0 + tex * scale
+        if gains[k] != (0.0, 0.0):
+            img = 128.0 + (1.0 + gains[k][0]) * tex * scale + 64.0 * gains[k][1]
         if noise > 0:
             g = torch.Generator(device="cpu")
             g.manual_seed(1000 * seed + 17 * (ref_view + k) + 5)

@@ -60,17 +60,29 @@ WORKLOADS = {
 APD_WORKLOADS = {"eth3d_pipes_fullres_10src_apd": "eth3d_pipes_fullres_10src", "synthetic_4096x3072_8src_apd": "synthetic_4096x3072_8src",
                  "small_apd": "small"}
 WORKLOADS.update({k: WORKLOADS[v] for k, v in APD_WORKLOADS.items()})
+# <name>_hard: the same shape on synth.HARD -- slabs in front of the planes (depth steps, occlusions), per-view gain / offset, a wider
+# camera ring whose sources aim off the target (parts of the frame project outside a source).  The default scene is the best case of
+# the LDS windows and the refinement early-outs; these lines put the other end on the same clock.
+HARD_SUFFIX = "_hard"
 
 
 def resolve_workload(name):
     """Named workloads above, or an ad-hoc shape for tuning runs: custom_<W>x<H>_<N>src[_apd]."""
     import re
+    if name.endswith(HARD_SUFFIX):
+        name = name[:-len(HARD_SUFFIX)]
     if name in WORKLOADS:
         return WORKLOADS[name], name in APD_WORKLOADS
     m = re.match(r"^custom_(\d+)x(\d+)_(\d+)src(_apd)?$", name)
     if not m:
-        raise SystemExit("bench.py: unknown workload %r (named: %s; or custom_<W>x<H>_<N>src[_apd])" % (name, ", ".join(sorted(WORKLOADS))))
+        raise SystemExit("bench.py: unknown workload %r (named: %s; or custom_<W>x<H>_<N>src[_apd]; any of them with the suffix _hard)"
+                         % (name, ", ".join(sorted(WORKLOADS))))
     return (int(m.group(1)), int(m.group(2)), int(m.group(3))), m.group(4) is not None
+
+
+def scene_kwargs(synth, name):
+    """Scene preset of a workload name: synth.HARD for <name>_hard, the default two-plane scene otherwise."""
+    return dict(synth.HARD) if name.endswith(HARD_SUFFIX) else {}
 
 
 def algorithmic_bytes_per_weak_pixel(num_src):
@@ -177,7 +189,7 @@ class SweepWorkload:
             view = ctx.rank + slot * ctx.world
             keep = views_per_gpu == 1 and any(e[1] == name and e[4] == "geometric" for e in PASS_WORKLOADS)   # a geometric whole pass follows
             sc = ctx.synth.make_scene(W, H, N, seed=0, ref_view=view, device=ctx.dev, textureless=0.2 if self.apd_mode else 0.0,
-                                      keep_view_depths=keep)
+                                      keep_view_depths=keep, **scene_kwargs(ctx.synth, name))
             cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
             dmin, dmax = 0.6 * sc.depth_min, 1.2 * sc.depth_max
             if keep:
@@ -437,6 +449,12 @@ class SweepWorkload:
         h.profile_enable(False)
         elapsed = sum(per_pass)
         rank_ms = ctx.gather_scalar(t_run / passes * 1e3)
+        d0 = torch.empty((H, W), device=ctx.dev, dtype=torch.float32)   # after the region: what the pass left, against the analytic depth
+        h.export_depth_normal(d0, None)
+        torch.cuda.synchronize()
+        gt = self.gt[0]
+        within = float((((d0 - gt).abs() / gt)[8:-8, 8:-8] < 0.01).float().mean().item())
+        del d0
         kernel_ms = {pkg.KERNEL_NAMES[k]: round(v[0] / passes, 3) for k, v in sorted(prof.items())}
         total_kernel = sum(kernel_ms.values())
         mpix = W * H / 1e6
@@ -460,6 +478,7 @@ class SweepWorkload:
             "pass_kernels": {"K14": pass_kernel_roofline(pkg, prof, pkg.K14, "k14", self.name, kind, self.opts, self.seed),
                              "K15": pass_kernel_roofline(pkg, prof, pkg.K15, "k15", self.name, kind, self.opts, self.seed)},
             "rank_ms_per_pass": [round(v, 3) for v in rank_ms],
+            "quality_within_1pct_depth": round(within, 4),
             "setup_s": round(self.setup_s, 2),
         }
 
@@ -603,6 +622,8 @@ SUB_WORKLOADS = [
     ("configs1_office_6iter", "eth3d_office_fullres_8src", 6, 1, False, 1),        # configs[1] at its own six iterations
     ("configs1_office_ref_pass_3iter", "eth3d_office_fullres_8src", 3, 1, False, 1),  # ... at the reference's default pass (main.cpp:183)
     ("configs2_pipes_apd_3iter", "eth3d_pipes_fullres_10src_apd", 3, 1, False, 1),  # configs[2]: adaptive patches on (K9/K10 roofline)
+    ("configs1_office_hard_6iter", "eth3d_office_fullres_8src_hard", 6, 1, False, 1),  # configs[1] on the hard scene (occlusions, gain, lost overlap)
+    ("configs2_pipes_hard_apd_3iter", "eth3d_pipes_fullres_10src_apd_hard", 3, 1, False, 1),  # configs[2] on the hard scene
     ("configs4_synthetic_16src_8iter", "synthetic_4096x3072_16src", 8, 1, False, 1),  # configs[4] shape, one replica per GPU
     ("configs3_tt1080p_20iter", "tt_family_1080p_10src", 20, 5, False, 1),          # configs[3] frame size, sweep only
     ("configs3_tt1080p_pass_with_exchange", "tt_family_1080p_10src", 3, 1, True, 2),  # configs[3] as the sharded scheduler runs it:
@@ -617,6 +638,7 @@ PASS_ITERATIONS = 3   # PatchMatchParams::max_iterations of the reference (main.
 PASS_WORKLOADS = [   # (key, workload, timed passes, warm-up passes, kind)
     ("configs2_pipes_apd_whole_pass", "eth3d_pipes_fullres_10src_apd", 2, 1, "photometric"),
     ("configs2_pipes_apd_geometric_pass", "eth3d_pipes_fullres_10src_apd", 2, 1, "geometric"),
+    ("configs2_pipes_hard_whole_pass", "eth3d_pipes_fullres_10src_apd_hard", 2, 1, "photometric"),
 ]
 
 

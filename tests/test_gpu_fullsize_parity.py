@@ -61,9 +61,9 @@ def _weak_windows(weak, w=128, hh=80):
     return wins
 
 
-def _scene(synth, W, H, N, textureless=0.0):
+def _scene(synth, W, H, N, textureless=0.0, **kw):
     import torch
-    sc = synth.make_scene(W, H, N, seed=0, device=torch.device("cuda", 0), textureless=textureless)
+    sc = synth.make_scene(W, H, N, seed=0, device=torch.device("cuda", 0), textureless=textureless, **kw)
     imgs = sc.images_numpy()
     del sc.images[:]
     torch.cuda.empty_cache()
@@ -117,6 +117,61 @@ def test_configs2_pipes_fullres_10src_apd_pass(gpu_pkg, ob, synth, record_proper
     record_property("weak_fraction", weak_fraction)
     record_property("max_neighbour_distance_px", int(far.max()))
     assert far.max() > 100
+    assert n == 20
+    h.close()
+    o.close()
+
+
+def _edge_windows(gt, count=4, w=160, hh=96):
+    """Windows centred on depth steps of the reference view (slab edges: a source sees the background where the reference sees the
+    slab): the `count` strongest steps at least 600 px apart, away from the frame border."""
+    H, W = gt.shape
+    step = np.zeros((H, W), np.float32)
+    step[:, 1:] = np.abs(gt[:, 1:] - gt[:, :-1])
+    step[1:, :] = np.maximum(step[1:, :], np.abs(gt[1:, :] - gt[:-1, :]))
+    step[:200, :] = step[-200:, :] = 0
+    step[:, :300] = step[:, -300:] = 0
+    wins = []
+    for _ in range(count):
+        cy, cx = np.unravel_index(int(np.argmax(step)), step.shape)
+        if step[cy, cx] < 0.05:
+            break
+        wins.append((cx - w // 2, cy - hh // 2, cx + w // 2, cy + hh // 2))
+        step[max(cy - 600, 0):cy + 600, max(cx - 600, 0):cx + 600] = 0
+    return wins
+
+
+def test_configs2_pipes_fullres_10src_apd_pass_on_the_hard_scene(gpu_pkg, ob, synth, record_property):
+    """configs[2] at full size on synth.HARD (the bench's *_hard lines): slabs in front of the planes, per-view gain / offset, sources
+    aiming off the target.  REFINE_INIT + APD pass (K1..K5, two iterations of K6..K10, K11..K15) on the WEAK map a FIRST_INIT pass
+    leaves; oracle windows across four depth steps (LDS windows staged over an occlusion edge, lanes of one wave landing on both
+    sides of it in the sources), on the frame corners and inside a textureless region."""
+    W, H, N = 6200, 4130, 10
+    sc, imgs = _scene(synth, W, H, N, textureless=0.2, **synth.HARD)
+    gt = sc.gt_depth.cpu().numpy()
+    p0 = common.base_params(sc, N, max_iterations=3, seed=12345, weak_peak_radius=6)
+    h0 = common.make_handle(gpu_pkg, sc, imgs, N, p0)
+    h0.run()
+    planes, weak, views = h0.download()
+    h0.close()
+    prior = common.postprocess(planes, weak, views, p0["depth_min"], p0["depth_max"])
+    weak_fraction = float((prior[2] == 0).mean())
+    good = float(((np.abs(planes[..., 3] - gt) / gt)[8:-8, 8:-8] < 0.01).mean())
+    record_property("weak_fraction", weak_fraction)
+    record_property("within_1pct_after_first_pass", good)
+    assert 0.05 < weak_fraction < 0.7, weak_fraction
+    assert 0.5 < good < 0.999, good   # a hard scene: the first pass must NOT converge everywhere
+    p = common.base_params(sc, N, max_iterations=2, seed=12346, state=1, use_APD=1, weak_peak_radius=6, rotate_time=4,
+                           ransac_threshold=0.01 - 0.00125 * 3)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p, prior=prior)
+    o = common.make_oracle(ob, sc, imgs, N, p, prior=prior)
+    assert h.weak_count == o.weak_count > 0
+    edges = _edge_windows(gt)
+    assert len(edges) >= 3, edges
+    windows = edges + _fixed_windows(W, H, 160, 96)[:4] + _weak_windows(prior[2], 160, 96)
+    log = []
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(2, True), windows, "configs[2] hard", log)
+    print("\n".join(log))
     assert n == 20
     h.close()
     o.close()

@@ -172,6 +172,20 @@ def test_randomised_three_pass_cases(gpu_pkg, ob, synth, case):
     mod.run_case(case)
 
 
+@pytest.mark.parametrize("case", [1, 4, 7, 12, 22, 33])
+def test_randomised_three_pass_cases_on_hard_scenes(gpu_pkg, ob, synth, case):
+    """The same sweep on synth.HARD-like scenes (APD_FUZZ_HARD=1): slabs in front of the planes (depth steps, occlusions), per-view
+    gain / offset, sources aiming off the target so that parts of the frame project outside them (APD.cu:546-548 returns 2.0
+    there) -- the windows, early-outs and view selection away from their best case.  Full sweep: profiles/r05/parity_fuzz_hard_*.txt."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("parity_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                               "tools", "parity_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert "hard(" in mod.run_case(case, hard=True)
+
+
 @pytest.mark.parametrize("W,H,N,float_images", [(80, 60, 20, False), (72, 56, 12, True), (64, 48, 31, False)])
 def test_many_source_views_three_pass(gpu_pkg, ob, synth, W, H, N, float_images):
     """The 16- and 32-view instantiations of the sweep kernels (the reference allows MAX_IMAGES = 32 including the

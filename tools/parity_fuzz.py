@@ -1,6 +1,8 @@
 """Randomised bit-exact parity sweep: HIP path vs CPU oracle over random sizes, view counts, scenes and seeds through the
 three pass kinds (FIRST_INIT, REFINE_INIT + APD, REFINE_ITER + APD + geometric term), 8-bit and float images, compared
-after every pass (all state arrays).  Usage: [APD_FUZZ_SCALE=3] python tools/parity_fuzz.py [cases] [first_seed]"""
+after every pass (all state arrays).  Usage: [APD_FUZZ_SCALE=3] [APD_FUZZ_HARD=1] python tools/parity_fuzz.py [cases] [first_seed]
+APD_FUZZ_HARD=1: every case on synth.HARD-like scenes (slabs in front of the planes: depth steps and occlusions; per-view gain /
+offset; sources aiming off the target), with the clutter, gain and aim drawn per case."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,9 +14,11 @@ from oracle import binding as ob
 import common
 
 
-def run_case(case):
+def run_case(case, hard=None):
     """One random configuration through the three pass kinds; raises AssertionError on the first differing state array."""
     rng = np.random.RandomState(1000 + case)
+    if hard is None:
+        hard = os.environ.get("APD_FUZZ_HARD", "0") == "1"
     scale = float(os.environ.get("APD_FUZZ_SCALE", "1"))  # larger frames: more tiles, supertiles and list blocks per launch (the oracle takes scale^2 longer)
     W, H = int(rng.randint(36, 260) * scale), int(rng.randint(30, 180) * scale)
     N = int(rng.randint(1, 10))
@@ -23,7 +27,14 @@ def run_case(case):
     tl = float(rng.choice([0.0, 0.15, 0.3]))
     iters = int(rng.randint(1, 4))
     float_images = bool(rng.rand() < 0.35)
-    sc, imgs = common.scene_inputs(synth, W, H, N, seed=case, textureless=tl, rotate=bool(rng.rand() < 0.8))
+    rotate = bool(rng.rand() < 0.8)
+    scene_kw = {}
+    if hard:
+        hr = np.random.RandomState(77000 + case)   # its own stream: the easy cases keep their draws
+        scene_kw = dict(clutter=int(hr.randint(3, 20)), gain=float(hr.choice([0.0, 0.05, 0.1, 0.2])), baseline=float(hr.choice([0.06, 0.1, 0.14])),
+                        aim_jitter=float(hr.choice([0.0, 0.2, 0.4, 0.7])))
+    sc = synth.make_scene(W, H, N, seed=case, textureless=tl, rotate=rotate, **scene_kw)
+    imgs = sc.images_numpy()
     if float_images:  # what a resampled pyramid level holds: non-integer grey values
         imgs = [(im * np.float32(0.731) + np.float32(3.3) * np.sin(np.arange(im.size, dtype=np.float32).reshape(im.shape) * 0.01)).astype(np.float32)
                 for im in imgs]
@@ -42,9 +53,11 @@ def run_case(case):
     recycle = bool(rng.rand() < 0.5)
     split = bool(rng.rand() < 0.5)
     share = bool(split and rng.rand() < 0.5)   # images created once on the device (apd_image_create) and uploaded by reference
-    label = "case %d: %dx%d N=%d textureless=%.2f iters=%d radii=%s %s%s%s" % (case, W, H, N, tl, iters, "/".join(str(q["weak_peak_radius"]) for q in passes),
-                                                                             "float" if float_images else "8-bit", " recycled" if recycle else "",
-                                                                             (" shared" if share else " split") if split else "")
+    label = "case %d: %dx%d N=%d textureless=%.2f iters=%d radii=%s %s%s%s%s" % (case, W, H, N, tl, iters, "/".join(str(q["weak_peak_radius"]) for q in passes),
+                                                                               "float" if float_images else "8-bit", " recycled" if recycle else "",
+                                                                               (" shared" if share else " split") if split else "",
+                                                                               (" hard(clutter %d gain %.2f baseline %.2f aim %.1f)" % (
+                                                                                   scene_kw["clutter"], scene_kw["gain"], scene_kw["baseline"], scene_kw["aim_jitter"])) if hard else "")
     cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
     shared = [pkg.SharedImage(W, H, im) for im in imgs] if share else None
     h = None

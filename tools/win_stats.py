@@ -1,5 +1,5 @@
 """Window hit statistics of the K6/K7 LDS-window kernel, per iteration (library built with -DAPD_LAB_WIN_STATS).
-Usage: python tools/win_stats.py [W H N iters]"""
+Usage: python tools/win_stats.py [--hard] [W H N iters]      --hard: the synth.HARD scene (occlusions, gain, lost overlap)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,8 +7,11 @@ import numpy as np, torch
 import __graft_entry__ as ge
 pkg = ge.load_package()
 from apd_mvs_amd import synth
+hard = "--hard" in sys.argv
+if hard:
+    sys.argv.remove("--hard")
 W, H, N, iters = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (2048, 1536, 8, 4)))
-sc = synth.make_scene(W, H, N, seed=0, device="cuda")
+sc = synth.make_scene(W, H, N, seed=0, device="cuda", **(synth.HARD if hard else {}))
 cams = [pkg.make_camera(sc.K[i], sc.R[i], sc.t[i], W, H, sc.depth_min, sc.depth_max) for i in range(N + 1)]
 p = pkg.default_params(num_images=N + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0, state=pkg.FIRST_INIT,
                        max_iterations=iters, seed=12345)
