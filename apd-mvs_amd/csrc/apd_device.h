@@ -1219,7 +1219,11 @@ __device__ __forceinline__ void subpatch_issue_quad(const Homography &H, global_
     APD_STAGE();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
+#if APD_K910_SUBPATCH_TILED   // lab build: `srcq` is the tiled copy and `qpitch` its tiles per tile row (profiles/r05/ab_k910_tiled.txt)
+        qx[k] = (int)quad_tiled_byte_offset(qx[k], qy[k], qpitch);
+#else
         qx[k] = (int)quad_byte_offset(qx[k], qy[k], (int)qpitch, (int)(qpitch + kRowEntryBytes));
+#endif
     }
     APD_STAGE();
 #pragma unroll

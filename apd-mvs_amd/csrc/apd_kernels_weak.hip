@@ -615,8 +615,13 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
     } else {
         center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
     }
+#if APD_K910_SUBPATCH_TILED
+    const global_quad_ptr srcq = (global_quad_ptr)vc.quad_tiled;   // needs --opt tiled_copy=2 (the copy is built for every pass)
+    const unsigned qpitch = quad_tiles_x(fa.W);
+#else
     const global_quad_ptr srcq = (global_quad_ptr)vc.quad;
     const unsigned qpitch = quad_row_pitch_bytes(fa.W);
+#endif
     const unsigned fpitch = 16u * (unsigned)(fa.W + 1);
     const global_fquad_ptr srcf = (global_fquad_ptr)vc.fquad;
     const int wm1 = fa.W - 1, hm1 = fa.H - 1;

@@ -121,6 +121,10 @@
 #ifndef APD_K910_WAVES
 #define APD_K910_WAVES 2
 #endif
+#ifndef APD_K910_SUBPATCH_TILED
+#define APD_K910_SUBPATCH_TILED 0  // 1 (A/B runs, with --opt tiled_copy=2): the 3 x 3 stride-5 sub-patch taps gather from the 7 x 8 pair tiles instead
+                                   // of the row-major pairs.  Measured in round 5 (profiles/r05/ab_k910_tiled.txt), see DESIGN.md section 6
+#endif
 #ifndef APD_K910_COMPACT_REFINE
 #define APD_K910_COMPACT_REFINE 1
 #endif
