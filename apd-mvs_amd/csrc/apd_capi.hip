@@ -93,6 +93,7 @@ struct apd_context {
     // kernels that walk them (K3, K8, K9, K10) are refused until apd_upload_prior / apd_reset -- the reference builds all three
     // once per object from the map it loads (APD.cpp:526-537) and never runs a second pass on it
     bool weak_map_stale = false;
+    bool first_half_done = false;  // apd_run_before_depths ran on this upload (cleared by reset / upload): apd_run_after_depths needs it
     int options[APD_OPT_COUNT] = {0, 1, 1, 1, 1, 1};  // defaults of include/apd_mi355x.h
     int *neighbours_map = nullptr;
     size_t neighbours_cap = 0;
@@ -375,6 +376,7 @@ int apd_reset(apd_handle c, const apd_params *params)
     c->weak_count = 0;
     c->weak_lists_valid = false;
     c->weak_map_stale = false;
+    c->first_half_done = false;
     const int st = initial_state(c);
     if (st != APD_OK) {
         return st;
@@ -492,6 +494,7 @@ static int finish_upload(apd_context *c, int num_images, const apd_camera *camer
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->views_uploaded = true;
     c->depths_pending = defer_depths;
+    c->first_half_done = false;
     refresh_frame_args(c);
     return APD_OK;
 }
@@ -860,6 +863,7 @@ int apd_upload_prior(apd_handle c, const float *planes4, const uint32_t *selecte
     HIP_TRY(hipMemsetAsync(c->neighbours, 0, c->neighbours_cap * APD_NEIGHBOUR_NUM * sizeof(short2), c->stream));
     c->weak_lists_valid = false;
     c->weak_map_stale = false;
+    c->first_half_done = false;
     if (need > c->weak_list_cap) {  // one colour holds at most every WEAK pixel of the map uploaded above (K4 only removes some)
         for (int k = 0; k < 2; ++k) {
             hipFree(c->weak_list[k]);
@@ -910,13 +914,7 @@ static void drain_profile(apd_context *c)
 
 static int launch_one(apd_context *c, int kernel_id, int iter)
 {
-    apd_context::PendingEvent pe{kernel_id, nullptr, nullptr};
-    if (c->profiling) {
-        pe.start = take_event(c);
-        pe.stop = take_event(c);
-        HIP_TRY(hipEventRecord(pe.start, c->stream));
-    }
-    hipError_t e;
+    // refusals first: a refused launch must leave nothing behind (no event taken from the pool, nothing recorded on the stream)
     if (c->weak_map_stale && (kernel_id == APD_K3_GEN_NEIGHBOURS || kernel_id == APD_K8_RANSAC_FIT_PLANE ||
                               kernel_id == APD_K9_BLACK_UPDATE_WEAK || kernel_id == APD_K10_RED_UPDATE_WEAK)) {
         return fail(APD_ERR_STATE, "kernel %d walks the WEAK lists / neighbour table of the last apd_upload_prior, but weak_info has been "
@@ -926,6 +924,17 @@ static int launch_one(apd_context *c, int kernel_id, int iter)
                               kernel_id == APD_K14_DEPTH_TO_WEAK || kernel_id == APD_K15_LOCAL_REFINE)) {
         return fail(APD_ERR_STATE, "kernel %d reads the sources' depth maps (geometric term): call apd_upload_depths first", kernel_id);
     }
+    apd_context::PendingEvent pe{kernel_id, nullptr, nullptr};
+    if (c->profiling) {
+        pe.start = take_event(c);
+        pe.stop = take_event(c);
+        if (hipEventRecord(pe.start, c->stream) != hipSuccess) {
+            c->event_pool.push_back(pe.start);
+            c->event_pool.push_back(pe.stop);
+            return fail(APD_ERR_HIP, "hipEventRecord failed before kernel %d", kernel_id);
+        }
+    }
+    hipError_t e;
     switch (kernel_id) {
     case APD_K3_GEN_NEIGHBOURS:
     case APD_K9_BLACK_UPDATE_WEAK:
@@ -1084,14 +1093,32 @@ static int check_run(apd_context *c, const char *who)
 
 int apd_run(apd_handle c)
 {
-    const int rc = check_run(c, "apd_run");
-    return rc ? rc : run_schedule(c, true, true);
+    int rc = check_run(c, "apd_run");
+    if (rc) {
+        return rc;
+    }
+    if (c->depths_pending) {   // refused up front: a whole pass would otherwise run K1..K8 and fail at the first kernel that reads a depth map
+        return fail(APD_ERR_STATE, "apd_run: the depth maps of this geometric pass are still pending (apd_upload_views_split / _shared): "
+                                   "call apd_upload_depths first, or drive the pass with apd_run_before_depths / apd_run_after_depths");
+    }
+    if (c->first_half_done) {
+        return fail(APD_ERR_STATE, "apd_run: apd_run_before_depths already ran on this upload; finish the pass with apd_run_after_depths");
+    }
+    return run_schedule(c, true, true);
 }
 
 int apd_run_before_depths(apd_handle c)
 {
-    const int rc = check_run(c, "apd_run_before_depths");
-    return rc ? rc : run_schedule(c, true, false);
+    int rc = check_run(c, "apd_run_before_depths");
+    if (rc) {
+        return rc;
+    }
+    if (c->first_half_done) {
+        return fail(APD_ERR_STATE, "apd_run_before_depths: already ran on this upload");
+    }
+    rc = run_schedule(c, true, false);
+    c->first_half_done = rc == APD_OK;
+    return rc;
 }
 
 int apd_run_after_depths(apd_handle c)
@@ -1100,10 +1127,15 @@ int apd_run_after_depths(apd_handle c)
     if (rc) {
         return rc;
     }
+    if (!c->first_half_done) {   // K9 / K10 / K14 / K15 on planes and random states nobody initialised
+        return fail(APD_ERR_STATE, "apd_run_after_depths: apd_run_before_depths has not run on this upload");
+    }
     if (c->depths_pending) {
         return fail(APD_ERR_STATE, "apd_run_after_depths: the depth maps of this geometric pass have not been uploaded (apd_upload_depths)");
     }
-    return run_schedule(c, false, true);
+    rc = run_schedule(c, false, true);
+    c->first_half_done = false;   // the pass is complete (or failed): a second call is refused
+    return rc;
 }
 
 int apd_synchronize(apd_handle c)

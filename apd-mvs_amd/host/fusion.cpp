@@ -8,7 +8,9 @@
 //
 // Outside the PatchMatch path proper.  Like the reference, the images are re-read in colour for the
 // point colours (cv::imread(IMREAD_COLOR), APD.cpp:859; host/jpeg_gray.cpp decodes to the same BGR bytes as libjpeg).
+#include <atomic>
 #include <chrono>
+#include <sstream>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -85,16 +87,20 @@ void RunFusion(const path &dense_folder, const std::vector<Problem> &problems) {
 // nullptr with 0 x 0 (read the files).
 namespace {
 
+// log: where the reference's progress lines go ("Reading image ...", "Fusing image ...", APD.cpp:855, :899); the prefetch worker
+// collects them and RunFusionOnDevice prints them where the reference would, after the passes' own lines.
 bool prepare_fusion_inputs(const path &dense_folder, const std::vector<Problem> &problems, const std::vector<FinalMaps> *maps, int map_cols,
-                           int map_rows, std::vector<FusionView> &views, std::vector<std::vector<int>> &sources, unsigned threads = 0)
+                           int map_rows, std::vector<FusionView> &views, std::vector<std::vector<int>> &sources, unsigned threads = 0,
+                           std::ostream *log = nullptr)
 {
+    std::ostream &out = log ? *log : std::cout;
     const bool on_device = !maps && map_cols > 0 && map_rows > 0;
     views.assign(problems.size(), FusionView());
     std::unordered_map<int, int> index_of_id;
     const path block_folder = dense_folder / path("blocks");
     const bool use_block = std::filesystem::exists(block_folder);  // APD.cpp:849-853
     for (size_t i = 0; i < problems.size(); ++i) {
-        std::cout << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
+        out << "Reading image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
         index_of_id.emplace(problems[i].ref_image_id, (int)i);
     }
     // the views are independent here: decode, read and rescale them on several host threads
@@ -170,7 +176,7 @@ bool prepare_fusion_inputs(const path &dense_folder, const std::vector<Problem> 
     }
     sources.assign(problems.size(), std::vector<int>());
     for (size_t i = 0; i < problems.size(); ++i) {
-        std::cout << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
+        out << "Fusing image " << std::setw(8) << std::setfill('0') << i << "..." << std::endl;
         for (int id : problems[i].src_image_ids) {
             // A source without a problem of its own has no maps to check against and is skipped.  (The reference's
             // imageIdToindexMap[id] default-inserts 0 for it, APD.cpp:919, i.e. silently checks against view 0 instead.)
@@ -221,9 +227,11 @@ struct FusionPrefetch {
     std::vector<const float *> imgs;
     std::vector<const uint8_t *> blocks;
     bool any_block = false, ok = false;
+    std::atomic<bool> failed{false};  // set by the worker as soon as it gives up: RunMultiDevice polls it between levels (FusionInputsFailed)
     int channels = 3;
     long long prepare_ms = 0;
     std::string error;
+    std::ostringstream log;           // the reference's progress lines, printed by RunFusionOnDevice
 };
 
 FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Problem> &problems, int device, int cols, int rows, unsigned threads)
@@ -236,7 +244,25 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
     f->rows = rows;
     f->worker = std::thread([f, threads]() {
         const auto t0 = std::chrono::steady_clock::now();
-        if (!prepare_fusion_inputs(f->dense_folder, f->problems, nullptr, f->cols, f->rows, f->views, f->sources, threads)) {
+        // every way out of this worker releases the upload stream and the staging buffer, and a failure is published at once
+        void *stream = nullptr, *staging = nullptr;
+        struct Guard {
+            FusionPrefetch *f;
+            void *&stream, *&staging;
+            ~Guard()
+            {
+                if (stream) {
+                    apd_stream_destroy(f->device, stream);
+                }
+                if (staging) {
+                    apd_host_free(staging);
+                }
+                if (!f->ok) {
+                    f->failed.store(true);
+                }
+            }
+        } guard{f, stream, staging};
+        if (!prepare_fusion_inputs(f->dense_folder, f->problems, nullptr, f->cols, f->rows, f->views, f->sources, threads, &f->log)) {
             f->error = "fusion inputs could not be read";
             return;
         }
@@ -247,11 +273,15 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
         f->blocks.assign(V, nullptr);
         auto upload = [&](const void *host, size_t bytes) -> void * {
             void *p = nullptr;
-            if (apd_device_malloc(f->device, bytes, &p) != APD_OK || apd_device_memcpy(f->device, p, host, bytes) != APD_OK) {
-                f->error = std::string("fusion: device upload failed: ") + apd_exchange_last_error();
+            if (apd_device_malloc(f->device, bytes, &p) != APD_OK) {
+                f->error = std::string("fusion: device allocation failed: ") + apd_exchange_last_error();
                 return nullptr;
             }
             f->owned.push_back(p);
+            if (apd_device_memcpy(f->device, p, host, bytes) != APD_OK) {
+                f->error = std::string("fusion: device upload failed: ") + apd_exchange_last_error();
+                return nullptr;
+            }
             return p;
         };
         // one allocation for every view's colour image: device allocations are not free while other threads launch kernels
@@ -266,16 +296,16 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
         // passes running beside it: a plain hipMemcpy of the pageable image, and just as much hipHostRegister + asynchronous copy +
         // unregister per image, cost the passes what the early start saved (8.2 -> 8.6 s): every map / unmap of host pages holds
         // the device's queues up; one mapping for the whole run does not.
-        void *stream = nullptr, *staging = nullptr;
-        if (apd_stream_create(f->device, &stream) != APD_OK || apd_host_alloc(image_bytes, &staging) != APD_OK) {
-            apd_stream_destroy(f->device, stream);
-            stream = staging = nullptr;
+        if (apd_stream_create(f->device, &stream) != APD_OK) {
+            stream = nullptr;
+        } else if (apd_host_alloc(image_bytes, &staging) != APD_OK) {
+            staging = nullptr;
         }
         for (int i = 0; i < V; ++i) {
             void *dst = (char *)all_images + (size_t)i * image_bytes;
             const void *src = f->views[i].image.data();
             int rc;
-            if (staging) {
+            if (stream && staging) {
                 memcpy(staging, src, image_bytes);
                 rc = apd_device_memcpy_async(f->device, stream, dst, staging, image_bytes);
                 rc = rc != APD_OK ? rc : apd_stream_synchronize(f->device, stream);
@@ -284,8 +314,6 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
             }
             if (rc != APD_OK) {
                 f->error = std::string("fusion: device upload failed: ") + apd_exchange_last_error();
-                apd_stream_destroy(f->device, stream);
-                apd_host_free(staging);
                 return;
             }
             f->imgs[i] = (const float *)dst;
@@ -298,12 +326,23 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
                 f->any_block = true;
             }
         }
-        apd_stream_destroy(f->device, stream);
-        apd_host_free(staging);
         f->prepare_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
         f->ok = true;
     });
     return f;
+}
+
+// true as soon as the prefetch worker has given up (unreadable colour image, device out of memory): the caller stops before the
+// next level instead of learning it after every pass has run
+bool FusionInputsFailed(const FusionPrefetch *f, std::string *why)
+{
+    if (!f || !f->failed.load()) {
+        return false;
+    }
+    if (why) {
+        *why = f->error;   // written before the flag was set
+    }
+    return true;
 }
 
 void CancelFusionInputs(FusionPrefetch *f)
@@ -342,6 +381,7 @@ void RunFusionOnDevice(FusionPrefetch *f, const std::vector<const float *> &dept
     }
     const path ply_path = f->dense_folder / path("APD") / path("APD.ply");
     const auto t_fuse = std::chrono::steady_clock::now();
+    std::cout << f->log.str();   // "Reading image ..." / "Fusing image ...": here, where the reference prints them (after the passes)
     std::cout << "Fusion inputs ready: prepared in " << f->prepare_ms << " ms behind the passes, waited "
               << std::chrono::duration_cast<std::chrono::milliseconds>(t_fuse - t_wait).count() << " ms" << std::endl;
     long long count = 0;

@@ -67,6 +67,8 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.no_fusion = true;
         } else if (a == "--late-fusion-inputs") {
             o.late_fusion_inputs = true;
+        } else if (a == "--scheduler-free-gb" && i + 1 < argc) {
+            o.scheduler_free_gb = atof(argv[++i]);
         } else if (a == "--clean-exit") {
             o.clean_exit = true;
         } else if (a == "--copy-images") {
@@ -291,6 +293,7 @@ int main(int argc, char **argv)
     // `APD dense_folder [gpu]`, the reference's command line: its order of views and its bytes, in memory when the folder fits the
     // device (InMemoryBytesPerPixel: level images, two sets of depth maps, every view's state, the handles of the views in flight, the
     // final maps and the fusion's buffers), through the files otherwise or with --files.
+    bool auto_in_memory = false;   // the in-memory scheduler was this function's choice, not the command line's
     if (!opt.files && !opt.in_memory && !opt.jacobi && opt.devices.size() == 1) {
         int w = 0, h = 0;
         size_t free_bytes = 0, total_bytes = 0;
@@ -299,9 +302,11 @@ int main(int argc, char **argv)
             for (const Problem &p : problems) {
                 max_src = std::max(max_src, p.src_image_ids.size());
             }
-            const int lanes = opt.ranks_per_device > 0 ? opt.ranks_per_device : DefaultLanes((size_t)w * h);
-            const double need = (double)w * h * InMemoryBytesPerPixel((int)ids.size(), (int)problems.size(), 1, lanes, (int)max_src);
+            const int lanes = InMemoryLanes(opt, w, h, (int)problems.size(), 1, true);   // the count RunMultiDevice will use
+            const double need = (double)w * h * InMemoryBytesPerPixel((int)ids.size(), (int)problems.size(), 1, lanes, (int)max_src, nullptr, nullptr,
+                                                                      !(opt.no_fusion || opt.late_fusion_inputs));
             opt.in_memory = need < 0.9 * (double)free_bytes;
+            auto_in_memory = opt.in_memory;
             if (!opt.in_memory) {
                 printf("%.1f GB of resident state against %.1f GB free on device %d: passing state through files\n", need / 1e9,
                        free_bytes / 1e9, opt.gpu_index);
@@ -316,15 +321,23 @@ int main(int argc, char **argv)
         printf("Start-up (pair.txt, image decode on several threads, device query): %lld ms\n",
                (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count());
         const int rc = RunMultiDevice(opt, problems);  // host/multi_device.cpp: in memory, views sharded over the device list
-        // Every file is written and closed.  Leaving through _Exit skips the one-by-one release of tens of gigabytes of device memory and
-        // the runtime's own teardown (half a second at 152 views): the driver reclaims a process's memory in one step.
-        // (--clean-exit returns normally: a profiler that writes its output from an exit handler -- rocprofv3 -- needs that.)
-        fflush(stdout);
-        fflush(stderr);
-        if (!opt.clean_exit) {
-            std::_Exit(rc);
+        if (rc == kExitDoesNotFit && auto_in_memory) {
+            // the plain `APD folder gpu` command line must process every folder the file driver can (free memory may have shrunk
+            // between the estimate above and the scheduler's own): nothing has been run or written yet, take the files
+            printf("in-memory scheduler refused the folder: passing state through files\n");
+            opt.in_memory = false;
+        } else {
+            // Every file is written and closed.  Leaving through _Exit skips the one-by-one release of tens of gigabytes of device memory
+            // and the runtime's own teardown (half a second at 152 views): the driver reclaims a process's memory in one step.
+            // (--clean-exit returns normally: a profiler that writes its output from an exit handler -- rocprofv3 -- needs that.)
+            const int code = rc == kExitDoesNotFit ? EXIT_FAILURE : rc;
+            fflush(stdout);
+            fflush(stderr);
+            if (!opt.clean_exit) {
+                std::_Exit(code);
+            }
+            return code;
         }
-        return rc;
     }
     int width = 0, height = 0;
     if (!CheckImages(problems, width, height)) {

@@ -173,11 +173,15 @@ int DefaultLanes(size_t pixels)
 // pass) -- and at the end the gathered final maps, their depth / normal split and the fusion's buffers.  Upper bound per pixel of
 // the finest level; main() compares it with the free memory before choosing this scheduler and every in-memory mode checks it
 // again here.
-double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources, double *passes_out, double *final_out)
+// fusion_prefetch: the colour images (3 floats per pixel and view) and block masks (1 B) of the fusion are uploaded to the first
+// device WHILE the passes run (StartFusionInputs), so they count towards the passes' footprint, not only the final stage's.
+double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources, double *passes_out, double *final_out,
+                             bool fusion_prefetch)
 {
     const double slots = (double)((num_views + num_ranks - 1) / num_ranks);
     const double m = (double)max_sources;
-    const double passes = 8.5 * num_images + 4.0 * slots * (1.0 + num_ranks) + 4.0 + 21.0 * slots + lanes * (21.0 + 107.0 + 25.0 + 4.0 * (m + 1.0));
+    const double passes = 8.5 * num_images + 4.0 * slots * (1.0 + num_ranks) + 4.0 + 21.0 * slots + lanes * (21.0 + 107.0 + 25.0 + 4.0 * (m + 1.0)) +
+                          (fusion_prefetch ? 13.0 * num_views : 0.0);
     const double final_stage = 21.0 * slots + (num_ranks > 1 ? 17.0 * slots * num_ranks : 0.0) + 16.0 * num_views + 21.0 * num_views + 8.0 * m + 40.0;
     if (passes_out) {
         *passes_out = passes;
@@ -186,6 +190,23 @@ double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int l
         *final_out = final_stage;
     }
     return std::max(passes, final_stage);
+}
+
+// Views in flight per rank of a run over `num_views` views on `num_ranks` ranks whose finest level is width x height: the larger of
+// what the finest and the coarsest pyramid level ask for (a coarse level's launches are small, more of its views fit the device side
+// by side), never more than a rank owns.  ONE function for main()'s choice of scheduler and for RunMultiDevice's own fit test: the
+// two used to count differently (6 against 4 at 1920 x 1080) and a folder main() had accepted could be refused here.
+int InMemoryLanes(const Options &opt, int width, int height, int num_views, int num_ranks, bool distinct_devices)
+{
+    const int round_num = opt.single_level ? 1 : RoundNum(width, height);
+    const int coarsest = opt.single_level ? 1 : 1 << (round_num - 1);
+    const int own = std::max(1, (num_views + num_ranks - 1) / num_ranks);
+    auto lanes_at = [&](size_t level_pixels) {
+        const int want = opt.ranks_per_device > 0 ? opt.ranks_per_device : (distinct_devices ? DefaultLanes(level_pixels) : 1);
+        return std::max(1, std::min(want, own));
+    };
+    return std::max(lanes_at((size_t)width * height),
+                    lanes_at((size_t)std::lround(width / (double)coarsest) * (size_t)std::lround(height / (double)coarsest)));
 }
 
 int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
@@ -253,23 +274,26 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         const int want = opt.ranks_per_device > 0 ? opt.ranks_per_device : (distinct ? DefaultLanes(level_pixels) : 1);
         return std::max(1, std::min(want, (V + G - 1) / G));
     };
-    const int coarsest = opt.single_level ? 1 : 1 << (round_num - 1);
-    const int lanes = std::max(lanes_at(pix0), lanes_at((size_t)std::lround(W0 / (double)coarsest) * (size_t)std::lround(H0 / (double)coarsest)));
+    const int lanes = InMemoryLanes(opt, W0, H0, V, G, distinct);
     const bool gauss_seidel = opt.in_memory;  // the reference's order of views (one rank); otherwise Jacobi over views
     bool release_before_fusion = true;
     printf("There are %d problems needed to be processed on %d rank(s), up to %d view(s) in flight per rank!\nRound nums: %d\n", V, G, lanes, round_num);
     {
         size_t free_bytes = 0, total_bytes = 0;
         double per_px_passes = 0, per_px_final = 0;
-        const double need = (double)pix0 * InMemoryBytesPerPixel(N, V, G, lanes, (int)max_src, &per_px_passes, &per_px_final);
+        const bool prefetch = !(opt.no_fusion || opt.late_fusion_inputs);
+        const double need = (double)pix0 * InMemoryBytesPerPixel(N, V, G, lanes, (int)max_src, &per_px_passes, &per_px_final, prefetch);
         const bool have_memory = apd_device_memory(devices[0], &free_bytes, &total_bytes) == APD_OK;
+        if (have_memory && opt.scheduler_free_gb > 0) {
+            free_bytes = std::min(free_bytes, (size_t)(opt.scheduler_free_gb * 1e9));
+        }
         // room for the passes' buffers AND the final maps at once: the handles, level images and depth sets are then left to the end of
         // the process instead of being released one hipFree (= one device synchronisation) at a time before the fusion
         release_before_fusion = !have_memory || (double)pix0 * (per_px_passes + per_px_final) > 0.8 * (double)free_bytes;
         if (have_memory && need > 0.9 * (double)free_bytes) {
             fprintf(stderr, "%.1f GB of resident state against %.1f GB free on device %d: this folder does not fit the in-memory scheduler "
                             "(use --files, more devices or fewer views in flight: --ranks 1)\n", need / 1e9, free_bytes / 1e9, devices[0]);
-            return EXIT_FAILURE;
+            return kExitDoesNotFit;   // main() falls back to the file-based loop when it had chosen this scheduler by itself
         }
     }
 
@@ -527,6 +551,12 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             size_t last = first;  // passes [first, last) run at one level
             while (last < plan.size() && plan[last].scale_size == plan[first].scale_size) {
                 ++last;
+            }
+            {   // the fusion's inputs are prepared behind the passes: if that has failed, stop now, not after every pass has run
+                std::string why;
+                if (FusionInputsFailed(fusion_inputs, &why)) {
+                    throw std::runtime_error(why.empty() ? "fusion inputs could not be prepared" : why);
+                }
             }
             if (plan[first].scale_size != level_scale) {
                 prepare_level(plan[first]);

@@ -27,6 +27,8 @@ struct Options {
     bool single_level = false, keep_maps = false, no_fusion = false;
     bool copy_images = false;         // --copy-images: handles copy and pack their images per (view, pass) instead of sharing the level images (A/B)
     bool clean_exit = false;          // --clean-exit: return from main() instead of _Exit (exit handlers run: profilers)
+    double scheduler_free_gb = 0;     // --scheduler-free-gb X: RunMultiDevice's own fit test counts at most X GB of free device memory (main()'s
+                                      // choice of scheduler still uses the device's figure: this is how a test reaches the fall-back to files)
     bool late_fusion_inputs = false;  // --late-fusion-inputs: colour decode + upload after the passes instead of behind them (A/B measurements)
 };
 
@@ -106,8 +108,10 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems);
 // Views in flight per device by frame size, and the device bytes per pixel (finest level) the in-memory scheduler keeps resident
 // on its busiest device (host/multi_device.cpp).
 int DefaultLanes(size_t pixels);
+int InMemoryLanes(const Options &opt, int width, int height, int num_views, int num_ranks, bool distinct_devices);
 double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources, double *passes_out = nullptr,
-                             double *final_out = nullptr);
+                             double *final_out = nullptr, bool fusion_prefetch = false);
+constexpr int kExitDoesNotFit = 75;  // RunMultiDevice: the folder does not fit the in-memory scheduler (nothing has been run or written)
 
 // APD.h:34 with the maps already in memory (index = problem index); RunFusion reads them from the result folders instead
 struct FinalMaps {
@@ -122,5 +126,6 @@ FusionPrefetch *StartFusionInputs(const path &dense_folder, const std::vector<Pr
 void RunFusionOnDevice(FusionPrefetch *inputs, const std::vector<const float *> &depths, const std::vector<const float *> &normals,
                        const std::vector<const uint8_t *> &weaks);
 void CancelFusionInputs(FusionPrefetch *inputs);
+bool FusionInputsFailed(const FusionPrefetch *inputs, std::string *why);
 
 #endif  // APD_MI355X_HOST_SCHEDULE_H_

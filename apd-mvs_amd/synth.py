@@ -113,6 +113,7 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
     images, Ks, Rs, ts = [], [], [], []
     gt_depth = None
     view_depths = [] if keep_view_depths else None
+    view_normals, view_textured = ([] if keep_view_depths else None), ([] if keep_view_depths else None)
     for k in range(num_src + 1):
         Rm, c = rots[k], centers[k]
         Rt = torch.tensor(Rm.T, device=dev, dtype=dt)
@@ -121,20 +122,25 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
         # ray direction in world = R^T [dcx, dcy, 1]
         dw = [Rt[i, 0] * dcx + Rt[i, 1] * dcy + Rt[i, 2] for i in range(3)]
         best_s = None
-        for n, d in planes:
+        surf = None   # keep_view_depths: index of the surface a ray hits (planes first, then slabs)
+        for pi_, (n, d) in enumerate(planes):
             num = -(float(n @ c) + d)
             den = n[0] * dw[0] + n[1] * dw[1] + n[2] * dw[2]
             s = num / den
             s = torch.where(s > 1e-6, s, torch.full_like(s, 1e9))
+            if keep_view_depths:
+                surf = torch.zeros_like(s, dtype=torch.int32) if best_s is None else torch.where(s < best_s, torch.full_like(surf, pi_), surf)
             best_s = s if best_s is None else torch.minimum(best_s, s)
         shift_x = shift_y = None
-        for (n, d, x0, x1, y0, y1, ox, oy) in slabs:
+        for si_, (n, d, x0, x1, y0, y1, ox, oy) in enumerate(slabs):
             num = -(float(n @ c) + d)
             den = n[0] * dw[0] + n[1] * dw[1] + n[2] * dw[2]
             s = num / den
             hx, hy = cc[0] + s * dw[0], cc[1] + s * dw[1]
             hit = (s > 1e-6) & (hx >= x0) & (hx <= x1) & (hy >= y0) & (hy <= y1) & (s < best_s)
             best_s = torch.where(hit, s, best_s)
+            if keep_view_depths:
+                surf = torch.where(hit, torch.full_like(surf, len(planes) + si_), surf)
             if shift_x is None:
                 shift_x, shift_y = torch.zeros_like(best_s), torch.zeros_like(best_s)
             shift_x = torch.where(hit, torch.full_like(shift_x, ox), shift_x)
@@ -144,6 +150,17 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
             gt_depth = best_s.to(torch.float32)  # camera-frame z: ray has z=1 in camera coordinates
         if keep_view_depths:
             view_depths.append(best_s.to(torch.float32))
+            # unit normal of the surface hit, world frame, facing the camera (the convention of normals.dmb: APD.cu:1600)
+            all_n = [n_ for n_, _ in planes] + [q_[0] for q_ in slabs]
+            nmap = torch.zeros((height, width, 3), device=dev, dtype=torch.float32)
+            for idx_, n_ in enumerate(all_n):
+                u_ = np.asarray(n_, np.float64) / np.linalg.norm(n_)
+                facing = (u_[0] * dw[0] + u_[1] * dw[1] + u_[2] * dw[2]) > 0     # pointing away from the camera along this ray: flip
+                sel_ = surf == idx_
+                for a_ in range(3):
+                    toward = torch.where(facing, torch.full_like(best_s, -u_[a_]), torch.full_like(best_s, u_[a_])).to(torch.float32)
+                    nmap[..., a_] = torch.where(sel_, toward, nmap[..., a_])
+            view_normals.append(nmap)
         X, Y = P[0], P[1]
         if shift_x is not None:   # a slab carries the same procedural texture, displaced: no continuation across its edge
             X, Y = X + shift_x, Y + shift_y
@@ -157,6 +174,8 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
         for (x0, y0, x1, y1) in rects:
             inside = (X >= x0) & (X <= x1) & (Y >= y0) & (Y <= y1)
             scale = torch.where(inside, torch.full_like(scale, 0.03), scale)
+        if keep_view_depths:
+            view_textured.append(scale > 0.5)
         img = 128.0 + tex * scale
         if gains[k] != (0.0, 0.0):
             img = 128.0 + (1.0 + gains[k][0]) * tex * scale + 64.0 * gains[k][1]
@@ -170,4 +189,6 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
         Ks.append(K.astype(np.float32))
         Rs.append(Rm.reshape(9).astype(np.float32))
         ts.append((-Rm @ c).astype(np.float32))
-    return Scene(width, height, num_src, images, Ks, Rs, ts, 1.0, 4.0, gt_depth, view_depths)
+    sc = Scene(width, height, num_src, images, Ks, Rs, ts, 1.0, 4.0, gt_depth, view_depths)
+    sc.view_normals, sc.view_textured = view_normals, view_textured   # with keep_view_depths: analytic normal and "has texture" mask of every view
+    return sc

@@ -254,12 +254,28 @@ def test_split_pass_around_the_depth_maps_changes_no_bit(gpu_pkg, ob, synth, use
     for kid in (9, 10, 14, 15):
         with pytest.raises(gpu_pkg.ApdError, match="apd_upload_depths"):
             h.run_kernel(kid)
+    with pytest.raises(gpu_pkg.ApdError, match="apd_run_before_depths has not run"):
+        h.run_after_depths()             # the second half alone: K9 / K10 / K14 / K15 on planes nobody initialised
+    with pytest.raises(gpu_pkg.ApdError, match="apd_upload_depths"):
+        h.run()                          # a whole pass is refused up front while the maps are outstanding, not at K9 with the handle half-run
+    h.profile_enable(True)
+    for kid in (9, 14):                  # refused launches take nothing from the event pool and record nothing
+        with pytest.raises(gpu_pkg.ApdError, match="apd_upload_depths"):
+            h.run_kernel(kid)
+    assert h.profile() == {}
+    h.profile_enable(False)
+    h.run_before_depths()
+    with pytest.raises(gpu_pkg.ApdError, match="already ran"):
+        h.run_before_depths()
+    with pytest.raises(gpu_pkg.ApdError, match="apd_run_after_depths"):
+        h.run()
     with pytest.raises(gpu_pkg.ApdError, match="apd_upload_depths"):
         h.run_after_depths()
-    h.run_before_depths()
     h.synchronize()
     h.upload_depths(depths)
     h.run_after_depths()
+    with pytest.raises(gpu_pkg.ApdError):
+        h.run_after_depths()             # the pass is complete
     o = common.make_oracle(ob, sc, imgs, N, p1, depths=depths, prior=(prior[0], prior[1], prior[2] if use_apd else None))
     o.run()
     common.assert_state_equal(gpu_pkg, h, o, "split geometric pass, use_APD=%d" % use_apd)

@@ -2,7 +2,10 @@
 """Writes a synthetic dense folder in the reference's layout (pair.txt, cams/%08d_cam.txt, images/%08d.pgm|jpg) from the
 analytic scene generator: `num_views` cameras on a ring looking at slanted, textured planes.
 
-  python tools/make_synthetic_dense.py <folder> --width 1920 --height 1080 --views 16 --src 10 [--textureless 0.2] [--jpeg]
+  python tools/make_synthetic_dense.py <folder> --width 1920 --height 1080 --views 16 --src 10 [--textureless 0.2] [--jpeg] [--hard] [--gt]
+
+--hard: the synth.HARD scene (slabs in front of the planes, per-view gain / offset, sources aiming off the target).
+--gt:   also writes gt/%08d.npy (+ _normal.npy, _textured.npy), the analytic z-depth, world-frame normal and has-texture mask of every view (tools/jacobi_vs_gs.py compares both orders of views against it).
 """
 import argparse
 import os
@@ -14,11 +17,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def write_dense_folder(folder, synth, width, height, num_views, num_src, seed=0, textureless=0.0, jpeg=False, device="cpu"):
+def write_dense_folder(folder, synth, width, height, num_views, num_src, seed=0, textureless=0.0, jpeg=False, device="cpu", hard=False, gt=False):
     os.makedirs(os.path.join(folder, "images"), exist_ok=True)
     os.makedirs(os.path.join(folder, "cams"), exist_ok=True)
-    sc = synth.make_scene(width, height, num_views - 1, seed=seed, textureless=textureless, device=device)
+    sc = synth.make_scene(width, height, num_views - 1, seed=seed, textureless=textureless, device=device, keep_view_depths=gt,
+                          **(synth.HARD if hard else {}))
     imgs = sc.images_numpy()
+    if gt:
+        os.makedirs(os.path.join(folder, "gt"), exist_ok=True)
+        for i in range(num_views):
+            np.save(os.path.join(folder, "gt", "%08d.npy" % i), sc.view_depths[i].detach().cpu().numpy())
+            np.save(os.path.join(folder, "gt", "%08d_normal.npy" % i), sc.view_normals[i].detach().cpu().numpy())
+            np.save(os.path.join(folder, "gt", "%08d_textured.npy" % i), sc.view_textured[i].detach().cpu().numpy())
     for i in range(num_views):
         a = imgs[i].astype(np.uint8)
         if jpeg:
@@ -56,13 +66,15 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--textureless", type=float, default=0.0)
     ap.add_argument("--jpeg", action="store_true")
+    ap.add_argument("--hard", action="store_true")
+    ap.add_argument("--gt", action="store_true")
     args = ap.parse_args()
     import __graft_entry__ as ge
     ge.load_package()
     from apd_mvs_amd import synth
     import torch
     dev = "cuda" if torch.cuda.is_available() else "cpu"
-    write_dense_folder(args.folder, synth, args.width, args.height, args.views, args.src, args.seed, args.textureless, args.jpeg, dev)
+    write_dense_folder(args.folder, synth, args.width, args.height, args.views, args.src, args.seed, args.textureless, args.jpeg, dev, hard=args.hard, gt=args.gt)
     print("wrote", args.folder)
 
 
