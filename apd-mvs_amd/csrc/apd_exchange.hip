@@ -19,6 +19,9 @@
 #include <vector>
 
 #include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
 
 #include "apd_device.h"
 
@@ -116,11 +119,15 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    std::mutex m;          // load() may run on the preload thread and on a caller's
+    double load_ms = 0.0;  // what the first successful load() took (dlopen of a library with code objects for every architecture)
     bool load()
     {
+        std::lock_guard<std::mutex> lock(m);
         if (lib) {
             return true;
         }
+        const auto t0 = std::chrono::steady_clock::now();
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) {
@@ -141,17 +148,21 @@ struct RcclApi {
             lib = nullptr;
             return false;
         }
+        load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return true;
     }
 };
 static RcclApi g_rccl;
 constexpr int kNcclInt8 = 0;  // ncclDataType_t ncclInt8 / ncclChar: the payload is moved as bytes
 
-// RCCL's set-up (dlopen of a library with code objects for every architecture + ncclCommInitAll) takes seconds -- 5.6 s for
-// ONE device on the MI355X box, more than all eight passes of a 12-view 1080p reconstruction (4.0 s) -- and it cannot be
-// hidden: run on a background thread while the first passes compute, it stalls their launches for as long as it takes
-// (passes 4.0 -> 9.9 s, measured), so it runs before the first pass or not at all.  A caller with one rank has nothing to
-// exchange between devices and should ask for direct copies (host/multi_device.cpp does).
+// RCCL's set-up takes seconds -- 5.6 s for ONE device on a fresh MI355X box, more than all eight passes of a 12-view 1080p
+// reconstruction (4.0 s).  Round 5 took it apart (tools/rccl_init_time.hip, profiles/r05/rccl_init_time.txt): 5.0 s of it are the
+// dlopen of librccl.so on a cold page cache (1.0 s warm), ncclCommInitAll is 0.65 s for one device (0.07 s for a second communicator
+// of the process).  Both can run behind other work: apd_exchange_preload_rccl starts the dlopen on a thread of its own (a host calls it
+// first thing, before it decodes its images), apd_exchange_create_async returns at once and initialises the communicators on a
+// thread while the first passes run -- exchanges go through direct copies until RCCL reports ready, through RCCL afterwards (same
+// bytes either way).  apd_exchange_create (blocking) is unchanged.  A caller with one rank has nothing to exchange between devices
+// and should ask for direct copies (host/multi_device.cpp does).
 enum { kRcclOff = 0, kRcclPending = 1, kRcclReady = 2, kRcclFailed = 3 };
 
 struct apd_exchange {
@@ -166,25 +177,33 @@ struct apd_exchange {
     std::string rccl_error;
     int exchanges_rccl = 0, exchanges_copy = 0;
     std::string backend;        // what apd_exchange_backend last reported
+    std::thread init_thread;    // apd_exchange_create_async: rccl_initialise runs here
+    double init_ms = 0.0;       // ncclCommInitAll (+ the wait for / the run of the dlopen) on that thread, or inside apd_exchange_create
+    std::chrono::steady_clock::time_point created = std::chrono::steady_clock::now();
 };
+
+static std::thread g_preload;          // apd_exchange_preload_rccl
+static std::once_flag g_preload_once;
 
 static void rccl_initialise(apd_exchange *x)
 {
+    const auto t0 = std::chrono::steady_clock::now();
+    int state = kRcclReady;
     const int n = x->period;  // one communicator entry per distinct device
     if (!g_rccl.load()) {
         x->rccl_error = "librccl not found";
-        x->rccl_state.store(kRcclFailed);
-        return;
+        state = kRcclFailed;
+    } else {
+        x->comms.assign(n, nullptr);
+        const int rc = g_rccl.CommInitAll(x->comms.data(), n, x->devices.data());
+        if (rc != 0) {
+            x->rccl_error = g_rccl.GetErrorString(rc);
+            x->comms.clear();
+            state = kRcclFailed;
+        }
     }
-    x->comms.assign(n, nullptr);
-    const int rc = g_rccl.CommInitAll(x->comms.data(), n, x->devices.data());
-    if (rc != 0) {
-        x->rccl_error = g_rccl.GetErrorString(rc);
-        x->comms.clear();
-        x->rccl_state.store(kRcclFailed);
-        return;
-    }
-    x->rccl_state.store(kRcclReady);
+    x->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    x->rccl_state.store(state);   // seq_cst: what was written above is visible to whoever reads the state
 }
 
 extern "C" {
@@ -382,7 +401,7 @@ int apd_host_unregister(void *p)
     return APD_OK;
 }
 
-int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl)
+static int exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl, bool async)
 {
     if (!out || num_ranks < 1 || !devices) {
         return xfail(APD_ERR_INVALID, "apd_exchange_create: bad argument");
@@ -428,9 +447,15 @@ int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, 
     }
     if (prefer_rccl && x->period > 0) {  // one communicator entry per device, all in this process
         x->rccl_state.store(kRcclPending);
-        rccl_initialise(x);
-        if (x->rccl_state.load() == kRcclFailed) {
-            fprintf(stderr, "apd_exchange_create: RCCL is not available (%s): using direct copies\n", x->rccl_error.c_str());
+        if (async) {
+            x->init_thread = std::thread([x]() {
+                rccl_initialise(x);   // the state becomes ready / failed with a release store: allgather reads it with an acquire load
+            });
+        } else {
+            rccl_initialise(x);
+            if (x->rccl_state.load() == kRcclFailed) {
+                fprintf(stderr, "apd_exchange_create: RCCL is not available (%s): using direct copies\n", x->rccl_error.c_str());
+            }
         }
     }
     if (x->rccl_state.load() != kRcclReady) {  // direct copies between different devices: let them go over xGMI
@@ -448,6 +473,60 @@ int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, 
         }
     }
     *out = x;
+    return APD_OK;
+}
+
+int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl)
+{
+    return exchange_create(out, num_ranks, devices, prefer_rccl, false);
+}
+
+int apd_exchange_create_async(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl)
+{
+    return exchange_create(out, num_ranks, devices, prefer_rccl, true);
+}
+
+int apd_exchange_preload_rccl(void)
+{
+    std::call_once(g_preload_once, []() {
+        g_preload = std::thread([]() { g_rccl.load(); });
+        g_preload.detach();   // load() is serialised by its mutex: whoever needs the library next waits for this thread there
+    });
+    return APD_OK;
+}
+
+int apd_exchange_wait(apd_exchange_t x, double *setup_ms, double *waited_ms)
+{
+    if (!x) {
+        return xfail(APD_ERR_INVALID, "apd_exchange_wait: null exchange");
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    if (x->init_thread.joinable()) {
+        x->init_thread.join();
+        if (x->rccl_state.load() == kRcclFailed) {
+            fprintf(stderr, "apd_exchange: RCCL is not available (%s): using direct copies\n", x->rccl_error.c_str());
+        }
+    }
+    if (waited_ms) {
+        *waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (setup_ms) {
+        *setup_ms = x->init_ms;
+    }
+    return APD_OK;
+}
+
+int apd_exchange_setup_times(apd_exchange_t x, double *dlopen_ms, double *init_ms)
+{
+    if (!x) {
+        return xfail(APD_ERR_INVALID, "apd_exchange_setup_times: null exchange");
+    }
+    if (dlopen_ms) {
+        *dlopen_ms = g_rccl.load_ms;
+    }
+    if (init_ms) {
+        *init_ms = x->rccl_state.load() == kRcclPending ? -1.0 : x->init_ms;   // -1: still running
+    }
     return APD_OK;
 }
 
@@ -474,8 +553,23 @@ int apd_exchange_counts(apd_exchange_t x, int *with_rccl, int *with_copies)
     return APD_OK;
 }
 
+static int exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank, bool sends_complete);
+
 // recv[r] of every rank r ends as send[0] | send[1] | ... | send[num_ranks - 1], `bytes_per_rank` each.
 int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank)
+{
+    return exchange_allgather(x, send, recv, bytes_per_rank, false);
+}
+
+// The same for a caller that KNOWS every send buffer to be complete (it has synchronised the streams that wrote them) and nobody to be
+// reading or writing the recv buffers: no device-wide synchronisation, so kernels that other host threads have queued for the next
+// pass keep running beside the exchange.  (The scheduler's lanes synchronise their stream after every export: apd_export_state_device.)
+int apd_exchange_allgather_ready(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank)
+{
+    return exchange_allgather(x, send, recv, bytes_per_rank, true);
+}
+
+static int exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank, bool sends_complete)
 {
     if (!x || !send || !recv) {
         return xfail(APD_ERR_INVALID, "apd_exchange_allgather: bad argument");
@@ -485,7 +579,7 @@ int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *cons
     // streams are non-blocking ones and would not wait for any of them.  Blocking collective: everything the devices were
     // given before this call has finished before the first byte moves.  (Found the hard way: at 3100 x 2065 the planes of
     // views 1.. reached the fusion partly or not at all while the 1100 x 64 test passed.)
-    for (int r = 0; r < n; ++r) {
+    for (int r = 0; r < n && !sends_complete; ++r) {
         X_TRY(hipSetDevice(x->devices[r]));
         X_TRY(hipDeviceSynchronize());
     }
@@ -536,6 +630,9 @@ int apd_exchange_destroy(apd_exchange_t x)
 {
     if (!x) {
         return APD_OK;
+    }
+    if (x->init_thread.joinable()) {
+        x->init_thread.join();
     }
     for (void *c : x->comms) {
         if (c) {

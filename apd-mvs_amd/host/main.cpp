@@ -84,6 +84,10 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.ranks_per_device = (int)v;
         } else if (a == "--no-rccl") {
             o.use_rccl = false;
+        } else if (a == "--exchange-device-sync") {
+            o.exchange_device_sync = true;
+        } else if (a == "--async-rccl") {
+            o.async_rccl = true;
         } else if (a == "--rccl") {
             o.force_rccl = true;
         } else if (i == 2 && a.size() && a[0] != '-') {
@@ -234,7 +238,7 @@ int main(int argc, char **argv)
     const auto t_start = std::chrono::steady_clock::now();
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
-        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl] [--late-fusion-inputs] [--copy-images] [--clean-exit]\n");
+        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl] [--async-rccl] [--exchange-device-sync] [--late-fusion-inputs] [--copy-images] [--clean-exit]\n");
         return EXIT_FAILURE;
     }
     if (opt.devices.empty()) {
@@ -245,6 +249,9 @@ int main(int argc, char **argv)
             fprintf(stderr, "Requested GPU %d, found %d device(s)\n", d, apd_device_count());
             return EXIT_FAILURE;
         }
+    }
+    if (WantsRccl(opt) && !opt.files && opt.async_rccl) {
+        apd_exchange_preload_rccl();   // librccl.so: 5 s to dlopen from a cold page cache, 1 s warm; started before pair.txt and the image decode
     }
     APD::SetDevice(opt.gpu_index);
     SetFusionDevice(opt.gpu_index);

@@ -342,19 +342,20 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             }
         }
         const long long ms_alloc = stage.lap();
-        // RCCL's set-up costs seconds (5.6 s for one device on the MI355X box, against 4.0 s for all eight passes of a 12-view 1080p
-        // folder) and cannot be overlapped with the passes: ranks that share one device have nothing to send through xGMI and do without
-        // unless --rccl
-        int physical = 0;  // distinct devices of the list
-        for (int i = 0; i < G; ++i) {
-            bool seen = false;
-            for (int j = 0; j < i; ++j) {
-                seen = seen || devices[j] == devices[i];
-            }
-            physical += seen ? 0 : 1;
+        // RCCL's set-up costs seconds (dlopen of librccl 5.0 s from a cold page cache / 1.0 s warm, ncclCommInitAll 0.65 s for one device:
+        // profiles/r05/rccl_init_time.txt) and runs here, before the first pass.  --async-rccl moves it behind the start-up and the first
+        // passes (the dlopen from main()'s first line, the communicators on a thread of the exchange; a pass that ends before RCCL is ready
+        // exchanges its maps with direct copies) -- measured on 24 views of 1920 x 1080 (profiles/r05/ab_rccl_async_tt24.txt): the dlopen
+        // stalls every HIP call of the other threads for as long as it runs (start-up 0.16 -> 1.24 s warm, 4.9 s cold), and the passes take
+        // 9.3 s instead of 7.5 s; the blocking set-up stays the default.  Ranks that share one device have nothing to send through xGMI and
+        // do without RCCL unless --rccl.
+        const bool want_rccl = WantsRccl(opt);
+        if (want_rccl && opt.async_rccl) {
+            Check(apd_exchange_create_async(&exchange, G, devices.data(), 1), "apd_exchange_create_async");
+        } else {
+            Check(apd_exchange_create(&exchange, G, devices.data(), want_rccl ? 1 : 0), "apd_exchange_create");
         }
-        Check(apd_exchange_create(&exchange, G, devices.data(), (opt.use_rccl && (physical > 1 || opt.force_rccl)) ? 1 : 0), "apd_exchange_create");
-        printf("Device buffers: %lld ms, exchange set-up: %lld ms\n", ms_alloc, stage.lap());
+        printf("Device buffers: %lld ms, exchange set-up: %lld ms%s\n", ms_alloc, stage.lap(), (want_rccl && opt.async_rccl) ? " (RCCL continues behind the passes)" : "");
         printf("Exchange of depth maps between passes: %s\n", apd_exchange_backend(exchange));
 
         auto gathered_depth = [&](const Rank &k, int v, size_t pix) {  // view v inside a gathered block (the pass before)
@@ -732,7 +733,12 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                                             send[q] = ranks[q].send.p;
                                             recv[q] = ranks[q].recv.p;
                                         }
-                                        Check(apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)),
+                                        // every view of the pass has exported and synchronised its stream (apd_export_state_device); the
+                                        // readers of the old gathered maps were views of this pass: no device-wide synchronisation, the
+                                        // first halves other lanes have queued for the next pass keep running beside the exchange
+                                        Check(opt.exchange_device_sync
+                                                  ? apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float))
+                                                  : apd_exchange_allgather_ready(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)),
                                               "apd_exchange_allgather");
                                         {
                                             std::lock_guard<std::mutex> lock(done_m);
@@ -804,6 +810,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             }
             std::vector<const void *> send(G);
             std::vector<void *> recv(G);
+            apd_exchange_wait(exchange, nullptr, nullptr);   // the final maps go through RCCL (north_star): it has had all passes to get ready
             for (int sl = 0; sl < slots; ++sl) {
                 for (int pass_kind = 0; pass_kind < 2; ++pass_kind) {
                     const size_t elem = pass_kind == 0 ? 16 : 1;
@@ -864,7 +871,11 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         {
             int with_rccl = 0, with_copies = 0;
             apd_exchange_counts(exchange, &with_rccl, &with_copies);
-            printf("Exchanges: %d through RCCL, %d through direct copies\n", with_rccl, with_copies);
+            double setup = 0, waited = 0, dl = 0, init = 0;
+            apd_exchange_wait(exchange, &setup, &waited);
+            apd_exchange_setup_times(exchange, &dl, &init);
+            printf("Exchanges: %d through RCCL, %d through direct copies; RCCL set-up: dlopen %.0f ms, communicators %.0f ms (incl. waiting for the dlopen), "
+                   "waited for at the end of the passes %.0f ms; backend now %s\n", with_rccl, with_copies, dl, init, waited, apd_exchange_backend(exchange));
         }
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_all).count();
         printf("All passes done: %lld ms\n", (long long)ms);

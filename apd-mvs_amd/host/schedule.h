@@ -20,6 +20,10 @@ struct Options {
     bool in_memory = false;     // --in-memory: the in-memory scheduler on one device in the reference's own order (one rank, a view reads the
                                 // depth maps its sources have at that moment): the file-based driver's bytes without the files
     bool use_rccl = true;       // --no-rccl: exchange maps with direct copies
+    bool async_rccl = false;    // --async-rccl: RCCL's set-up runs behind the start-up and the first passes instead of blocking before the first pass.
+                                // Measured slower on this box (profiles/r05/ab_rccl_async_tt24.txt): the dlopen of librccl stalls every other thread's HIP
+                                // calls while it runs, and passes that overlap ncclCommInitAll lose more than the 0.65 s it takes
+    bool exchange_device_sync = false;  // --exchange-device-sync: the per-pass exchange synchronises every device first, as in rounds 2-4 (A/B measurements)
     bool force_rccl = false;    // --rccl: RCCL even for a single rank (which has nothing to exchange between devices and uses direct copies otherwise)
     uint64_t seed = 12345;
     int iters = 3;          // PatchMatchParams::max_iterations of every pass (reference: 3)
@@ -35,6 +39,17 @@ struct Options {
 
 // One pass over all views.  round_num pyramid levels, coarse to fine; per level one photometric pass and three
 // geometric ones (main.cpp:168-215).
+// true when a run over this device list sets RCCL up (several physical devices, or --rccl).  With --async-rccl main() starts the dlopen of
+// librccl before anything else (apd_exchange_preload_rccl) and RunMultiDevice initialises the communicators behind the first passes
+inline bool WantsRccl(const Options &opt)
+{
+    bool several = false;
+    for (size_t i = 1; i < opt.devices.size(); ++i) {
+        several = several || opt.devices[i] != opt.devices[0];
+    }
+    return opt.use_rccl && (several || opt.force_rccl);
+}
+
 struct Pass {
     int level = 0;             // i of main.cpp:168
     int iteration = 0;         // Problem::iteration, counts passes

@@ -75,7 +75,7 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
         centers.append(c)
         aim = target
         if aim_jitter > 0 and k > 0:
-            jr = np.random.RandomState(7919 * seed + 31 * j + 3)
+            jr = np.random.RandomState((7919 * seed + 31 * j + 3) % (2 ** 32))
             aim = target + np.array([jr.uniform(-aim_jitter, aim_jitter), jr.uniform(-aim_jitter, aim_jitter), 0.0])
         rots.append(_lookat_rotation(c, aim) if (rotate and not (k == 0 and ref_view == 0)) else np.eye(3))
     # texture parameters (wavelengths in reference pixels at depth 2)
@@ -104,7 +104,7 @@ def make_scene(width, height, num_src, seed=0, textureless=0.0, rotate=True, bas
         slabs.append((n, d, mx - 0.5 * sx, mx + 0.5 * sx, my - 0.5 * sy, my + 0.5 * sy, rng.uniform(-3, 3), rng.uniform(-3, 3)))
     gains = [(0.0, 0.0)]
     for k in range(1, num_src + 1):
-        gr = np.random.RandomState(104729 * seed + 13 * (ref_view + k) + 1)
+        gr = np.random.RandomState((104729 * seed + 13 * (ref_view + k) + 1) % (2 ** 32))
         gains.append((gr.uniform(-gain, gain), gr.uniform(-gain, gain)) if gain > 0 else (0.0, 0.0))
 
     dev = torch.device(device)

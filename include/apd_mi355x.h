@@ -246,11 +246,23 @@ int apd_host_free(void *p);
  * per device, e.g. 0,1,0,1) runs RCCL between one leader rank per device and copies inside the devices; 0,0,0 (one device)
  * uses copies unless RCCL is forced.  Blocking; not thread-safe per exchange object. */
 typedef struct apd_exchange *apd_exchange_t;
-/* prefer_rccl != 0: RCCL, set up before the call returns.  That takes seconds (librccl + ncclCommInitAll: 5.6 s for ONE device on
- * the MI355X box) and cannot be hidden behind the first passes (on a background thread it stalls their launches for as long
- * as it runs); a caller with a single rank should pass 0. */
+/* prefer_rccl != 0: RCCL, set up before the call returns.  That takes seconds on a fresh box (5.0 s to dlopen librccl from a cold page
+ * cache, 1.0 s warm; ncclCommInitAll 0.65 s for one device: profiles/r05/rccl_init_time.txt); a caller with a single rank should pass 0.
+ * apd_exchange_preload_rccl: starts the dlopen on a thread of its own and returns at once -- call it first thing in a process that
+ *   will exchange between devices, before the images are decoded.
+ * apd_exchange_create_async: as apd_exchange_create, but the communicators are initialised on a thread while the caller goes on;
+ *   apd_exchange_allgather moves its bytes with direct copies until RCCL is ready and with RCCL from then on (same result).
+ * apd_exchange_wait: blocks until that set-up has ended (ready or failed); setup_ms = what it took on its thread, waited_ms = what
+ *   this call waited.  apd_exchange_setup_times: the dlopen's and the initialisation's own durations (init_ms = -1 while running). */
 int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl);
+int apd_exchange_create_async(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl);
+int apd_exchange_preload_rccl(void);
+int apd_exchange_wait(apd_exchange_t x, double *setup_ms, double *waited_ms);
+int apd_exchange_setup_times(apd_exchange_t x, double *dlopen_ms, double *init_ms);
 int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank);
+/* ... for a caller that has synchronised the streams which wrote the send buffers and knows the recv buffers to be idle: no device-wide
+ * synchronisation, kernels queued by other host threads (the next pass's first halves) keep running beside the exchange. */
+int apd_exchange_allgather_ready(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank);
 const char *apd_exchange_backend(apd_exchange_t x);   /* "rccl" or "peer-copy" */
 int apd_exchange_counts(apd_exchange_t x, int *with_rccl, int *with_copies);   /* exchanges served by either backend so far */
 int apd_exchange_destroy(apd_exchange_t x);

@@ -120,3 +120,55 @@ def test_exchange_refuses_devices_that_do_not_exist(gpu_pkg):
     dev = (C.c_int * 2)(0, 99)
     assert L.apd_exchange_create(C.byref(x), 2, dev, 1) != 0
     assert b"99" in L.apd_exchange_last_error()
+
+
+def test_async_set_up_serves_exchanges_with_copies_until_rccl_is_ready(gpu_pkg):
+    """apd_exchange_create_async returns at once; every all-gather gives the same bytes whether it ran through direct copies (RCCL
+    still initialising) or through RCCL (ready); apd_exchange_wait ends the set-up and reports what it took; after it the backend is
+    RCCL.  apd_exchange_allgather_ready (no device-wide synchronisation: the caller has synchronised the writers) gives the same bytes."""
+    L = _lib(gpu_pkg)
+    L.apd_exchange_create_async.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.apd_exchange_wait.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.apd_exchange_setup_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.apd_exchange_allgather_ready.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t]
+    assert L.apd_exchange_preload_rccl() == 0
+    n, per_rank = 2, 8 << 20
+    x = C.c_void_p()
+    dev = (C.c_int * n)(0, 0)
+    assert L.apd_exchange_create_async(C.byref(x), n, dev, 1) == 0, L.apd_exchange_last_error()
+    rng = np.random.default_rng(11)
+    send = [_malloc(L, per_rank) for _ in range(n)]
+    recv = [_malloc(L, per_rank * n) for _ in range(n)]
+    try:
+        sp = (C.c_void_p * n)(*[s.value for s in send])
+        rp = (C.c_void_p * n)(*[r_.value for r_ in recv])
+
+        def one_round(fn):
+            host = [rng.integers(0, 256, per_rank, dtype=np.uint8) for _ in range(n)]
+            for r in range(n):
+                assert L.apd_device_memcpy(0, send[r], _host_ptr(host[r]), per_rank) == 0   # synchronises: the sends are complete
+                assert L.apd_device_memset(0, recv[r], 0xEE, per_rank * n) == 0
+            assert fn(x, sp, rp, per_rank) == 0, L.apd_exchange_last_error()
+            want = np.concatenate(host)
+            for r in range(n):
+                got = np.empty(per_rank * n, np.uint8)
+                assert L.apd_device_memcpy(0, _host_ptr(got), recv[r], per_rank * n) == 0
+                assert np.array_equal(got, want)
+
+        one_round(L.apd_exchange_allgather)          # usually while RCCL is still initialising: direct copies
+        one_round(L.apd_exchange_allgather_ready)
+        setup, waited = C.c_double(), C.c_double()
+        assert L.apd_exchange_wait(x, C.byref(setup), C.byref(waited)) == 0
+        assert setup.value > 0 and waited.value >= 0
+        assert L.apd_exchange_backend(x) == b"rccl"
+        dl, init = C.c_double(), C.c_double()
+        assert L.apd_exchange_setup_times(x, C.byref(dl), C.byref(init)) == 0 and dl.value > 0 and init.value > 0
+        one_round(L.apd_exchange_allgather)          # RCCL now
+        one_round(L.apd_exchange_allgather_ready)
+        a, b = C.c_int(), C.c_int()
+        assert L.apd_exchange_counts(x, C.byref(a), C.byref(b)) == 0
+        assert a.value + b.value == 4 and a.value >= 2
+    finally:
+        for p in send + recv:
+            L.apd_device_free(0, p)
+        assert L.apd_exchange_destroy(x) == 0
