@@ -14,8 +14,10 @@ run_profile eth3d_office_fullres_8src 24
 run_profile eth3d_pipes_fullres_10src_apd 6
 run_profile synthetic_4096x3072_16src 8
 run_profile tt_family_1080p_10src 24
+run_profile eth3d_office_fullres_8src_hard 6
+run_profile eth3d_pipes_fullres_10src_apd_hard 3
 # whole passes (K14 / K15): the sub-lines of bench.PASS_WORKLOADS
-for key in configs2_pipes_apd_whole_pass configs2_pipes_apd_geometric_pass; do
+for key in configs2_pipes_apd_whole_pass configs2_pipes_apd_geometric_pass configs2_pipes_hard_whole_pass; do
   APD_PROFILE_PASS_KEY=$key timeout 1500 python tools/profile_bench.py "$OUT" > "$OUT/profile_$key.log" 2>&1 || echo "profile of $key failed" >> "$OUT/errors.txt"
 done
 mkdir -p profiles/$ROUND && cp "$OUT"/pmc_bench_*.json "$OUT"/pmc_pass_*.json profiles/$ROUND/   # where they will be committed; bench.py looks under profiles/*/

@@ -161,6 +161,8 @@ def check(directory):
             top = json.loads(first)
         except ValueError:
             continue
+        if "full_block" in top:   # a compact stdout line (tools/profile_bench.py keeps the line of every counter pass): checked as line_*.json only
+            continue
         for tag, line in sub_lines(os.path.basename(path), top):
             for kname, kroof in sorted((line.get("pass_kernels") or {}).items()):   # whole-pass sub-lines: K14 / K15 against their own profile
                 if kroof.get("achieved") is None:
