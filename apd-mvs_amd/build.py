@@ -99,12 +99,13 @@ TOOLS_DIR = os.path.join(HERE, "..", "tools")
 
 def build_tools(force=False):
     """tools/_build/: valu_rates (exhaustive ISA checks of the arithmetic contract), valu_issue (issue cost per VALU instruction
-    class, the basis of bench.py's roofline peak), unaligned_gather (cost of dword gathers at 2-byte alignment), lds_addr_bits (ds_read does not ignore high address bits), tcp_patterns (L1 tag accesses per gather by lane address pattern), tcp_mix (cost of gathers whose lanes partly miss the L1)."""
+    class, the basis of bench.py's roofline peak), unaligned_gather (cost of dword gathers at 2-byte alignment), lds_addr_bits (ds_read does not ignore high address bits), tcp_patterns (L1 tag accesses per gather by lane address pattern), tcp_mix (cost of gathers whose lanes partly miss the L1), rccl_init_time (what RCCL's set-up consists of)."""
     out_dir = os.path.join(TOOLS_DIR, "_build")
     os.makedirs(out_dir, exist_ok=True)
     outs = []
     for name, flags in (("valu_rates", ["-ffp-contract=off", "-fno-slp-vectorize"]), ("valu_issue", []), ("unaligned_gather", []),
-                        ("lds_addr_bits", ["-Wno-unused-value"]), ("tcp_patterns", []), ("tcp_mix", [])):
+                        ("lds_addr_bits", ["-Wno-unused-value"]), ("tcp_patterns", []), ("tcp_mix", []),
+                        ("rccl_init_time", ["-Wno-unused-result", "-Wno-unused-value", "-ldl", "-pthread"])):
         src = os.path.join(TOOLS_DIR, name + ".hip")
         out = os.path.join(out_dir, name)
         if force or _newer(out, [src]):

@@ -1,4 +1,4 @@
-O=gpurun_out/r5h; mkdir -p $O
+O=gpurun_out/lab; mkdir -p $O
 python tools/make_synthetic_dense.py /tmp/tt24 --width 1920 --height 1080 --views 24 --src 10 --textureless 0.2 --jpeg > /dev/null
 APD=apd-mvs_amd/_build/APD
 run() {  # tag, args...

@@ -1,4 +1,4 @@
-O=gpurun_out/r5b; mkdir -p $O
+O=gpurun_out/lab; mkdir -p $O
 export TMPDIR=/tmp
 (time python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize_parity.py -m gpu -x -q -k "hard") > $O/pytest_hard.log 2>&1; tail -5 $O/pytest_hard.log
 for key in configs2_pipes_apd_whole_pass configs2_pipes_apd_geometric_pass configs2_pipes_hard_whole_pass; do
