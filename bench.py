@@ -281,13 +281,16 @@ class SweepWorkload:
         gc.disable()
         ctx.barrier(hs)
         t0 = time.perf_counter()
-        hs[0].run_sweeps(0, 1, sync=False)
-        hs[0].synchronize()
-        t_first = time.perf_counter()
-        if steps > 1:
-            hs[0].run_sweeps(1, steps - 1, sync=False)
-        for h in hs[1:]:
-            h.run_sweeps(0, steps, sync=False)
+        if len(hs) == 1:
+            hs[0].run_sweeps(0, 1, sync=False)
+            hs[0].synchronize()     # one view: iteration 0 (random planes) is reported on its own
+            t_first = time.perf_counter()
+            if steps > 1:
+                hs[0].run_sweeps(1, steps - 1, sync=False)
+        else:                       # several views in flight: every view's sweep is queued at once, each on its handle's stream
+            for h in hs:
+                h.run_sweeps(0, steps, sync=False)
+            t_first = t0
         if pass_exchange:
             for h, d in zip(hs, depth):
                 for kid in (pkg.K11, pkg.K12, pkg.K13):
@@ -626,6 +629,8 @@ SUB_WORKLOADS = [
     ("configs2_pipes_hard_apd_3iter", "eth3d_pipes_fullres_10src_apd_hard", 3, 1, False, 1),  # configs[2] on the hard scene
     ("configs4_synthetic_16src_8iter", "synthetic_4096x3072_16src", 8, 1, False, 1),  # configs[4] shape, one replica per GPU
     ("configs3_tt1080p_20iter", "tt_family_1080p_10src", 20, 5, False, 1),          # configs[3] frame size, sweep only
+    ("configs3_tt1080p_6views_20iter", "tt_family_1080p_10src", 20, 5, False, 6),    # ... with six views in flight per GPU, each on its own stream:
+    # how the schedulers fill a device with small frames (host/multi_device.cpp: DefaultLanes)
     ("configs3_tt1080p_pass_with_exchange", "tt_family_1080p_10src", 3, 1, True, 2),  # configs[3] as the sharded scheduler runs it:
     # two views per GPU, the reference's three iterations, then K11..K13 + export + all-gather of all depth maps inside the timed region
 ]
