@@ -32,6 +32,9 @@
 #ifndef APD_WIN_CORNER_REUSE
 #define APD_WIN_CORNER_REUSE 1
 #endif
+#ifndef APD_WIN_DRAIN_SMEM
+#define APD_WIN_DRAIN_SMEM 1  // s_waitcnt lgkmcnt(0) at the head of the window body (see ncc_window_moments)
+#endif
 #ifndef APD_WIN_SETPRIO
 #define APD_WIN_SETPRIO 1  // issue priority for the wave inside its 36-sample burst: +0.7 % on configs[1] (0 = off)
 #endif

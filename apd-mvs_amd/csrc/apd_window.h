@@ -412,6 +412,13 @@ __device__ __forceinline__ void ncc_window_moments(const Ref &rp, const Homograp
 #if APD_WIN_SETPRIO > 0
     __builtin_amdgcn_s_setprio(APD_WIN_SETPRIO);
 #endif
+#if APD_WIN_DRAIN_SMEM
+    // Scalar loads return out of order: while one is pending (the per-view constants a caller prefetches for its next NCC), the
+    // compiler can only wait for "every LDS and scalar access" -- and the first row of the body then ends with `s_waitcnt
+    // lgkmcnt(0)` right after the NEXT row's six reads have been issued: a whole LDS round trip per NCC.  Waiting for the scalar
+    // loads here, where they have had the whole prologue to arrive, lets every wait of the body be a counted one.
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), vmcnt / expcnt untouched
+#endif
     float a[2][kPatchN], b[2][kPatchN];
     WinTaps<typename WinEntry<kQuad>::type> t[2][kPatchN];
     {
