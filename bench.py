@@ -1002,17 +1002,19 @@ def selftest_cpu(args, world, rank):
     dist.all_gather_into_tensor(per_rank2, torch.tensor([t_rank2 * 1e3], dtype=torch.float64))
     assert elapsed2 * 1e3 >= float(per_rank2.max()) + 0.0   # the exchange is inside: the region cannot be shorter than the slowest rank
     if rank == 0:
-        print(json.dumps({"metric": "Mpix*iterations/sec (PatchMatch sweep)", "value": None, "unit": "Mpix*iter/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                          "selftest": "launcher and collectives only, CPU/gloo, no PatchMatch work", "scaling": "weak",
-                          "config": {"workload": args.workload, "backend": dist.get_backend()},
-                          "rank_ms_per_step": [round(float(v), 3) for v in per_rank.tolist()],
-                          "allgather_ms": round(allgather_ms, 3),
-                          "workloads": {"configs3_tt1080p_pass_with_exchange": {
-                              "value": None, "n_gpus": world, "steps": 1, "ms_per_step": round(elapsed2 * 1e3, 3),
-                              "timed_region_ms": round(elapsed2 * 1e3, 3), "pass_allgather_ms": round(pass_ms, 3),
-                              "pass_allgather_inside_timed_region": True, "rank_ms_per_step": [round(float(v), 3) for v in per_rank2.tolist()],
-                              "config": {"views_per_gpu": vpg, "backend": dist.get_backend(), "views": vpg * world}}}}), flush=True)
+        # through the same emit() as a measured line: compact stdout line + full block in bench_workloads.json
+        emit({"metric": "Mpix*iterations/sec (PatchMatch sweep)", "value": None, "unit": "Mpix*iter/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+              "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "roofline": None, "cpu_baseline": None,
+              "selftest": "launcher and collectives only, CPU/gloo, no PatchMatch work", "scaling": "weak",
+              "config": {"workload": args.workload, "backend": dist.get_backend()},
+              "rank_ms_per_step": [round(float(v), 3) for v in per_rank.tolist()],
+              "allgather_ms": round(allgather_ms, 3),
+              "workloads": {"configs3_tt1080p_pass_with_exchange": {
+                  "value": None, "n_gpus": world, "steps": 1, "ms_per_step": round(elapsed2 * 1e3, 3),
+                  "timed_region_ms": round(elapsed2 * 1e3, 3), "pass_allgather_ms": round(pass_ms, 3),
+                  "pass_allgather_inside_timed_region": True, "rank_ms_per_step": [round(float(v), 3) for v in per_rank2.tolist()],
+                  "config": {"views_per_gpu": vpg, "backend": dist.get_backend(), "views": vpg * world}}}}, full_line=args.full_line)
     dist.destroy_process_group()
     return 0
 

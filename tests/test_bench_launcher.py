@@ -21,10 +21,14 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_slowest():
     r = _run("--gpus", "2", "--steps", "3", "--warmup", "0", "--selftest-cpu")
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout  # ONE line, from rank 0
-    out = json.loads(lines[0])
+    assert len(lines) == 1, r.stdout  # ONE line, from rank 0: the compact one (what the driver parses), at most 2,000 bytes
+    assert len(lines[0].encode()) <= 2000
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] is None and line["selftest"] is True
+    assert line["config"]["backend"] == "gloo" and line["workloads"]["configs3_tt1080p_pass_with_exchange"][0] is None
+    out = json.loads(open(os.path.join(ROOT, "bench_workloads.json")).readline())   # the full block of the same run
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] is None and "selftest" in out
-    assert out["config"]["backend"] == "gloo"
+    assert out["config"]["backend"] == "gloo" and out["ms_per_step"] == line["ms_per_step"]
     per_rank = out["rank_ms_per_step"]
     assert len(per_rank) == 2 and per_rank[1] > 1.5 * per_rank[0]           # rank 1 sleeps twice as long
     assert out["ms_per_step"] >= per_rank[1] * 0.99                            # MAX over ranks, not rank 0's own time
