@@ -85,7 +85,8 @@
 #define APD_K14_PAIRS_FROM_N 10  // ... in launches with at least this many source views
 #endif
 #ifndef APD_K14_CHUNK
-#define APD_K14_CHUNK 8  // depth samples per staged window (K14 ms at 4096x3072, 8 views: 4: 144.7, 6: 138.8, 8: 135.6, 16: 140.6, 31: 161.1)
+#define APD_K14_CHUNK 8  // depth samples per staged window = length of the register vector of cost sums: 4, 8 or 16 (K14 ms at 6200x4130, 10 views,
+                         // photometric / geometric pass, profiles/r05/tune_k14.txt: 4: 316 / 276, 8: 286 / 275, 16: 377 / 448)
 #endif
 #ifndef APD_K14W_WAVES
 #define APD_K14W_WAVES 4  // ms at 4096x3072, 8 views: 4 waves/SIMD (128 VGPRs, 18 spilled) 140.6, 3 waves 150.1
@@ -100,9 +101,6 @@
 #endif
 #ifndef APD_K14_CENTRE_FIRST
 #define APD_K14_CENTRE_FIRST 1
-#endif
-#ifndef APD_K14_PREFETCH
-#define APD_K14_PREFETCH 1
 #endif
 #ifndef APD_K15_EARLY_OUT
 #define APD_K15_EARLY_OUT 1
