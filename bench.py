@@ -894,6 +894,7 @@ def compact_roofline(r):
     return {"bound": r.get("bound"), "kernel": str(r.get("kernel", "")).split(" ")[0], "achieved": r.get("achieved"), "peak": r.get("peak"),
             "unit": r.get("unit"), "frac": r.get("frac"), "traffic": None if r.get("traffic") is None else int(r["traffic"]),
             "avg_launch_ms": r.get("avg_launch_ms"), "launches": r.get("launches"), "hbm_frac": hbm.get("frac"),
+            "valu_busy": (r.get("valu_busy_estimate") or {}).get("frac"),   # frac weighted with the body's instruction mix (2.78 cycles per instruction, not 2)
             "algorithmic_GBps": alg.get("GBps"), "pmc_source": r.get("pmc_source")}
 
 

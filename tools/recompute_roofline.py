@@ -228,6 +228,8 @@ def check_compact_lines(directory, problems):
         pairs += [("roofline.traffic", r.get("traffic"), None if fr.get("traffic") is None else int(fr["traffic"])),
                   ("roofline.hbm_frac", r.get("hbm_frac"), (fr.get("hbm") or {}).get("frac")),
                   ("roofline.algorithmic_GBps", r.get("algorithmic_GBps"), (fr.get("algorithmic") or {}).get("GBps"))]
+        if "valu_busy" in r:
+            pairs += [("roofline.valu_busy", r.get("valu_busy"), (fr.get("valu_busy_estimate") or {}).get("frac"))]
         cb, fcb = c.get("cpu_baseline") or {}, full.get("cpu_baseline") or {}
         pairs += [("cpu_baseline." + k, cb.get(k), fcb.get(k)) for k in ("value", "cores", "kind")]
         if set(c.get("workloads") or {}) != set(full.get("workloads") or {}):
