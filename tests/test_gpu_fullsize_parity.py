@@ -243,3 +243,65 @@ def test_float_images_at_a_pyramid_level_of_configs1(gpu_pkg, ob, synth):
     assert n == 15
     h.close()
     o.close()
+
+
+def test_configs0_office_halfres_2src_3iter(gpu_pkg, ob, synth, record_property):
+    """configs[0]: ETH3D office at half resolution (scale_factor 2), 2 source views, 3 iterations -- the shape BASELINE.json runs on
+    the reference's CPU path.  The full-size 8-bit frames are resampled as the reference does for scale_size = 2 (cv::resize
+    INTER_LINEAR on the float image, intrinsics scaled by the rounded size ratio, APD.cpp:464-488), so the level holds
+    non-integer grey values: 3100 x 2065, the float texel-quad path, the N = 2 instantiation of every sweep kernel at a size
+    where the XCD-banded grid and the LDS windows are the real ones.  Whole FIRST_INIT pass, main.cpp:171-190."""
+    from apd_mvs_amd import pipeline
+    W0, H0, N = 6200, 4130, 2
+    sc, imgs0 = _scene(synth, W0, H0, N)
+    W, H = W0 // 2, H0 // 2
+    imgs = [pipeline.resize_linear(im, W, H) for im in imgs0]
+    assert any(np.any(im != np.round(im)) for im in imgs), "a resampled level holds non-integer grey values"
+    del imgs0
+    sx, sy = np.float32(W) / np.float32(W0), np.float32(H) / np.float32(H0)
+    for k in range(N + 1):   # APD.cpp:480-487
+        K = sc.K[k].copy()
+        K[0], K[2], K[4], K[5] = K[0] * sx, K[2] * sx, K[4] * sy, K[5] * sy
+        sc.K[k] = K
+    sc.width, sc.height = W, H
+    p = common.base_params(sc, N, max_iterations=3, seed=12345, weak_peak_radius=6)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p)
+    o = common.make_oracle(ob, sc, imgs, N, p)
+    log = []
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(3, False), _fixed_windows(W, H), "configs[0]", log)
+    print("\n".join(log))
+    record_property("kernels_compared", n)
+    assert n == 17
+    # the pass must have done its job on this shape: depth within 1 % of the analytic depth (rendered at full size: every other pixel)
+    d = h.state(gpu_pkg.STATE_PLANES)[..., 3]
+    gt = sc.gt_depth.cpu().numpy()[::2, ::2][:H, :W]
+    good = float(((np.abs(d - gt) / gt)[8:-8, 8:-8] < 0.02).mean())
+    record_property("within_2pct_depth", good)
+    assert good > 0.9, good
+    h.close()
+    o.close()
+
+
+def test_configs1_full_frame_oracle_iteration2(gpu_pkg, ob, synth, record_property):
+    """configs[1], ONE iteration over the WHOLE frame against the oracle (no region of interest): after K1, K2, K5 and
+    iterations 0 and 1 on the HIP path, its state is loaded into the oracle and K6, K7, K8 of iteration 2 -- the converged regime,
+    LDS windows on, compacted refinement, early-outs -- run on both over all 25.6 Mpix; every state array of every pixel is compared
+    as raw bits.  The window tests above cover 1.3 % of the frame after every kernel; this one covers every wave's footprint once
+    (APD.cu:1547-1585: the launch visits every pixel of a colour)."""
+    import time
+    W, H, N = 6200, 4130, 8
+    sc, imgs = _scene(synth, W, H, N)
+    p = common.base_params(sc, N, max_iterations=3, seed=12345, weak_peak_radius=6)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p)
+    o = common.make_oracle(ob, sc, imgs, N, p)
+    for kid, it in _schedule(2, False, tail=False):
+        h.run_kernel(kid, it)
+    t0 = time.perf_counter()
+    log = []
+    n = common.fullsize_lockstep(gpu_pkg, h, o, [(6, 2), (7, 2), (8, 2)], [(0, 0, W, H)], "configs[1] full frame", log)
+    print("\n".join(log))
+    record_property("oracle_full_frame_s", round(time.perf_counter() - t0, 1))
+    record_property("pixels_compared", W * H)
+    assert n == 3
+    h.close()
+    o.close()

@@ -186,6 +186,31 @@ def test_randomised_three_pass_cases_on_hard_scenes(gpu_pkg, ob, synth, case):
     assert "hard(" in mod.run_case(case, hard=True)
 
 
+def _fuzz():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("parity_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                               "tools", "parity_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("case", list(range(80000, 80036)))
+def test_fuzz_sweep_easy(gpu_pkg, ob, synth, case):
+    """36 further cases of tools/parity_fuzz.py in the driver's suite (the 700-case sweeps were builder-side logs):
+    random size 36..260 x 30..180, N = 1..18, textureless share, iterations, 8-bit / float images, one handle per pass or one
+    recycled, whole pass or split around the depth maps, shared level images -- every state array bit-identical after each of the
+    three pass kinds."""
+    _fuzz().run_case(case, hard=False)
+
+
+@pytest.mark.parametrize("case", list(range(81000, 81030)))
+def test_fuzz_sweep_hard(gpu_pkg, ob, synth, case):
+    """30 further hard cases (slabs, gain / offset, sources aiming off the target)."""
+    assert "hard(" in _fuzz().run_case(case, hard=True)
+
+
 @pytest.mark.parametrize("W,H,N,float_images", [(80, 60, 20, False), (72, 56, 12, True), (64, 48, 31, False)])
 def test_many_source_views_three_pass(gpu_pkg, ob, synth, W, H, N, float_images):
     """The 16- and 32-view instantiations of the sweep kernels (the reference allows MAX_IMAGES = 32 including the
