@@ -68,8 +68,37 @@ def library_path():
     return LIB_PATH
 
 
+def expected_build_id():
+    """Digest of csrc/*, the headers and the compiler flags of THIS tree (build.py: expected_build_id)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("apd_build", os.path.join(_HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.expected_build_id()
+
+
+def build_id(L=None):
+    """apd_build_id() of the loaded library: the digest of the sources it was compiled from."""
+    L = L or lib()
+    L.apd_build_id.restype = C.c_char_p
+    return L.apd_build_id().decode()
+
+
+def check_build_id(L):
+    """A library built from other sources than the tree's is refused (an mtime test cannot tell a stale binary on a box
+    whose push preserved the times).  APD_ALLOW_STALE_LIBRARY=1 skips the test (lab builds with ad-hoc flags)."""
+    if os.environ.get("APD_ALLOW_STALE_LIBRARY") == "1":
+        return
+    if not hasattr(L, "apd_build_id"):
+        raise ApdError("%s has no apd_build_id(): a binary of an earlier round; run __graft_entry__.build()" % LIB_PATH)
+    have, want = build_id(L), expected_build_id()
+    if have != want:
+        raise ApdError("stale HIP library: %s was built from sources with digest %s, the tree's csrc/ + flags give %s; "
+                       "run __graft_entry__.build()" % (LIB_PATH, have, want))
+
+
 def lib():
-    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    """Loads the HIP library; raises if it has not been built or was built from other sources (no fallback)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -82,6 +111,7 @@ def lib():
     except ImportError:
         pass
     L = C.CDLL(LIB_PATH)
+    check_build_id(L)
     H = C.c_void_p
     fpp = C.POINTER(C.c_void_p)
     L.apd_default_params.argtypes = [C.POINTER(Params)]

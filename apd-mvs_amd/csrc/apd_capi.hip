@@ -108,7 +108,17 @@ struct apd_context {
     };
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
+    hipEvent_t export_event = nullptr;   // recorded behind the kernel of the last export (apd_export_event)
 };
+
+static int record_export(apd_context *c)
+{
+    if (!c->export_event) {
+        HIP_TRY(hipEventCreateWithFlags(&c->export_event, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(c->export_event, c->stream));
+    return APD_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // contract C2/C3 on the host: plane-independent part of ComputeHomography (APD.cu:305-331).
@@ -259,7 +269,16 @@ void apd_default_params(apd_params *p)
 }
 
 const char *apd_last_error(void) { return g_last_error.c_str(); }
-int apd_version(void) { return 100; }
+int apd_version(void) { return 106; }
+
+// Digest of the HIP sources, headers and compiler flags this library was built from (apd-mvs_amd/build.py writes it next to the
+// objects before compiling this file): what apd_mvs_amd.build.expected_build_id() returns for the same tree.
+const char *apd_build_id(void)
+{
+    return
+#include "apd_build_id.inc"
+        ;
+}
 
 int apd_ransac_distance_cut(float depth_min, float depth_max, float ransac_threshold, float *cut)
 {
@@ -424,6 +443,9 @@ int apd_destroy(apd_handle c)
     hipFree(c->weak_list_scratch);
     hipFree(c->neighbours_map);
     hipFree(c->neighbours);
+    if (c->export_event) {
+        hipEventDestroy(c->export_event);
+    }
     for (auto &pe : c->pending) {
         hipEventDestroy(pe.start);
         hipEventDestroy(pe.stop);
@@ -1246,6 +1268,9 @@ int apd_export_depth_normal_device(apd_handle c, float *depth_dev, float *normal
     if (e != hipSuccess) {
         return fail(APD_ERR_HIP, "export kernel failed: %s", hipGetErrorString(e));
     }
+    if (int rc = record_export(c)) {
+        return rc;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return APD_OK;
 }
@@ -1260,8 +1285,20 @@ int apd_export_state_device(apd_handle c, float *planes4_dev, uint8_t *weak_dev,
     if (e != hipSuccess) {
         return fail(APD_ERR_HIP, "export kernel failed: %s", hipGetErrorString(e));
     }
+    if (int rc = record_export(c)) {
+        return rc;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     drain_profile(c);
+    return APD_OK;
+}
+
+int apd_export_event(apd_handle c, void **hip_event)
+{
+    if (!c || !hip_event) {
+        return fail(APD_ERR_INVALID, "apd_export_event: bad argument");
+    }
+    *hip_event = (void *)c->export_event;
     return APD_OK;
 }
 

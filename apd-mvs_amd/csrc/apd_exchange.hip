@@ -5,7 +5,8 @@
 //
 // The all-gather is RCCL's (ncclCommInitAll + one grouped ncclAllGather per call, every rank on its own stream), i.e. the
 // xGMI path.  librccl is opened at run time (dlopen): the library has no link-time dependency on it, and a missing librccl falls
-// back to direct copies (hipMemcpyPeerAsync), which give the same bytes.  A device list that repeats itself ("0,1,2,3,0,1,2,3":
+// back to direct reads (one gather kernel per rank over peer-mapped send buffers; hipMemcpyPeerAsync where a pair of devices has no
+// peer access), which give the same bytes.  A device list that repeats itself ("0,1,2,3,0,1,2,3":
 // two scheduler ranks per device) runs RCCL between one leader rank per device and copies inside the devices; a list without that
 // structure ("0,0,1") uses direct copies.
 #include <hip/hip_runtime.h>
@@ -18,10 +19,9 @@
 #include <string>
 #include <vector>
 
-#include <atomic>
+#include <algorithm>
 #include <chrono>
 #include <mutex>
-#include <thread>
 
 #include "apd_device.h"
 
@@ -119,8 +119,13 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
-    std::mutex m;          // load() may run on the preload thread and on a caller's
-    double load_ms = 0.0;  // what the first successful load() took (dlopen of a library with code objects for every architecture)
+    std::mutex m;          // exchanges may be created from several host threads
+    double load_ms = 0.0;  // what the first successful load() took (dlopen of a library with code objects for every architecture); written under m
+    double loaded_ms()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        return load_ms;
+    }
     bool load()
     {
         std::lock_guard<std::mutex> lock(m);
@@ -156,14 +161,13 @@ static RcclApi g_rccl;
 constexpr int kNcclInt8 = 0;  // ncclDataType_t ncclInt8 / ncclChar: the payload is moved as bytes
 
 // RCCL's set-up takes seconds -- 5.6 s for ONE device on a fresh MI355X box, more than all eight passes of a 12-view 1080p
-// reconstruction (4.0 s).  Round 5 took it apart (tools/rccl_init_time.hip, profiles/r05/rccl_init_time.txt): 5.0 s of it are the
-// dlopen of librccl.so on a cold page cache (1.0 s warm), ncclCommInitAll is 0.65 s for one device (0.07 s for a second communicator
-// of the process).  Both can run behind other work: apd_exchange_preload_rccl starts the dlopen on a thread of its own (a host calls it
-// first thing, before it decodes its images), apd_exchange_create_async returns at once and initialises the communicators on a
-// thread while the first passes run -- exchanges go through direct copies until RCCL reports ready, through RCCL afterwards (same
-// bytes either way).  apd_exchange_create (blocking) is unchanged.  A caller with one rank has nothing to exchange between devices
-// and should ask for direct copies (host/multi_device.cpp does).
-enum { kRcclOff = 0, kRcclPending = 1, kRcclReady = 2, kRcclFailed = 3 };
+// reconstruction (4.0 s): 5.0 s of it are the dlopen of librccl.so on a cold page cache (1.0 s warm), ncclCommInitAll is 0.65 s for one
+// device (tools/rccl_init_time.hip, profiles/r05/rccl_init_time.txt).  Round 5 tried to run both behind the first passes (a preload
+// thread + communicators initialised on a thread, exchanges through copies until RCCL was ready): the dlopen stalls every HIP call of
+// the other threads for as long as it runs and the passes beside the initialisation took 9.3 instead of 7.5 s
+// (profiles/r05/ab_rccl_async_tt24.txt) -- slower; the code was removed in round 6, the set-up is blocking.  A caller with one rank has
+// nothing to exchange between devices and should ask for direct copies (host/multi_device.cpp does).
+enum { kRcclOff = 0, kRcclReady = 2, kRcclFailed = 3 };
 
 struct apd_exchange {
     std::vector<int> devices;
@@ -172,18 +176,15 @@ struct apd_exchange {
     // one leader rank per device -- ranks 0 .. period - 1, one communicator entry each -- once per repetition, and the other ranks of
     // a device copy the gathered blocks from their leader, inside the device.  period == number of ranks: the plain case.
     int period = 0;
-    std::vector<void *> comms;  // ncclComm_t per leader rank; used only once rccl_state == kRcclReady
-    std::atomic<int> rccl_state{kRcclOff};
+    std::vector<void *> comms;  // ncclComm_t per leader rank; used only when rccl_state == kRcclReady
+    int rccl_state = kRcclOff;
+    std::vector<char> peer_ok;  // [dst * n + src]: rank dst's device can read rank src's memory from a kernel (same device, or peer access enabled)
+    std::vector<hipEvent_t> done;   // one per rank: recorded behind a rank's part of an exchange (the other ranks of its device wait for the leader's)
     std::string rccl_error;
     int exchanges_rccl = 0, exchanges_copy = 0;
     std::string backend;        // what apd_exchange_backend last reported
-    std::thread init_thread;    // apd_exchange_create_async: rccl_initialise runs here
-    double init_ms = 0.0;       // ncclCommInitAll (+ the wait for / the run of the dlopen) on that thread, or inside apd_exchange_create
-    std::chrono::steady_clock::time_point created = std::chrono::steady_clock::now();
+    double init_ms = 0.0;       // dlopen (first exchange of the process) + ncclCommInitAll inside apd_exchange_create
 };
-
-static std::thread g_preload;          // apd_exchange_preload_rccl
-static std::once_flag g_preload_once;
 
 static void rccl_initialise(apd_exchange *x)
 {
@@ -203,7 +204,7 @@ static void rccl_initialise(apd_exchange *x)
         }
     }
     x->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    x->rccl_state.store(state);   // seq_cst: what was written above is visible to whoever reads the state
+    x->rccl_state = state;
 }
 
 extern "C" {
@@ -401,7 +402,35 @@ int apd_host_unregister(void *p)
     return APD_OK;
 }
 
-static int exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl, bool async)
+namespace apd {
+// The peer-copy all-gather of one rank as ONE launch: workgroup (x, src) copies 16-byte words of rank src's send buffer (its own
+// device's memory, or a peer's mapped over xGMI) into block src of this rank's result.  Replaces num_ranks hipMemcpy(Peer)Async calls
+// per rank, which the runtime serves with its blit path one after the other (1.3 s of a 24 x 1080p run, profiles/r05/ab_rccl_async_tt24.txt).
+constexpr int kGatherMaxRanks = 64;
+typedef unsigned int word4 __attribute__((ext_vector_type(4)));   // a plain 16-byte vector: what the nontemporal builtins take
+struct GatherArgs {
+    const word4 *src[kGatherMaxRanks];
+};
+
+__global__ __launch_bounds__(256) void k_gather_blocks(GatherArgs a, word4 *__restrict__ dst, size_t words_per_rank, size_t tail_bytes)
+{
+    const int r = blockIdx.y;
+    const word4 *__restrict__ src = a.src[r];
+    if (!src) {   // this block goes through hipMemcpyPeerAsync (no peer access for the pair)
+        return;
+    }
+    word4 *__restrict__ out = dst + (size_t)r * words_per_rank;   // only reached with tail_bytes == 0 for r > 0 (see the caller)
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words_per_rank; i += stride) {
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), out + i);   // streamed once: keep it out of the way of the sweeps' L2 lines
+    }
+    if (tail_bytes && blockIdx.x == 0 && threadIdx.x < tail_bytes) {   // bytes_per_rank not a multiple of 16: single rank layout only
+        reinterpret_cast<uint8_t *>(out + words_per_rank)[threadIdx.x] = reinterpret_cast<const uint8_t *>(src + words_per_rank)[threadIdx.x];
+    }
+}
+}  // namespace apd
+
+int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl)
 {
     if (!out || num_ranks < 1 || !devices) {
         return xfail(APD_ERR_INVALID, "apd_exchange_create: bad argument");
@@ -421,8 +450,10 @@ static int exchange_create(apd_exchange_t *out, int num_ranks, const int *device
         }
     }
     x->streams.resize(num_ranks, nullptr);
+    x->done.resize(num_ranks, nullptr);
     for (int i = 0; i < num_ranks; ++i) {
-        if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&x->streams[i], hipStreamNonBlocking) != hipSuccess) {
+        if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&x->streams[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming) != hipSuccess) {
             apd_exchange_destroy(x);
             return xfail(APD_ERR_HIP, "apd_exchange_create: cannot create a stream on device %d", devices[i]);
         }
@@ -446,73 +477,32 @@ static int exchange_create(apd_exchange_t *out, int num_ranks, const int *device
         x->period = periodic ? first_repeat : 0;  // 0: no structure RCCL could use, direct copies
     }
     if (prefer_rccl && x->period > 0) {  // one communicator entry per device, all in this process
-        x->rccl_state.store(kRcclPending);
-        if (async) {
-            x->init_thread = std::thread([x]() {
-                rccl_initialise(x);   // the state becomes ready / failed with a release store: allgather reads it with an acquire load
-            });
-        } else {
-            rccl_initialise(x);
-            if (x->rccl_state.load() == kRcclFailed) {
-                fprintf(stderr, "apd_exchange_create: RCCL is not available (%s): using direct copies\n", x->rccl_error.c_str());
-            }
+        rccl_initialise(x);
+        if (x->rccl_state == kRcclFailed) {
+            fprintf(stderr, "apd_exchange_create: RCCL is not available (%s): using direct copies\n", x->rccl_error.c_str());
         }
     }
-    if (x->rccl_state.load() != kRcclReady) {  // direct copies between different devices: let them go over xGMI
-        for (int i = 0; i < num_ranks; ++i) {
-            for (int j = 0; j < num_ranks; ++j) {
-                int can = 0;
-                if (i != j && hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
-                    hipSetDevice(devices[i]);
-                    hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
-                        (void)hipGetLastError();
-                    }
+    // direct reads between different devices go over xGMI: peer access, where the pair has it (also used by the copies inside a
+    // device that follow an RCCL gather between leaders)
+    x->peer_ok.assign((size_t)num_ranks * num_ranks, 0);
+    for (int i = 0; i < num_ranks; ++i) {
+        for (int j = 0; j < num_ranks; ++j) {
+            if (devices[i] == devices[j]) {
+                x->peer_ok[(size_t)i * num_ranks + j] = 1;
+                continue;
+            }
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                hipSetDevice(devices[i]);
+                hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+                if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) {
+                    x->peer_ok[(size_t)i * num_ranks + j] = 1;
                 }
+                (void)hipGetLastError();
             }
         }
     }
     *out = x;
-    return APD_OK;
-}
-
-int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl)
-{
-    return exchange_create(out, num_ranks, devices, prefer_rccl, false);
-}
-
-int apd_exchange_create_async(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl)
-{
-    return exchange_create(out, num_ranks, devices, prefer_rccl, true);
-}
-
-int apd_exchange_preload_rccl(void)
-{
-    std::call_once(g_preload_once, []() {
-        g_preload = std::thread([]() { g_rccl.load(); });
-        g_preload.detach();   // load() is serialised by its mutex: whoever needs the library next waits for this thread there
-    });
-    return APD_OK;
-}
-
-int apd_exchange_wait(apd_exchange_t x, double *setup_ms, double *waited_ms)
-{
-    if (!x) {
-        return xfail(APD_ERR_INVALID, "apd_exchange_wait: null exchange");
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    if (x->init_thread.joinable()) {
-        x->init_thread.join();
-        if (x->rccl_state.load() == kRcclFailed) {
-            fprintf(stderr, "apd_exchange: RCCL is not available (%s): using direct copies\n", x->rccl_error.c_str());
-        }
-    }
-    if (waited_ms) {
-        *waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
-    if (setup_ms) {
-        *setup_ms = x->init_ms;
-    }
     return APD_OK;
 }
 
@@ -522,10 +512,10 @@ int apd_exchange_setup_times(apd_exchange_t x, double *dlopen_ms, double *init_m
         return xfail(APD_ERR_INVALID, "apd_exchange_setup_times: null exchange");
     }
     if (dlopen_ms) {
-        *dlopen_ms = g_rccl.load_ms;
+        *dlopen_ms = g_rccl.loaded_ms();
     }
     if (init_ms) {
-        *init_ms = x->rccl_state.load() == kRcclPending ? -1.0 : x->init_ms;   // -1: still running
+        *init_ms = x->init_ms;
     }
     return APD_OK;
 }
@@ -535,7 +525,7 @@ const char *apd_exchange_backend(apd_exchange_t x)
     if (!x) {
         return "";
     }
-    x->backend = x->rccl_state.load() == kRcclReady ? "rccl" : "peer-copy";
+    x->backend = x->rccl_state == kRcclReady ? "rccl" : "peer-copy";
     return x->backend.c_str();
 }
 
@@ -553,37 +543,54 @@ int apd_exchange_counts(apd_exchange_t x, int *with_rccl, int *with_copies)
     return APD_OK;
 }
 
-static int exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank, bool sends_complete);
+static int exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank, bool device_sync, int num_events,
+                              void *const *hip_events);
 
-// recv[r] of every rank r ends as send[0] | send[1] | ... | send[num_ranks - 1], `bytes_per_rank` each.
+// recv[r] of every rank r ends as send[0] | send[1] | ... | send[num_ranks - 1], `bytes_per_rank` each.  Waits for everything the
+// devices were given before the call (the send buffers may have been written on any stream).
 int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank)
 {
-    return exchange_allgather(x, send, recv, bytes_per_rank, false);
+    return exchange_allgather(x, send, recv, bytes_per_rank, true, 0, nullptr);
 }
 
-// The same for a caller that KNOWS every send buffer to be complete (it has synchronised the streams that wrote them) and nobody to be
-// reading or writing the recv buffers: no device-wide synchronisation, so kernels that other host threads have queued for the next
-// pass keep running beside the exchange.  (The scheduler's lanes synchronise their stream after every export: apd_export_state_device.)
-int apd_exchange_allgather_ready(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank)
+// The same without the device-wide synchronisation: the exchange's streams wait for `hip_events` (hipEvent_t, e.g. apd_export_event of
+// every handle that wrote a block of a send buffer) and for nothing else, so kernels that other host threads have queued for the next
+// pass keep running beside the exchange.  The caller guarantees that nobody reads or writes the recv buffers meanwhile.
+int apd_exchange_allgather_after(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank, int num_events,
+                                 void *const *hip_events)
 {
-    return exchange_allgather(x, send, recv, bytes_per_rank, true);
+    if (num_events < 0 || (num_events > 0 && !hip_events)) {
+        return xfail(APD_ERR_INVALID, "apd_exchange_allgather_after: bad event list");
+    }
+    return exchange_allgather(x, send, recv, bytes_per_rank, false, num_events, hip_events);
 }
 
-static int exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank, bool sends_complete)
+static int exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank, bool device_sync, int num_events,
+                              void *const *hip_events)
 {
     if (!x || !send || !recv) {
         return xfail(APD_ERR_INVALID, "apd_exchange_allgather: bad argument");
     }
     const int n = (int)x->devices.size();
     // The send buffers were written on other streams (the handles' own, the null stream of the pack copies); the exchange's
-    // streams are non-blocking ones and would not wait for any of them.  Blocking collective: everything the devices were
+    // streams are non-blocking ones and would not wait for any of them.  Blocking form: everything the devices were
     // given before this call has finished before the first byte moves.  (Found the hard way: at 3100 x 2065 the planes of
-    // views 1.. reached the fusion partly or not at all while the 1100 x 64 test passed.)
-    for (int r = 0; r < n && !sends_complete; ++r) {
+    // views 1.. reached the fusion partly or not at all while the 1100 x 64 test passed.)  Event form: every stream of the
+    // exchange waits for every writer's event -- an already completed event costs nothing, a pending one is honoured
+    // (the contract used to rest on the callers having synchronised their streams).
+    for (int r = 0; r < n && device_sync; ++r) {
         X_TRY(hipSetDevice(x->devices[r]));
         X_TRY(hipDeviceSynchronize());
     }
-    if (x->rccl_state.load() == kRcclReady) {
+    for (int r = 0; r < n && num_events > 0; ++r) {
+        X_TRY(hipSetDevice(x->devices[r]));
+        for (int e = 0; e < num_events; ++e) {
+            if (hip_events[e]) {
+                X_TRY(hipStreamWaitEvent(x->streams[r], (hipEvent_t)hip_events[e], 0));
+            }
+        }
+    }
+    if (x->rccl_state == kRcclReady) {
         x->exchanges_rccl++;
         // Repetition l of the device list is ranks l * period .. (l + 1) * period - 1, one per device in communicator order: its
         // all-gather, run by the leaders (a send buffer only has to live on the leader's device), fills blocks l * period ..
@@ -607,16 +614,52 @@ static int exchange_allgather(apd_exchange_t x, const void *const *send, void *c
         }
     } else {
         x->exchanges_copy++;
-        for (int dst = 0; dst < n; ++dst) {  // every rank pulls every block on its own stream
+        // Every rank pulls every block on its own stream: one gather kernel over the blocks its device can read directly, a peer
+        // copy for the others.  Ranks that share a device with an earlier rank copy that rank's finished result instead (one
+        // contiguous read of local memory, no second trip over xGMI).
+        const size_t words = bytes_per_rank / 16, tail = bytes_per_rank % 16;
+        const bool kernel_ok = n <= apd::kGatherMaxRanks && (tail == 0 || n == 1);
+        for (int dst = 0; dst < n; ++dst) {
             X_TRY(hipSetDevice(x->devices[dst]));
+            int twin = -1;   // an earlier rank on the same device
+            for (int q = 0; q < dst && twin < 0; ++q) {
+                twin = x->devices[q] == x->devices[dst] ? q : -1;
+            }
+            apd::GatherArgs ga;
+            memset(&ga, 0, sizeof(ga));
+            if (twin >= 0) {
+                X_TRY(hipStreamWaitEvent(x->streams[dst], x->done[twin], 0));
+                const size_t all = (size_t)n * bytes_per_rank;
+                if (all % 16 == 0 && all > 0 && ((uintptr_t)recv[dst] % 16) == 0 && ((uintptr_t)recv[twin] % 16) == 0) {
+                    ga.src[0] = reinterpret_cast<const apd::word4 *>(recv[twin]);   // the whole result as one block
+                    const unsigned gx = (unsigned)std::min<size_t>((all / 16 + 255) / 256, 2048);
+                    hipLaunchKernelGGL(apd::k_gather_blocks, dim3(gx, 1), dim3(256), 0, x->streams[dst], ga, reinterpret_cast<apd::word4 *>(recv[dst]), all / 16, (size_t)0);
+                    X_TRY(hipGetLastError());
+                } else {
+                    X_TRY(hipMemcpyAsync(recv[dst], recv[twin], all, hipMemcpyDeviceToDevice, x->streams[dst]));
+                }
+                X_TRY(hipEventRecord(x->done[dst], x->streams[dst]));
+                continue;
+            }
+            int direct = 0;
             for (int src = 0; src < n; ++src) {
                 char *to = (char *)recv[dst] + (size_t)src * bytes_per_rank;
-                if (x->devices[src] == x->devices[dst]) {
+                const bool aligned = ((uintptr_t)send[src] % 16) == 0 && ((uintptr_t)to % 16) == 0;
+                if (kernel_ok && aligned && x->peer_ok[(size_t)dst * n + src] && bytes_per_rank > 0) {
+                    ga.src[src] = reinterpret_cast<const apd::word4 *>(send[src]);
+                    ++direct;
+                } else if (x->devices[src] == x->devices[dst]) {
                     X_TRY(hipMemcpyAsync(to, send[src], bytes_per_rank, hipMemcpyDeviceToDevice, x->streams[dst]));
                 } else {
                     X_TRY(hipMemcpyPeerAsync(to, x->devices[dst], send[src], x->devices[src], bytes_per_rank, x->streams[dst]));
                 }
             }
+            if (direct > 0) {
+                const unsigned gx = (unsigned)std::min<size_t>((words + 255) / 256 + 1, 2048 / (size_t)std::max(1, std::min(direct, 8)) + 1);
+                hipLaunchKernelGGL(apd::k_gather_blocks, dim3(gx, (unsigned)n), dim3(256), 0, x->streams[dst], ga, reinterpret_cast<apd::word4 *>(recv[dst]), words, tail);
+                X_TRY(hipGetLastError());
+            }
+            X_TRY(hipEventRecord(x->done[dst], x->streams[dst]));
         }
     }
     for (int r = 0; r < n; ++r) {
@@ -631,18 +674,18 @@ int apd_exchange_destroy(apd_exchange_t x)
     if (!x) {
         return APD_OK;
     }
-    if (x->init_thread.joinable()) {
-        x->init_thread.join();
-    }
     for (void *c : x->comms) {
         if (c) {
             g_rccl.CommDestroy(c);
         }
     }
     for (size_t i = 0; i < x->streams.size(); ++i) {
+        hipSetDevice(x->devices[i]);
         if (x->streams[i]) {
-            hipSetDevice(x->devices[i]);
             hipStreamDestroy(x->streams[i]);
+        }
+        if (i < x->done.size() && x->done[i]) {
+            hipEventDestroy(x->done[i]);
         }
     }
     delete x;

@@ -86,8 +86,6 @@ bool ParseOptions(int argc, char **argv, Options &o)
             o.use_rccl = false;
         } else if (a == "--exchange-device-sync") {
             o.exchange_device_sync = true;
-        } else if (a == "--async-rccl") {
-            o.async_rccl = true;
         } else if (a == "--rccl") {
             o.force_rccl = true;
         } else if (i == 2 && a.size() && a[0] != '-') {
@@ -238,7 +236,7 @@ int main(int argc, char **argv)
     const auto t_start = std::chrono::steady_clock::now();
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
-        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl] [--async-rccl] [--exchange-device-sync] [--late-fusion-inputs] [--copy-images] [--clean-exit]\n");
+        fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl] [--exchange-device-sync] [--late-fusion-inputs] [--copy-images] [--clean-exit]\n");
         return EXIT_FAILURE;
     }
     if (opt.devices.empty()) {
@@ -249,9 +247,6 @@ int main(int argc, char **argv)
             fprintf(stderr, "Requested GPU %d, found %d device(s)\n", d, apd_device_count());
             return EXIT_FAILURE;
         }
-    }
-    if (WantsRccl(opt) && !opt.files && opt.async_rccl) {
-        apd_exchange_preload_rccl();   // librccl.so: 5 s to dlopen from a cold page cache, 1 s warm; started before pair.txt and the image decode
     }
     APD::SetDevice(opt.gpu_index);
     SetFusionDevice(opt.gpu_index);
@@ -303,20 +298,20 @@ int main(int argc, char **argv)
     bool auto_in_memory = false;   // the in-memory scheduler was this function's choice, not the command line's
     if (!opt.files && !opt.in_memory && !opt.jacobi && opt.devices.size() == 1) {
         int w = 0, h = 0;
-        size_t free_bytes = 0, total_bytes = 0;
-        if (CheckImages(problems, w, h) && apd_device_memory(opt.gpu_index, &free_bytes, &total_bytes) == APD_OK) {
+        if (CheckImages(problems, w, h)) {
             size_t max_src = 1;
             for (const Problem &p : problems) {
                 max_src = std::max(max_src, p.src_image_ids.size());
             }
+            // the scheduler's own test (same function, same free-memory figure and --scheduler-free-gb cap), BEFORE it loads a single
+            // full-size image or prints its header: a folder that does not fit goes to the file loop at once
             const int lanes = InMemoryLanes(opt, w, h, (int)problems.size(), 1, true);   // the count RunMultiDevice will use
-            const double need = (double)w * h * InMemoryBytesPerPixel((int)ids.size(), (int)problems.size(), 1, lanes, (int)max_src, nullptr, nullptr,
-                                                                      !(opt.no_fusion || opt.late_fusion_inputs));
-            opt.in_memory = need < 0.9 * (double)free_bytes;
+            const InMemoryFit fit = TestInMemoryFit(opt, opt.gpu_index, w, h, (int)ids.size(), (int)problems.size(), 1, lanes, (int)max_src);
+            opt.in_memory = fit.have_memory && fit.fits;
             auto_in_memory = opt.in_memory;
-            if (!opt.in_memory) {
-                printf("%.1f GB of resident state against %.1f GB free on device %d: passing state through files\n", need / 1e9,
-                       free_bytes / 1e9, opt.gpu_index);
+            if (fit.have_memory && !fit.fits) {
+                printf("%.1f GB of resident state against %.1f GB free on device %d: this folder does not fit the in-memory scheduler, passing state through files\n",
+                       fit.need_bytes / 1e9, fit.free_bytes / 1e9, opt.gpu_index);
             }
         }
     }

@@ -98,6 +98,7 @@ struct ResidentView {
 struct Lane {
     apd_handle handle = nullptr;
     int handle_w = 0, handle_h = 0;
+    void *export_event = nullptr;   // hipEvent_t behind the handle's newest export (apd_export_event); written and read under done_m
     DeviceBuffer scratch_planes, scratch_weak, scratch_views;  // resampling targets (swapped with a view's buffers)
 };
 
@@ -209,6 +210,26 @@ int InMemoryLanes(const Options &opt, int width, int height, int num_views, int 
                     lanes_at((size_t)std::lround(width / (double)coarsest) * (size_t)std::lround(height / (double)coarsest)));
 }
 
+InMemoryFit TestInMemoryFit(const Options &opt, int device, int width, int height, int num_images, int num_views, int num_ranks, int lanes, int max_sources)
+{
+    InMemoryFit fit;
+    size_t free_bytes = 0, total_bytes = 0;
+    double per_px_passes = 0, per_px_final = 0;
+    const double pixels = (double)width * (double)height;
+    const bool prefetch = !(opt.no_fusion || opt.late_fusion_inputs);
+    fit.need_bytes = pixels * InMemoryBytesPerPixel(num_images, num_views, num_ranks, lanes, max_sources, &per_px_passes, &per_px_final, prefetch);
+    fit.have_memory = apd_device_memory(device, &free_bytes, &total_bytes) == APD_OK;
+    if (fit.have_memory && opt.scheduler_free_gb > 0) {
+        free_bytes = std::min(free_bytes, (size_t)(opt.scheduler_free_gb * 1e9));
+    }
+    fit.free_bytes = (double)free_bytes;
+    // room for the passes' buffers AND the final maps at once: the handles, level images and depth sets are then left to the end of
+    // the process instead of being released one hipFree (= one device synchronisation) at a time before the fusion
+    fit.release_before_fusion = !fit.have_memory || pixels * (per_px_passes + per_px_final) > 0.8 * (double)free_bytes;
+    fit.fits = !fit.have_memory || fit.need_bytes <= 0.9 * (double)free_bytes;
+    return fit;
+}
+
 int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
 {
     StageClock stage;
@@ -279,20 +300,11 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
     bool release_before_fusion = true;
     printf("There are %d problems needed to be processed on %d rank(s), up to %d view(s) in flight per rank!\nRound nums: %d\n", V, G, lanes, round_num);
     {
-        size_t free_bytes = 0, total_bytes = 0;
-        double per_px_passes = 0, per_px_final = 0;
-        const bool prefetch = !(opt.no_fusion || opt.late_fusion_inputs);
-        const double need = (double)pix0 * InMemoryBytesPerPixel(N, V, G, lanes, (int)max_src, &per_px_passes, &per_px_final, prefetch);
-        const bool have_memory = apd_device_memory(devices[0], &free_bytes, &total_bytes) == APD_OK;
-        if (have_memory && opt.scheduler_free_gb > 0) {
-            free_bytes = std::min(free_bytes, (size_t)(opt.scheduler_free_gb * 1e9));
-        }
-        // room for the passes' buffers AND the final maps at once: the handles, level images and depth sets are then left to the end of
-        // the process instead of being released one hipFree (= one device synchronisation) at a time before the fusion
-        release_before_fusion = !have_memory || (double)pix0 * (per_px_passes + per_px_final) > 0.8 * (double)free_bytes;
-        if (have_memory && need > 0.9 * (double)free_bytes) {
+        const InMemoryFit fit = TestInMemoryFit(opt, devices[0], W0, H0, N, V, G, lanes, (int)max_src);
+        release_before_fusion = fit.release_before_fusion;
+        if (fit.have_memory && !fit.fits) {
             fprintf(stderr, "%.1f GB of resident state against %.1f GB free on device %d: this folder does not fit the in-memory scheduler "
-                            "(use --files, more devices or fewer views in flight: --ranks 1)\n", need / 1e9, free_bytes / 1e9, devices[0]);
+                            "(use --files, more devices or fewer views in flight: --ranks 1)\n", fit.need_bytes / 1e9, fit.free_bytes / 1e9, devices[0]);
             return kExitDoesNotFit;   // main() falls back to the file-based loop when it had chosen this scheduler by itself
         }
     }
@@ -343,19 +355,11 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         }
         const long long ms_alloc = stage.lap();
         // RCCL's set-up costs seconds (dlopen of librccl 5.0 s from a cold page cache / 1.0 s warm, ncclCommInitAll 0.65 s for one device:
-        // profiles/r05/rccl_init_time.txt) and runs here, before the first pass.  --async-rccl moves it behind the start-up and the first
-        // passes (the dlopen from main()'s first line, the communicators on a thread of the exchange; a pass that ends before RCCL is ready
-        // exchanges its maps with direct copies) -- measured on 24 views of 1920 x 1080 (profiles/r05/ab_rccl_async_tt24.txt): the dlopen
-        // stalls every HIP call of the other threads for as long as it runs (start-up 0.16 -> 1.24 s warm, 4.9 s cold), and the passes take
-        // 9.3 s instead of 7.5 s; the blocking set-up stays the default.  Ranks that share one device have nothing to send through xGMI and
-        // do without RCCL unless --rccl.
+        // profiles/r05/rccl_init_time.txt) and runs here, before the first pass (moving it behind the passes lost: csrc/apd_exchange.hip).
+        // Ranks that share one device have nothing to send through xGMI and do without RCCL unless --rccl.
         const bool want_rccl = WantsRccl(opt);
-        if (want_rccl && opt.async_rccl) {
-            Check(apd_exchange_create_async(&exchange, G, devices.data(), 1), "apd_exchange_create_async");
-        } else {
-            Check(apd_exchange_create(&exchange, G, devices.data(), want_rccl ? 1 : 0), "apd_exchange_create");
-        }
-        printf("Device buffers: %lld ms, exchange set-up: %lld ms%s\n", ms_alloc, stage.lap(), (want_rccl && opt.async_rccl) ? " (RCCL continues behind the passes)" : "");
+        Check(apd_exchange_create(&exchange, G, devices.data(), want_rccl ? 1 : 0), "apd_exchange_create");
+        printf("Device buffers: %lld ms, exchange set-up: %lld ms\n", ms_alloc, stage.lap());
         printf("Exchange of depth maps between passes: %s\n", apd_exchange_backend(exchange));
 
         auto gathered_depth = [&](const Rank &k, int v, size_t pix) {  // view v inside a gathered block (the pass before)
@@ -457,6 +461,10 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             const apd_params p = ToAbi(q);
             if (!lane.handle || lane.handle_w != LW || lane.handle_h != LH) {
                 if (lane.handle) {
+                    {
+                        std::lock_guard<std::mutex> lock(done_m);
+                        lane.export_event = nullptr;   // the event goes with the handle
+                    }
                     apd_destroy(lane.handle);
                     lane.handle = nullptr;
                 }
@@ -522,8 +530,11 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             s.W = LW;
             s.H = LH;
             s.valid = true;
+            void *exported = nullptr;
+            Check(apd_export_event(lane.handle, &exported), "apd_export_event");
             {
                 std::lock_guard<std::mutex> lock(done_m);
+                lane.export_event = exported;
                 done_pass[v] = pass.iteration;
                 printf("pass %d (round %d, scale %d) view %08d done on rank %d (device %d)\n", pass.iteration, pass.level, pass.scale_size,
                        problem.ref_image_id, r, k.device);
@@ -733,12 +744,26 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                                             send[q] = ranks[q].send.p;
                                             recv[q] = ranks[q].recv.p;
                                         }
-                                        // every view of the pass has exported and synchronised its stream (apd_export_state_device); the
-                                        // readers of the old gathered maps were views of this pass: no device-wide synchronisation, the
-                                        // first halves other lanes have queued for the next pass keep running beside the exchange
+                                        // every view of the pass has exported; the exchange's streams wait for the export event of every
+                                        // lane's handle (each marks the newest export on that lane's stream: at least this pass's) and for
+                                        // nothing else -- no device-wide synchronisation, the first halves other lanes have queued for the
+                                        // next pass keep running beside the exchange.  The readers of the old gathered maps were views of
+                                        // this pass.
+                                        std::vector<void *> exported;
+                                        {
+                                            std::lock_guard<std::mutex> lock(done_m);
+                                            for (Rank &q : ranks) {
+                                                for (Lane &l : q.lanes) {
+                                                    if (l.export_event) {
+                                                        exported.push_back(l.export_event);
+                                                    }
+                                                }
+                                            }
+                                        }
                                         Check(opt.exchange_device_sync
                                                   ? apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float))
-                                                  : apd_exchange_allgather_ready(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float)),
+                                                  : apd_exchange_allgather_after(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float),
+                                                                                 (int)exported.size(), exported.data()),
                                               "apd_exchange_allgather");
                                         {
                                             std::lock_guard<std::mutex> lock(done_m);
@@ -777,6 +802,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                     if (l.handle) {
                         apd_destroy(l.handle);
                         l.handle = nullptr;
+                        l.export_event = nullptr;
                     }
                     l.scratch_planes.release();
                     l.scratch_weak.release();
@@ -810,7 +836,6 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             }
             std::vector<const void *> send(G);
             std::vector<void *> recv(G);
-            apd_exchange_wait(exchange, nullptr, nullptr);   // the final maps go through RCCL (north_star): it has had all passes to get ready
             for (int sl = 0; sl < slots; ++sl) {
                 for (int pass_kind = 0; pass_kind < 2; ++pass_kind) {
                     const size_t elem = pass_kind == 0 ? 16 : 1;
@@ -871,11 +896,10 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         {
             int with_rccl = 0, with_copies = 0;
             apd_exchange_counts(exchange, &with_rccl, &with_copies);
-            double setup = 0, waited = 0, dl = 0, init = 0;
-            apd_exchange_wait(exchange, &setup, &waited);
+            double dl = 0, init = 0;
             apd_exchange_setup_times(exchange, &dl, &init);
-            printf("Exchanges: %d through RCCL, %d through direct copies; RCCL set-up: dlopen %.0f ms, communicators %.0f ms (incl. waiting for the dlopen), "
-                   "waited for at the end of the passes %.0f ms; backend now %s\n", with_rccl, with_copies, dl, init, waited, apd_exchange_backend(exchange));
+            printf("Exchanges: %d through RCCL, %d through direct copies; RCCL set-up: dlopen %.0f ms, communicators %.0f ms (incl. the dlopen when this "
+                   "exchange was the process's first); backend %s\n", with_rccl, with_copies, dl, init, apd_exchange_backend(exchange));
         }
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_all).count();
         printf("All passes done: %lld ms\n", (long long)ms);

@@ -20,9 +20,6 @@ struct Options {
     bool in_memory = false;     // --in-memory: the in-memory scheduler on one device in the reference's own order (one rank, a view reads the
                                 // depth maps its sources have at that moment): the file-based driver's bytes without the files
     bool use_rccl = true;       // --no-rccl: exchange maps with direct copies
-    bool async_rccl = false;    // --async-rccl: RCCL's set-up runs behind the start-up and the first passes instead of blocking before the first pass.
-                                // Measured slower on this box (profiles/r05/ab_rccl_async_tt24.txt): the dlopen of librccl stalls every other thread's HIP
-                                // calls while it runs, and passes that overlap ncclCommInitAll lose more than the 0.65 s it takes
     bool exchange_device_sync = false;  // --exchange-device-sync: the per-pass exchange synchronises every device first, as in rounds 2-4 (A/B measurements)
     bool force_rccl = false;    // --rccl: RCCL even for a single rank (which has nothing to exchange between devices and uses direct copies otherwise)
     uint64_t seed = 12345;
@@ -39,8 +36,8 @@ struct Options {
 
 // One pass over all views.  round_num pyramid levels, coarse to fine; per level one photometric pass and three
 // geometric ones (main.cpp:168-215).
-// true when a run over this device list sets RCCL up (several physical devices, or --rccl).  With --async-rccl main() starts the dlopen of
-// librccl before anything else (apd_exchange_preload_rccl) and RunMultiDevice initialises the communicators behind the first passes
+// true when a run over this device list sets RCCL up (several physical devices, or --rccl); the set-up blocks before the first pass
+// (round 5's --async-rccl measured slower and is gone: profiles/r05/ab_rccl_async_tt24.txt)
 inline bool WantsRccl(const Options &opt)
 {
     bool several = false;
@@ -126,6 +123,15 @@ int DefaultLanes(size_t pixels);
 int InMemoryLanes(const Options &opt, int width, int height, int num_views, int num_ranks, bool distinct_devices);
 double InMemoryBytesPerPixel(int num_images, int num_views, int num_ranks, int lanes, int max_sources, double *passes_out = nullptr,
                              double *final_out = nullptr, bool fusion_prefetch = false);
+// The scheduler's fit test, ONE function for main()'s choice of scheduler and for RunMultiDevice's own check: bytes the run keeps resident on
+// `device` (its busiest one) against 90 % of the free device memory, the latter capped by --scheduler-free-gb.
+struct InMemoryFit {
+    bool have_memory = false;            // hipMemGetInfo answered
+    bool fits = true;                    // need <= 0.9 * free (true when the device did not answer: the allocations will tell)
+    bool release_before_fusion = true;   // no room for the passes' buffers and the final maps at once
+    double need_bytes = 0, free_bytes = 0;
+};
+InMemoryFit TestInMemoryFit(const Options &opt, int device, int width, int height, int num_images, int num_views, int num_ranks, int lanes, int max_sources);
 constexpr int kExitDoesNotFit = 75;  // RunMultiDevice: the folder does not fit the in-memory scheduler (nothing has been run or written)
 
 // APD.h:34 with the maps already in memory (index = problem index); RunFusion reads them from the result folders instead

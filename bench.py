@@ -49,6 +49,7 @@ DEFAULT_WORKLOAD = "eth3d_office_fullres_8src"
 WORKLOADS = {
     # name: (width, height, num_src)
     "eth3d_office_fullres_8src": (6200, 4130, 8),    # BASELINE.json configs[1]
+    "eth3d_office_halfres_2src": (3100, 2065, 2),    # configs[0]: half resolution, 2 source views (the reference's CPU-path case)
     "eth3d_pipes_fullres_10src": (6200, 4130, 10),   # configs[2] shape (strong pixels only here)
     "synthetic_4096x3072_16src": (4096, 3072, 16),   # configs[4]
     "tt_family_1080p_10src": (1920, 1080, 10),       # configs[3] shape
@@ -372,8 +373,8 @@ class SweepWorkload:
             # two views in flight on one device share the CUs: per-launch times of such a line are not a kernel's own
             "roofline": None if len(hs) > 1 else (weak_roofline if self.apd_mode else roofline),
             "strong_path": roofline if (self.apd_mode and len(hs) == 1) else None,
-            "weak_path": weak_path,
-            "iterations": {"first_ms": round(first_iter_s * 1e3, 3),
+            "weak_path": weak_path if len(hs) == 1 else None,   # per-launch event times of views sharing the CUs are not a kernel's own
+            "iterations": {"first_ms": round(first_iter_s * 1e3, 3) if len(hs) == 1 else None,   # several views in flight: iteration 0 is not timed on its own
                            "later_ms_per_step": round(later_s / max(steps - 1, 1) * 1e3, 3) if steps > 1 and len(hs) == 1 and not pass_exchange else None,
                            "later_value": round(views_total * mpix * (steps - 1) / later_s, 4) if steps > 1 and len(hs) == 1 and not pass_exchange else None,
                            "note": "timed region = iterations 0..K-1 of a freshly initialised pass; iteration 0 starts from random planes"},
@@ -621,7 +622,10 @@ def weak_rooflines(pkg, prof, W, H, N, weak_fraction, workload, steps, warmup, o
 
 # The sub-lines of the `workloads` block: every BASELINE.json config on the clock of the same process, after the headline.
 # (key, workload, steps, warmup, pass_exchange, views_per_gpu)
+CONFIGS0_KEY = "configs0_office_halfres_2src_3iter"
 SUB_WORKLOADS = [
+    (CONFIGS0_KEY, "eth3d_office_halfres_2src", 3, 1, False, 1),   # configs[0]: the shape BASELINE.json runs on the CPU path; the oracle
+    # is timed on the SAME shape and iterations right after (run_cpu_configs0), so the config has its HIP and its CPU number side by side
     ("configs1_office_6iter", "eth3d_office_fullres_8src", 6, 1, False, 1),        # configs[1] at its own six iterations
     ("configs1_office_ref_pass_3iter", "eth3d_office_fullres_8src", 3, 1, False, 1),  # ... at the reference's default pass (main.cpp:183)
     ("configs2_pipes_apd_3iter", "eth3d_pipes_fullres_10src_apd", 3, 1, False, 1),  # configs[2]: adaptive patches on (K9/K10 roofline)
@@ -840,6 +844,10 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
         cpu_baseline = run_cpu_baseline(args, N_head, np)
+        if workloads.get(CONFIGS0_KEY, {}).get("value") is not None:   # configs[0] names the CPU path: its own shape on the CPU, same line
+            c0 = run_cpu_configs0(args)
+            workloads[CONFIGS0_KEY]["cpu_baseline"] = c0
+            workloads[CONFIGS0_KEY]["hip_over_cpu"] = round(workloads[CONFIGS0_KEY]["value"] / c0["value"], 1) if c0["value"] > 0 else None
 
     if rank == 0:
         out = {
@@ -881,21 +889,25 @@ def main():
     return 0
 
 
-COMPACT_LINE_MAX_BYTES = 2000   # the driver keeps a bounded tail of stdout (BENCH_r04.parsed was null with a 24 KB line)
+COMPACT_LINE_MAX_BYTES = 1990   # the driver keeps a bounded tail of stdout (BENCH_r04.parsed was null with a 24 KB line)
 FULL_BLOCK_FILE = "bench_workloads.json"
 
 
 def compact_roofline(r):
-    """The roofline object of the stdout line: numbers only, notes stay in the full block."""
+    """The roofline object of the stdout line: numbers only, notes stay in the full block.  `frac` is the fraction of the bound the
+    kernel actually runs into (`frac_kind`); SURVEY 8(d)'s algorithmic-byte ratio is carried beside it as `algorithmic_over_hbm_peak`
+    (it prices LDS / L1 / L2 hits as HBM bytes and exceeds 1: not a roofline)."""
     if not r:
         return None
     alg = r.get("algorithmic") or {}
     hbm = r.get("hbm") or {}
-    return {"bound": r.get("bound"), "kernel": str(r.get("kernel", "")).split(" ")[0], "achieved": r.get("achieved"), "peak": r.get("peak"),
-            "unit": r.get("unit"), "frac": r.get("frac"), "traffic": None if r.get("traffic") is None else int(r["traffic"]),
+    gbps = alg.get("GBps", alg.get("GBps_nominal_max"))
+    return {"bound": r.get("bound"), "frac_kind": r.get("bound"), "kernel": str(r.get("kernel", "")).split(" ")[0], "achieved": r.get("achieved"),
+            "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"), "traffic": None if r.get("traffic") is None else int(r["traffic"]),
             "avg_launch_ms": r.get("avg_launch_ms"), "launches": r.get("launches"), "hbm_frac": hbm.get("frac"),
-            "valu_busy": (r.get("valu_busy_estimate") or {}).get("frac"),   # frac weighted with the body's instruction mix (2.78 cycles per instruction, not 2)
-            "algorithmic_GBps": alg.get("GBps"), "pmc_source": r.get("pmc_source")}
+            "valu_busy": (r.get("valu_busy_estimate") or {}).get("frac"),   # frac weighted with the whole kernel's instruction mix
+            "algorithmic_GBps": gbps, "algorithmic_over_hbm_peak": None if gbps is None else round(gbps / HBM_PEAK_GBPS, 2),
+            "pmc_source": r.get("pmc_source")}
 
 
 def compact_workloads(workloads):
@@ -915,9 +927,14 @@ def compact_workloads(workloads):
     return out
 
 
+CONFIG_ITERS_KEY = "configs1_office_6iter"          # configs[1] at the six iterations the config names
+WHOLE_PASS_KEY = "configs2_pipes_apd_whole_pass"    # apd_run = RunPatchMatch, K1..K15: what a real schedule runs at full size
+
+
 def compact_line(out):
     """The ONE stdout line: headline + roofline + cpu_baseline + one triple per sub-workload, at most COMPACT_LINE_MAX_BYTES bytes.
-    Everything else of `out` is in FULL_BLOCK_FILE and on stderr."""
+    Everything else of `out` is in FULL_BLOCK_FILE and on stderr.  A line that would not fit is shortened (cpu sample text, then the
+    per-workload triples, then pmc_source) and says so in `truncated` -- it never costs a measured run its line."""
     cfg = out["config"]
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data")}
@@ -928,20 +945,45 @@ def compact_line(out):
     cb = out.get("cpu_baseline")
     line["cpu_baseline"] = None if not cb else {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                                 "sample": cb.get("sample_short", cb["sample"])[:96]}
-    line["workloads"] = compact_workloads(out.get("workloads") or {})
+    wl = out.get("workloads") or {}
+    # what the headline is NOT: the config at its own iteration count, and a whole pass of the real schedule
+    it6 = wl.get(CONFIG_ITERS_KEY) or {}
+    line["value_config_iters"] = out["value"] if out.get("steps") == 6 and cfg.get("workload") == DEFAULT_WORKLOAD else it6.get("value")
+    wp = wl.get(WHOLE_PASS_KEY) or {}
+    line["whole_pass"] = None if wp.get("value") is None else [wp["value"], wp.get("ms_per_pass")]
+    c0 = (wl.get(CONFIGS0_KEY) or {}).get("cpu_baseline")
+    line["configs0_cpu"] = None if not c0 else [c0["value"], c0["cores"]]   # configs[0] on the CPU (oracle, same shape); its HIP value is in `workloads`
+    line["workloads"] = compact_workloads(wl)
     line["workloads_fields"] = ["value", "ms_per_step|ms_per_pass", "frac"]
     line["full_block"] = FULL_BLOCK_FILE
     if out.get("selftest"):
         line["selftest"] = True
-    text = json.dumps(line, separators=(",", ":"))
-    assert len(text.encode()) <= COMPACT_LINE_MAX_BYTES, "bench.py: the stdout line grew to %d bytes (limit %d)" % (len(text.encode()), COMPACT_LINE_MAX_BYTES)
-    return text
+
+    def size():
+        return len(json.dumps(line, separators=(",", ":")).encode())
+
+    steps_taken = []
+    if size() > COMPACT_LINE_MAX_BYTES and line["cpu_baseline"]:
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:24]
+        steps_taken.append("cpu_baseline.sample")
+    if size() > COMPACT_LINE_MAX_BYTES:
+        line["workloads"] = {k: v[0] for k, v in line["workloads"].items()}
+        line["workloads_fields"] = ["value"]
+        steps_taken.append("workloads: values only")
+    if size() > COMPACT_LINE_MAX_BYTES and line["roofline"]:
+        line["roofline"]["pmc_source"] = None
+        steps_taken.append("roofline.pmc_source")
+    if size() > COMPACT_LINE_MAX_BYTES:
+        line["workloads"] = None
+        steps_taken.append("workloads")
+    if steps_taken:
+        line["truncated"] = steps_taken
+    return json.dumps(line, separators=(",", ":"))
 
 
 def emit(out, full_line=False):
-    """Full block -> FULL_BLOCK_FILE (next to bench.py, and under gpurun_out/ when that exists) and stderr; compact line -> the LAST and
-    only line of stdout."""
-    text = compact_line(out)   # a line that does not fit is a bug: fail before anything is printed
+    """Full block -> FULL_BLOCK_FILE (next to bench.py, and under gpurun_out/ when that exists) and stderr FIRST; then the compact line
+    -> the LAST and only line of stdout."""
     full = json.dumps(out)
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
@@ -952,6 +994,7 @@ def emit(out, full_line=False):
                 sys.stderr.write("bench.py: could not write %s: %r\n" % (os.path.join(d, FULL_BLOCK_FILE), e))
     sys.stderr.write("bench.py full block: " + full + "\n")
     sys.stderr.flush()
+    text = compact_line(out)
     print(full if full_line else text, flush=True)
 
 
@@ -1101,24 +1144,21 @@ def load_valu_mix(prefer_dir=None):
     return best
 
 
-def run_cpu_baseline(args, num_src, np):
-    """The oracle (kind "port": plain-C restatement of the reference path, OpenMP over pixels) timed on
-    this host's cores on a bounded sample of the same workload: same generator, same N, smaller frame, and the same
-    iterations the GPU line times (iteration 0 on random planes included)."""
+def time_oracle_sweeps(width, height, num_src, steps, seed, budget_s):
+    """Iterations 0..steps-1 of a fresh FIRST_INIT pass on the CPU oracle (K1, K2, K5 untimed, like the GPU lines), stopped early
+    once `budget_s` is spent.  Returns (iterations done, seconds, threads)."""
     import __graft_entry__ as ge
     ge.load_package()
     from apd_mvs_amd import synth
     from oracle import binding as ob
 
-    w, hgt = [int(v) for v in args.cpu_sample.lower().split("x")]
-
-    def make(width, height):
-        sc = synth.make_scene(width, height, num_src, seed=0)
+    def make(w, h):
+        sc = synth.make_scene(w, h, num_src, seed=0)
         imgs = sc.images_numpy()
-        cams = [ob.make_camera(sc.K[i], sc.R[i], sc.t[i], width, height, sc.depth_min, sc.depth_max) for i in range(num_src + 1)]
+        cams = [ob.make_camera(sc.K[i], sc.R[i], sc.t[i], w, h, sc.depth_min, sc.depth_max) for i in range(num_src + 1)]
         p = ob.default_params(num_images=num_src + 1, depth_min=0.6 * sc.depth_min, depth_max=1.2 * sc.depth_max, use_APD=0,
-                              state=ob.FIRST_INIT, max_iterations=args.steps, seed=args.seed)
-        o = ob.Oracle(width, height, p, cams, imgs)
+                              state=ob.FIRST_INIT, max_iterations=steps, seed=seed)
+        o = ob.Oracle(w, h, p, cams, imgs)
         for kid in (1, 2, 5):
             o.run_kernel(kid)
         return o
@@ -1126,21 +1166,40 @@ def run_cpu_baseline(args, num_src, np):
     tiny = make(160, 120)  # thread pool and code warm-up on a throw-away frame
     tiny.run_sweeps(0, 1)
     tiny.close()
-    o = make(w, hgt)
+    o = make(width, height)
     iters = 0
     t0 = time.perf_counter()
     while True:
         o.run_sweeps(iters, 1)
         iters += 1
         dt = time.perf_counter() - t0
-        if dt > 12.0 or iters >= min(args.steps, 8):
+        if dt > budget_s or iters >= steps:
             break
-    cores = ob.lib().orc_get_threads()
+    cores = int(ob.lib().orc_get_threads())
     o.close()
-    return {"value": round(w * hgt * iters / dt / 1e6, 5), "unit": "Mpix*iter/s", "cores": int(cores), "kind": "port",
+    return iters, dt, cores
+
+
+def run_cpu_baseline(args, num_src, np):
+    """The oracle (kind "port": plain-C restatement of the reference path, OpenMP over pixels) timed on
+    this host's cores on a bounded sample of the same workload: same generator, same N, smaller frame, and the same
+    iterations the GPU line times (iteration 0 on random planes included)."""
+    w, hgt = [int(v) for v in args.cpu_sample.lower().split("x")]
+    iters, dt, cores = time_oracle_sweeps(w, hgt, num_src, min(args.steps, 8), args.seed, 12.0)
+    return {"value": round(w * hgt * iters / dt / 1e6, 5), "unit": "Mpix*iter/s", "cores": cores, "kind": "port",
             "sample": "%dx%d frame of the same synthetic scene, %d src views, iterations 0..%d of a fresh pass (iteration 0 included, "
                       "as in the GPU line), %.1f s" % (w, hgt, num_src, iters - 1, dt),
             "sample_short": "%dx%d, %d src, iterations 0..%d, %.1f s" % (w, hgt, num_src, iters - 1, dt)}
+
+
+def run_cpu_configs0(args):
+    """BASELINE.json configs[0] on the CPU, beside its HIP sub-line: the oracle on the SAME shape (3100 x 2065, 2 source views, no crop)
+    and the same three iterations of a fresh FIRST_INIT pass; a host too slow to finish inside the budget stops after fewer iterations and
+    the sample says so."""
+    (w, hgt, n), _ = resolve_workload("eth3d_office_halfres_2src")
+    iters, dt, cores = time_oracle_sweeps(w, hgt, n, 3, args.seed, 25.0)
+    return {"value": round(w * hgt * iters / dt / 1e6, 5), "unit": "Mpix*iter/s", "cores": cores, "kind": "port",
+            "sample": "the whole %dx%d frame, %d src views, iterations 0..%d of 0..2, %.1f s" % (w, hgt, n, iters - 1, dt)}
 
 
 if __name__ == "__main__":

@@ -207,6 +207,10 @@ int apd_export_depth_normal_device(apd_handle h, float *depth_dev, float *normal
  * (main.cpp:109-112), selected views, and the depth map alone (what the geometric term of the next pass reads,
  * APD.cpp:492-509).  DEVICE pointers, W*H elements each; any may be NULL. */
 int apd_export_state_device(apd_handle h, float *planes4_dev, uint8_t *weak_dev, uint32_t *views_dev, float *depth_dev);
+/* The HIP event (hipEvent_t) the handle records on its stream behind the kernel of its last apd_export_state_device /
+ * apd_export_depth_normal_device (NULL before the first export): what a consumer on another stream waits for
+ * (apd_exchange_allgather_after).  Owned by the handle, re-recorded by every export. */
+int apd_export_event(apd_handle h, void **hip_event);
 
 /* ---- several devices in one process (one host thread + one stream per device) ----------------------------
  * The reference takes one device index (main.cpp:149-153).  A multi-device host shards the reference views over devices
@@ -248,21 +252,17 @@ int apd_host_free(void *p);
 typedef struct apd_exchange *apd_exchange_t;
 /* prefer_rccl != 0: RCCL, set up before the call returns.  That takes seconds on a fresh box (5.0 s to dlopen librccl from a cold page
  * cache, 1.0 s warm; ncclCommInitAll 0.65 s for one device: profiles/r05/rccl_init_time.txt); a caller with a single rank should pass 0.
- * apd_exchange_preload_rccl: starts the dlopen on a thread of its own and returns at once -- call it first thing in a process that
- *   will exchange between devices, before the images are decoded.
- * apd_exchange_create_async: as apd_exchange_create, but the communicators are initialised on a thread while the caller goes on;
- *   apd_exchange_allgather moves its bytes with direct copies until RCCL is ready and with RCCL from then on (same result).
- * apd_exchange_wait: blocks until that set-up has ended (ready or failed); setup_ms = what it took on its thread, waited_ms = what
- *   this call waited.  apd_exchange_setup_times: the dlopen's and the initialisation's own durations (init_ms = -1 while running). */
+ * (Round 5's asynchronous set-up -- preload thread, communicators initialised behind the first passes -- measured slower and was removed
+ * in round 6: profiles/r05/ab_rccl_async_tt24.txt.)  apd_exchange_setup_times: what the dlopen and the initialisation took. */
 int apd_exchange_create(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl);
-int apd_exchange_create_async(apd_exchange_t *out, int num_ranks, const int *devices, int prefer_rccl);
-int apd_exchange_preload_rccl(void);
-int apd_exchange_wait(apd_exchange_t x, double *setup_ms, double *waited_ms);
 int apd_exchange_setup_times(apd_exchange_t x, double *dlopen_ms, double *init_ms);
 int apd_exchange_allgather(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank);
-/* ... for a caller that has synchronised the streams which wrote the send buffers and knows the recv buffers to be idle: no device-wide
- * synchronisation, kernels queued by other host threads (the next pass's first halves) keep running beside the exchange. */
-int apd_exchange_allgather_ready(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank);
+/* ... without the device-wide synchronisation: the exchange's streams wait for the `num_events` HIP events (hipEvent_t; NULL entries are
+ * skipped) that mark the send buffers complete -- apd_export_event of every handle that exported a block -- and for nothing else, so
+ * kernels queued by other host threads (the next pass's first halves) keep running beside the exchange.  The caller knows the recv
+ * buffers to be idle. */
+int apd_exchange_allgather_after(apd_exchange_t x, const void *const *send, void *const *recv, size_t bytes_per_rank, int num_events,
+                                 void *const *hip_events);
 const char *apd_exchange_backend(apd_exchange_t x);   /* "rccl" or "peer-copy" */
 int apd_exchange_counts(apd_exchange_t x, int *with_rccl, int *with_copies);   /* exchanges served by either backend so far */
 int apd_exchange_destroy(apd_exchange_t x);
@@ -333,6 +333,9 @@ int apd_ransac_distance_cut(float depth_min, float depth_max, float ransac_thres
 
 const char *apd_last_error(void);
 int apd_version(void);
+/* Digest (16 hex digits) of the HIP sources, headers and compiler flags the library was built from: equals
+ * apd-mvs_amd/build.py:expected_build_id() of the same tree; anything else is a stale binary. */
+const char *apd_build_id(void);
 int apd_device_count(void);
 
 #ifdef __cplusplus

@@ -72,3 +72,42 @@ def test_no_gpu_means_the_fusion_fails_loudly_too(pkg, tmp_path):
     out = tmp_path / "x.ply"
     st = L.apd_fuse_views(0, 2, cams, fptr, 1, fptr, nptr, wptr, None, rows, cols, offs, idx, 0, str(out).encode(), C.byref(n))
     assert st != 0 and not out.exists() and L.apd_fusion_last_error()
+
+
+def test_library_carries_the_digest_of_the_trees_sources(pkg, tmp_path):
+    """apd_build_id() == build.py's digest of csrc/*, the headers and the compiler flags (an mtime test cannot tell a
+    stale binary on a box whose push preserved the times).  Any edit of a kernel source changes the digest; a library with another
+    digest is refused by apd_mvs_amd.lib()."""
+    import importlib.util
+    import shutil
+    assert pkg.build_id() == pkg.expected_build_id() and re.fullmatch(r"[0-9a-f]{16}", pkg.build_id())
+    spec = importlib.util.spec_from_file_location("apd_build_t", os.path.join(ROOT, "apd-mvs_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.expected_build_id() == pkg.build_id()
+    assert b.expected_build_id(["-DAPD_LAB_SOMETHING=1"]) != pkg.build_id()       # other flags, other binary
+    # the digest is over contents: one byte appended to a kernel source gives another id
+    csrc = tmp_path / "pkg" / "csrc"      # HEADERS reaches include/ as csrc/../../include
+    shutil.copytree(b.CSRC, csrc)
+    inc = tmp_path / "include"
+    shutil.copytree(os.path.join(ROOT, "include"), inc)
+    real = b.CSRC
+    try:
+        b.CSRC = str(csrc)
+        assert b.expected_build_id() == pkg.build_id()        # same bytes elsewhere: same id (mtimes play no part)
+        with open(csrc / "apd_kernels_k67w.hip", "a") as f:
+            f.write("\n")
+        assert b.expected_build_id() != pkg.build_id()
+    finally:
+        b.CSRC = real
+
+    class Stale:
+        class _Fn:
+            restype = None
+
+            def __call__(self):
+                return b"0123456789abcdef"
+        apd_build_id = _Fn()
+
+    with pytest.raises(pkg.ApdError, match="stale HIP library"):
+        pkg.check_build_id(Stale())

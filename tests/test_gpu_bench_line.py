@@ -25,11 +25,12 @@ def test_default_line_carries_every_sub_line():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]   # stdout is the one JSON line
-    assert len(lines[0].encode()) <= bench.COMPACT_LINE_MAX_BYTES == 2000, len(lines[0])
+    assert len(lines[0].encode()) <= bench.COMPACT_LINE_MAX_BYTES <= 2000, len(lines[0])
     c = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline", "workloads"):
         assert k in c, k
+    assert "truncated" not in c and c["value_config_iters"] > 0 and c["whole_pass"][0] > 0 and c["roofline"]["frac_kind"] == c["roofline"]["bound"]
     assert c["roofline"]["frac"] > 0 and c["roofline"]["bound"] and c["roofline"]["pmc_source"] and c["roofline"]["traffic"] > 0
     d = json.load(open(os.path.join(ROOT, bench.FULL_BLOCK_FILE)))
     assert "bench.py full block: " in r.stderr

@@ -230,6 +230,21 @@ def check_compact_lines(directory, problems):
                   ("roofline.algorithmic_GBps", r.get("algorithmic_GBps"), (fr.get("algorithmic") or {}).get("GBps"))]
         if "valu_busy" in r:
             pairs += [("roofline.valu_busy", r.get("valu_busy"), (fr.get("valu_busy_estimate") or {}).get("frac"))]
+        if "frac_kind" in r:   # round 6 on: the line says which bound `frac` is a fraction of, and carries SURVEY 8(d)'s byte ratio beside it
+            gb = (fr.get("algorithmic") or {}).get("GBps", (fr.get("algorithmic") or {}).get("GBps_nominal_max"))
+            pairs += [("roofline.frac_kind", r.get("frac_kind"), fr.get("bound")),
+                      ("roofline.algorithmic_over_hbm_peak", r.get("algorithmic_over_hbm_peak"), None if gb is None else round(gb / 8000.0, 2))]
+        fw = full.get("workloads") or {}
+        if "value_config_iters" in c:
+            it6 = fw.get("configs1_office_6iter") or {}
+            pairs += [("value_config_iters", c["value_config_iters"],
+                       full["value"] if full.get("steps") == 6 and full["config"].get("workload") == "eth3d_office_fullres_8src" else it6.get("value"))]
+        if "whole_pass" in c:
+            wp = fw.get("configs2_pipes_apd_whole_pass") or {}
+            pairs += [("whole_pass", c["whole_pass"], None if wp.get("value") is None else [wp["value"], wp.get("ms_per_pass")])]
+        if "configs0_cpu" in c:
+            c0 = (fw.get("configs0_office_halfres_2src_3iter") or {}).get("cpu_baseline")
+            pairs += [("configs0_cpu", c["configs0_cpu"], None if not c0 else [c0["value"], c0["cores"]])]
         cb, fcb = c.get("cpu_baseline") or {}, full.get("cpu_baseline") or {}
         pairs += [("cpu_baseline." + k, cb.get(k), fcb.get(k)) for k in ("value", "cores", "kind")]
         if set(c.get("workloads") or {}) != set(full.get("workloads") or {}):
