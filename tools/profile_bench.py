@@ -8,6 +8,7 @@ prescribes (kernel trace only; never combined with other trace domains):
     1. --kernel-trace --stats                                   launch durations, kernel_stats
     2. --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VMEM_RD
     3. --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum   (L1 tag look-ups, L1 -> L2 requests, L2 hits / misses)
+    3b. --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64   (the launch's VALU instructions by class)
     4. --pmc FETCH_SIZE                                          (KiB; x2 on gfx950, MI355X_MICROARCH.md "HBM")
     5. --pmc WRITE_SIZE                                          (KiB)
 For the sweep kernels (k67*, k910*) only the launches of the TIMED region are reduced: bench.py launches each of them twice
@@ -33,6 +34,10 @@ PASSES = [
     ("sq", ["--kernel-trace", "--pmc", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
             "SQ_WAIT_ANY", "SQ_WAVES", "SQ_INSTS_VMEM_RD"]),
     ("tcp", ["--kernel-trace", "--pmc", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"]),
+    # the launch's VALU instructions by class, whole kernel (every basic block at its real execution count): what bench.py prices with the
+    # measured issue costs for `valu_busy_estimate` (round 6; rounds 2-5 priced the static mix of ONE basic block)
+    ("mix", ["--kernel-trace", "--pmc", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32",
+             "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64"]),
     ("fetch", ["--kernel-trace", "--pmc", "FETCH_SIZE"]),
     ("write", ["--kernel-trace", "--pmc", "WRITE_SIZE"]),
 ]
@@ -157,6 +162,9 @@ def main():
         k["wait_inst_any_per_launch"] = mean("SQ_WAIT_INST_ANY")
         k["wait_any_per_launch"] = mean("SQ_WAIT_ANY")
         k["vmem_rd_insts_per_launch"] = mean("SQ_INSTS_VMEM_RD")
+        k["valu_class_insts_per_launch"] = {c[len("SQ_INSTS_VALU_"):]: mean(c) for c in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
+                                                                                       "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32",
+                                                                                       "SQ_INSTS_VALU_INT64") if mean(c) is not None}
         k["tcp_tag_accesses_per_launch"] = mean("TCP_TOTAL_CACHE_ACCESSES_sum")
         k["tcp_to_l2_read_requests_per_launch"] = mean("TCP_TCC_READ_REQ_sum")
         k["l2_hits_per_launch"], k["l2_misses_per_launch"] = mean("TCC_HIT_sum"), mean("TCC_MISS_sum")

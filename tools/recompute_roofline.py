@@ -64,6 +64,27 @@ def timed_mean(k, profiled_steps, launches):
     return mean
 
 
+def from_classes(roof):
+    """round 6: valu_busy_estimate comes from the whole-kernel class counters of the counter profile, not from a static block mix"""
+    return "frac_hi" in (roof.get("valu_busy_estimate") or {})
+
+
+FAST_C, SLOW_C, TRANS_C = 2.2, 4.067, 8.108   # bench.py: VALU_COST_*
+
+
+def class_busy_rows(roof, mean, insts, t):
+    """valu_busy_estimate.frac / frac_hi re-derived: sum over the SQ_INSTS_VALU_* classes of instructions x measured issue cycles."""
+    if not from_classes(roof):
+        return ()
+    fast = mean("SQ_INSTS_VALU_FMA_F32") + mean("SQ_INSTS_VALU_ADD_F32") + mean("SQ_INSTS_VALU_MUL_F32")
+    trans, cvt = mean("SQ_INSTS_VALU_TRANS_F32"), mean("SQ_INSTS_VALU_CVT")
+    other = max(insts - fast - trans - cvt, 0.0)
+    base = FAST_C * fast + TRANS_C * trans + SLOW_C * cvt
+    simd = 1024 * 2.4e9 * t
+    return (("valu_busy_estimate.frac", roof["valu_busy_estimate"]["frac"], (base + FAST_C * other) / simd, 2e-3),
+            ("valu_busy_estimate.frac_hi", roof["valu_busy_estimate"]["frac_hi"], (base + SLOW_C * other) / simd, 2e-3))
+
+
 def check_k67(tag, roof, k, mix, problems, profiled_steps):
     n = roof["launches"]
     mean = timed_mean(k, profiled_steps, n)
@@ -81,14 +102,14 @@ def check_k67(tag, roof, k, mix, problems, profiled_steps):
             ("peak", roof["peak"], PEAK, 1e-6),
             ("traffic", roof["traffic"], traffic, 1e-9),
             ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
-            ) + ((("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),) if (mix and "valu_busy_estimate" in roof) else ()) + (
+            ) + class_busy_rows(roof, mean, insts, t) + ((("valu_busy_estimate", roof["valu_busy_estimate"]["frac"], insts * mix / (1024 * 2.4e9 * t), 2e-3),) if (mix and "valu_busy_estimate" in roof and not from_classes(roof)) else ()) + (
             ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03),)):
         ok = got == want if rel == 0 else close(got, want, rel)
         if not ok:
             problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
-    if mix is None and "valu_busy_estimate" in roof:
+    if mix is None and "valu_busy_estimate" in roof and not from_classes(roof):
         problems.append("%s: valu_busy_estimate without a valu_mix_k67w.json of the profile's own round" % tag)
-    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or (mix and "valu_busy_estimate" in roof and roof["valu_busy_estimate"]["frac"] > 1):
+    if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or ("valu_busy_estimate" in roof and roof["valu_busy_estimate"]["frac"] > 1):
         problems.append("%s: a fraction above 1" % tag)
     return "k67 frac %.4f  hbm %.4f  busy %s  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
         achieved / PEAK, traffic / t / 1e9 / HBM, ("%.4f" % (insts * mix / (1024 * 2.4e9 * t))) if mix else "n/a", n, t * 1e3,
@@ -136,7 +157,7 @@ def check_pass_kernel(tag, roof, k, problems):
             ("frac", roof["frac"], achieved / PEAK, 1e-3),
             ("traffic", roof["traffic"], traffic, 1e-9),
             ("hbm.frac", roof["hbm"]["frac"], traffic / t / 1e9 / HBM, 2e-3),
-            ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03)):
+            ("profile launch time vs live launch time", mean("duration_ns@trace") * 1e-9, t, 0.03)) + class_busy_rows(roof, mean, insts, t):
         if not close(got, want, rel):
             problems.append("%s: %s is %r in the line, %r from the counters" % (tag, what, got, want))
     if roof["frac"] > 1 or roof["hbm"]["frac"] > 1:
@@ -230,6 +251,8 @@ def check_compact_lines(directory, problems):
                   ("roofline.algorithmic_GBps", r.get("algorithmic_GBps"), (fr.get("algorithmic") or {}).get("GBps"))]
         if "valu_busy" in r:
             pairs += [("roofline.valu_busy", r.get("valu_busy"), (fr.get("valu_busy_estimate") or {}).get("frac"))]
+        if "valu_busy_hi" in r:
+            pairs += [("roofline.valu_busy_hi", r.get("valu_busy_hi"), (fr.get("valu_busy_estimate") or {}).get("frac_hi"))]
         if "frac_kind" in r:   # round 6 on: the line says which bound `frac` is a fraction of, and carries SURVEY 8(d)'s byte ratio beside it
             gb = (fr.get("algorithmic") or {}).get("GBps", (fr.get("algorithmic") or {}).get("GBps_nominal_max"))
             pairs += [("roofline.frac_kind", r.get("frac_kind"), fr.get("bound")),
