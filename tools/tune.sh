@@ -3,6 +3,7 @@
 # Usage: [TUNE_WORKLOAD=synthetic_4096x3072_8src_apd] [TUNE_STEPS=3] tools/tune.sh "<flags1>" "<flags2>" ...
 WL=${TUNE_WORKLOAD:-synthetic_4096x3072_8src}
 ARGS="--workload $WL --steps ${TUNE_STEPS:-3} --warmup 1 --no-cpu-baseline"
+export APD_ALLOW_STALE_LIBRARY=1   # lab builds with ad-hoc flags: the build-id guard of apd_mvs_amd.lib() is for the product
 for f in "$@"; do
   APD_EXTRA_FLAGS="$f" python apd-mvs_amd/build.py --force > /tmp/build.log 2>&1 || { echo "BUILD FAILED for $f"; tail -5 /tmp/build.log; continue; }
   echo "== flags: [$f] workload $WL"
