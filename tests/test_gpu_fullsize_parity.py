@@ -305,3 +305,49 @@ def test_configs1_full_frame_oracle_iteration2(gpu_pkg, ob, synth, record_proper
     assert n == 3
     h.close()
     o.close()
+
+
+def test_configs3_frame_every_kernel_over_the_whole_frame(gpu_pkg, ob, synth, record_property):
+    """configs[3]'s frame (1920 x 1080, 10 source views) with NO region of interest: every kernel of a REFINE_INIT + APD pass (K1..K5, two
+    iterations of K6..K10, K11..K15: 20 kernels) and of the REFINE_ITER + APD + geometric pass that follows it (K1..K5, one iteration,
+    K11..K15: 15 kernels) runs on the HIP path and on the oracle over all 2.07 Mpix from the same pre-kernel state, and every state array of
+    every pixel is compared as raw bits after every kernel.  The 6200 x 4130 tests compare windows (1.3 % of the frame) after every kernel
+    and one strong iteration over the whole frame; this one puts K3, K8, K9/K10, K14 and K15 -- list compaction in supertile order, XCD
+    chunking of the WEAK lists, the chunk-major K14 with its pair walk (ten sources) -- under a whole-frame comparison too."""
+    import time
+    W, H, N = 1920, 1080, 10
+    sc, imgs = _scene(synth, W, H, N, textureless=0.2)
+    p0 = common.base_params(sc, N, max_iterations=3, seed=2024, weak_peak_radius=6)
+    h0 = common.make_handle(gpu_pkg, sc, imgs, N, p0)
+    h0.run()
+    planes, weak, views = h0.download()
+    h0.close()
+    prior = common.postprocess(planes, weak, views, p0["depth_min"], p0["depth_max"])
+    weak_fraction = float((prior[2] == 0).mean())
+    assert 0.05 < weak_fraction < 0.5, weak_fraction
+    t0 = time.perf_counter()
+    p = common.base_params(sc, N, max_iterations=2, seed=2025, state=1, use_APD=1, weak_peak_radius=6, rotate_time=4, ransac_threshold=0.01 - 0.00125 * 3)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, p, prior=prior)
+    o = common.make_oracle(ob, sc, imgs, N, p, prior=prior)
+    assert h.weak_count == o.weak_count > 10000
+    log = []
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(2, True), [(0, 0, W, H)], "configs[3] frame, APD pass, whole frame", log)
+    assert n == 20
+    planes, weak, views = h.download()
+    h.close()
+    o.close()
+    prior = common.postprocess(planes, weak, views, p["depth_min"], p["depth_max"])
+    deps = [np.ascontiguousarray(prior[0][..., 3])] + common.fake_depth_maps(W, H, N)
+    pg = common.base_params(sc, N, max_iterations=1, seed=2026, state=2, use_APD=1, geom_consistency=1, weak_peak_radius=4, rotate_time=4,
+                            ransac_threshold=0.01 - 0.00125 * 3)
+    h = common.make_handle(gpu_pkg, sc, imgs, N, pg, depths=deps, prior=prior)
+    o = common.make_oracle(ob, sc, imgs, N, pg, depths=deps, prior=prior)
+    assert h.weak_count == o.weak_count > 0
+    n = common.fullsize_lockstep(gpu_pkg, h, o, _schedule(1, True), [(0, 0, W, H)], "configs[3] frame, geometric pass, whole frame", log)
+    assert n == 15
+    print("\n".join(log))
+    record_property("whole_frame_kernels_compared", 35)
+    record_property("weak_fraction", weak_fraction)
+    record_property("seconds", round(time.perf_counter() - t0, 1))
+    h.close()
+    o.close()
