@@ -3,7 +3,7 @@
 # committed for, then the bench lines themselves -- made AFTER their profiles, in the same checkout, so that every roofline
 # field follows from the committed counters (tools/recompute_roofline.py).  Usage: tools/profile_round.sh <out_dir> [round, e.g. r04]
 OUT=${1:-gpurun_out/profile_round}
-ROUND=${2:-r05}
+ROUND=${2:-r06}
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
@@ -11,6 +11,7 @@ run_profile() {  # workload steps
   timeout 1500 python tools/profile_bench.py "$OUT" --workload "$1" --steps "$2" --warmup 1 > "$OUT/profile_$1.log" 2>&1 || echo "profile of $1 failed" >> "$OUT/errors.txt"
 }
 run_profile eth3d_office_fullres_8src 24
+run_profile eth3d_office_halfres_2src 3      # configs[0]
 run_profile eth3d_pipes_fullres_10src_apd 6
 run_profile synthetic_4096x3072_16src 8
 run_profile tt_family_1080p_10src 24
