@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 
-@pytest.mark.parametrize("round_dir", ["r02", "r03", "r04", "r05"])
+@pytest.mark.parametrize("round_dir", ["r02", "r03", "r04", "r05", "r06"])
 def test_roofline_fields_follow_from_the_committed_counters(round_dir):
     d = os.path.join(ROOT, "profiles", round_dir)
     import glob
@@ -87,3 +87,24 @@ def test_pass_kernel_roofline_without_a_profile_reports_null_fields():
     r = bench.pass_kernel_roofline(Pkg, live, Pkg.K14, "k14", name, "photometric", (), 12345)
     assert r["pmc_source"].startswith("profiles/") and 0.0 < r["frac"] < 1.0 and 0.0 < r["hbm"]["frac"] < 1.0
     assert abs(r["achieved"] - r["valu_insts_per_launch"] / 0.3 / 1e9) < 0.1
+
+
+def test_whole_kernel_valu_busy_comes_from_the_class_counters():
+    """Round 6: valu_busy_estimate = the launch's VALU instructions by class (SQ_INSTS_VALU_*: every basic block at its execution count)
+    x measured issue cycles, as a bracket; the committed round-6 profile of the default workload gives a bracket inside (frac, 1)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    got = bench.load_pmc_profile("eth3d_office_fullres_8src", 20, 5, "k67")
+    assert got is not None and got["source"].startswith("profiles/r06/") and got["valu_classes"] is not None
+    t_ms = got["launch_ms"]
+    b = bench.valu_busy_from_classes(got["valu_insts_per_launch"], got["valu_classes"], t_ms)
+    issue = got["valu_insts_per_launch"] / (t_ms * 1e-3) / 1e9 / bench.VALU_PEAK_GINST
+    assert issue < b["frac"] < b["frac_hi"] < 1.0, (issue, b)      # 2.2 cycles per instruction at least, never more than the pipe has
+    assert abs(sum(b["class_share"].values()) - 1.0) < 0.02
+    assert bench.valu_busy_from_classes(1e9, None, 1.0) is None     # a profile without the class pass: no estimate (the static mix of rounds 2-5 is used)
+    # a synthetic check of the arithmetic: 100 instructions, 50 fast, 10 transcendental, 10 conversions, 30 of unknown class
+    c = {"fma": 30.0, "add": 10.0, "mul": 10.0, "trans": 10.0, "cvt": 10.0, "int32": 20.0, "int64": 0.0}
+    r = bench.valu_busy_from_classes(100.0, c, 1.0)
+    simd = bench.NUM_SIMDS * bench.MAX_CLOCK_GHZ * 1e9 * 1e-3
+    base = 2.2 * 50 + 8.108 * 10 + 4.067 * 10
+    assert abs(r["frac"] * simd - (base + 2.2 * 30)) < 1e-3 * simd * r["frac"] + 1e-9 or abs(r["frac"] - round((base + 2.2 * 30) / simd, 4)) <= 1e-4

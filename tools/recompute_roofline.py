@@ -111,9 +111,10 @@ def check_k67(tag, roof, k, mix, problems, profiled_steps):
         problems.append("%s: valu_busy_estimate without a valu_mix_k67w.json of the profile's own round" % tag)
     if roof["frac"] > 1 or roof["hbm"]["frac"] > 1 or ("valu_busy_estimate" in roof and roof["valu_busy_estimate"]["frac"] > 1):
         problems.append("%s: a fraction above 1" % tag)
+    rows = class_busy_rows(roof, mean, insts, t)
+    busy = ("%.4f..%.4f" % (rows[0][2], rows[1][2])) if rows else (("%.4f" % (insts * mix / (1024 * 2.4e9 * t))) if mix else "n/a")
     return "k67 frac %.4f  hbm %.4f  busy %s  (%d launches, %.3f ms live, %.3f ms in the trace)" % (
-        achieved / PEAK, traffic / t / 1e9 / HBM, ("%.4f" % (insts * mix / (1024 * 2.4e9 * t))) if mix else "n/a", n, t * 1e3,
-        mean("duration_ns@trace") * 1e-6)
+        achieved / PEAK, traffic / t / 1e9 / HBM, busy, n, t * 1e3, mean("duration_ns@trace") * 1e-6)
 
 
 def check_k910(tag, roof, k, problems, profiled_steps):
