@@ -234,6 +234,12 @@ void ProcessProblem(const Problem &problem)
 int main(int argc, char **argv)
 {
     const auto t_start = std::chrono::steady_clock::now();
+    // Views in flight run on their own HIP streams, and the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4):
+    // two streams that land on one queue take turns.  Eight queues: 24 x 1080p passes 7.70 -> 7.58 s with six views in flight, and the
+    // 1.3 s round 5 charged to the peer-copy exchange of `0,0 --no-rccl` (8.82 -> 7.54 s: its two lanes shared a queue; loading librccl
+    // happened to shift the mapping) -- profiles/r06/ab_hw_queues.txt.  Read by the HIP runtime when it starts, i.e. at the first HIP
+    // call below; a value the caller has set is kept.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Options opt;
     if (!ParseOptions(argc, argv, opt)) {
         fprintf(stderr, "USAGE: APD dense_folder [gpu_index | gpu,gpu,...] [--seed S] [--iters K] [--single-level] [--max-src N] [--keep-maps] [--no-fusion] [--files | --in-memory] [--jacobi] [--ranks N] [--no-rccl] [--rccl] [--exchange-device-sync] [--late-fusion-inputs] [--copy-images] [--clean-exit]\n");

@@ -373,6 +373,7 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
         std::vector<int> done_pass(V, -1);
         std::mutex done_m;
         std::condition_variable done_cv;
+        double exchange_ms = 0.0;   // wall time of the per-pass exchanges (under done_m)
         const auto t_all = std::chrono::steady_clock::now();
         // ---- level inputs (APD.cpp:464-488), once per level: resampled on the host (one thread per image), uploaded by one thread per
         // rank, only the images a rank's views reference ----
@@ -760,13 +761,16 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
                                                 }
                                             }
                                         }
+                                        const auto t_x = std::chrono::steady_clock::now();
                                         Check(opt.exchange_device_sync
                                                   ? apd_exchange_allgather(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float))
                                                   : apd_exchange_allgather_after(exchange, send.data(), recv.data(), (size_t)slots * pix * sizeof(float),
                                                                                  (int)exported.size(), exported.data()),
                                               "apd_exchange_allgather");
+                                        const double x_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_x).count();
                                         {
                                             std::lock_guard<std::mutex> lock(done_m);
+                                            exchange_ms += x_ms;
                                             exchanged = it;
                                             if (it % 4 == 3) {
                                                 printf("Round: %d done\n", pass.level);
@@ -898,8 +902,9 @@ int RunMultiDevice(const Options &opt, std::vector<Problem> &problems)
             apd_exchange_counts(exchange, &with_rccl, &with_copies);
             double dl = 0, init = 0;
             apd_exchange_setup_times(exchange, &dl, &init);
-            printf("Exchanges: %d through RCCL, %d through direct copies; RCCL set-up: dlopen %.0f ms, communicators %.0f ms (incl. the dlopen when this "
-                   "exchange was the process's first); backend %s\n", with_rccl, with_copies, dl, init, apd_exchange_backend(exchange));
+            printf("Exchanges: %d through RCCL, %d through direct copies, the per-pass ones took %.0f ms in all; RCCL set-up: dlopen %.0f ms, communicators "
+                   "%.0f ms (incl. the dlopen when this exchange was the process's first); backend %s\n", with_rccl, with_copies, exchange_ms, dl, init,
+                   apd_exchange_backend(exchange));
         }
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_all).count();
         printf("All passes done: %lld ms\n", (long long)ms);

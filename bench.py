@@ -31,6 +31,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Handles launch on their own HIP streams; the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two views
+# in flight whose streams share a queue take turns.  Eight queues, as the drop-in binary sets for itself (host/main.cpp,
+# profiles/r06/ab_hw_queues.txt); only the lines with several views in flight per GPU can notice.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 # Vector-ALU issue ceiling of the chip: 256 CUs x 4 SIMDs at the 2.4 GHz maximum clock, one wave64 binary32 multiply / add /
