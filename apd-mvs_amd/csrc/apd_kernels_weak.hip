@@ -594,27 +594,29 @@ __device__ __forceinline__ void weak_prepare_neighbours(const FrameArgs &fa, con
     }
 }
 
+// ComputeBilateralNCCNew in three pieces, so that K9/K10 can evaluate the sub-patch part of a (pixel, hypothesis) pair on another lane than
+// the centre part (see the propagation phase of k910_update_weak); ncc_deformed below is the three in one.
+
+// k == 0: the pixel itself with the strong geometry.  The caller has done the bounds test of APD.cu:546 on the projected centre.
 // w: this wave's window of view v for the centre patch (texel-quad mode; valid = 0: none staged)
 template <bool kQuad, typename Ref>
-__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLdsT<kQuad> &lds,
-                                              int lane, int px, int py, const float4 pl, const SrcWindow &w)
+__device__ __forceinline__ float deformed_centre(const FrameArgs &fa, const ViewConst &vc, const Ref &rp, const Homography &H, int px, int py,
+                                                 const SrcWindow &w)
 {
-    float qx, qy, qz;
-    plane_q(pl, qx, qy, qz);
-    const Homography H = make_homography(fa, vc, qx, qy, qz);
-    float cx, cy;
-    correspond(H, (float)px, (float)py, cx, cy);
-    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
-        return 2.0f;
-    }
-    // k == 0: the pixel itself with the strong geometry (its bounds test repeats the one above).  Lanes whose 36 samples fall
-    // inside the wave's window read LDS, the others gather: only the latter cost L1 tag accesses, which bound this kernel.
-    float center_cost;
+    // Lanes whose 36 samples fall inside the wave's window read LDS, the others gather: only the latter cost L1 tag accesses, which bound this kernel.
     if constexpr (kQuad) {
-        center_cost = ncc_fixed_windowed_from_h<true, kWinW, false, false, APD_K910_WIN_DIVERGENT != 0>(fa, vc, w, rp, H, px, py);
+        return ncc_fixed_windowed_from_h<true, kWinW, false, false, APD_K910_WIN_DIVERGENT != 0>(fa, vc, w, rp, H, px, py);
     } else {
-        center_cost = ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
+        return ncc_fixed_from_h<kQuad>(fa, vc, rp, H, px, py);
     }
+}
+
+// k = 1 .. 8: the 3 x 3 sub-patches around the reliable neighbours of the pixel whose data sits in column `owner` of the wave's LDS
+// tables, warped by H; summed in slot order (APD.cu:461-520).
+template <bool kQuad>
+__device__ __forceinline__ void deformed_strong(const FrameArgs &fa, const ViewConst &vc, int v, const WeakLdsT<kQuad> &lds, int owner,
+                                                const Homography &H, float &strong_cost, int &strong_count)
+{
 #if APD_K910_SUBPATCH_TILED
     const global_quad_ptr srcq = (global_quad_ptr)vc.quad_tiled;   // needs --opt tiled_copy=2 (the copy is built for every pass)
     const unsigned qpitch = quad_tiles_x(fa.W);
@@ -625,11 +627,11 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
     const unsigned fpitch = 16u * (unsigned)(fa.W + 1);
     const global_fquad_ptr srcf = (global_fquad_ptr)vc.fquad;
     const int wm1 = fa.W - 1, hm1 = fa.H - 1;
-    float strong_cost = 0.0f;
-    int strong_count = 0;
+    strong_cost = 0.0f;
+    strong_count = 0;
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
-        const int packed = lds.nb[k][lane];
+        const int packed = lds.nb[k][owner];
         if (packed == -1) {
             continue;
         }
@@ -652,29 +654,53 @@ __device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewCon
         const bool fast = denominators_fast(H, (float)(nbx - kSubStep), (float)(nbx + kSubStep), (float)(nby - kSubStep), (float)(nby + kSubStep));
         uint32_t ref_rows[kSubN] = {0u, 0u, 0u};
         float mean_r, var_r;
-        lds.load_sub(k, lane, ref_rows, mean_r, var_r);
+        lds.load_sub(k, owner, ref_rows, mean_r, var_r);
         if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
             if constexpr (kQuad) {
                 c = subpatch_cost_quad<kRecipExact>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, mean_r, var_r);
             } else {
-                c = subpatch_cost_fquad<kRecipExact>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, mean_r, var_r);
+                c = subpatch_cost_fquad<kRecipExact>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][owner], 64, mean_r, var_r);
             }
         } else {
             if constexpr (kQuad) {
                 c = subpatch_cost_quad<kRecipIeee>(H, srcq, qpitch, wm1, hm1, nbx, nby, ref_rows, mean_r, var_r);
             } else {
-                c = subpatch_cost_fquad<kRecipIeee>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][lane], 64, mean_r, var_r);
+                c = subpatch_cost_fquad<kRecipIeee>(H, srcf, fpitch, wm1, hm1, nbx, nby, &lds.ref[k][0][owner], 64, mean_r, var_r);
             }
         }
         strong_cost += c;
         strong_count++;
     }
+}
+
+// APD.cu:505-527: the mean of the sub-patch costs, clamped, mixed 3 : 1 with the centre cost in double
+__device__ __forceinline__ float deformed_combine(float center_cost, float strong_cost, int strong_count)
+{
     if (strong_count == 0) {
         return center_cost;
     }
     strong_cost /= (float)strong_count;
     strong_cost = (strong_cost > 2.0f) ? 2.0f : strong_cost;
     return (float)(0.25 * (double)center_cost + 0.75 * (double)strong_cost);
+}
+
+template <bool kQuad, typename Ref>
+__device__ __forceinline__ float ncc_deformed(const FrameArgs &fa, const ViewConst &vc, int v, const Ref &rp, const WeakLdsT<kQuad> &lds,
+                                              int lane, int px, int py, const float4 pl, const SrcWindow &w)
+{
+    float qx, qy, qz;
+    plane_q(pl, qx, qy, qz);
+    const Homography H = make_homography(fa, vc, qx, qy, qz);
+    float cx, cy;
+    correspond(H, (float)px, (float)py, cx, cy);
+    if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
+        return 2.0f;
+    }
+    const float center_cost = deformed_centre<kQuad>(fa, vc, rp, H, px, py, w);
+    float strong_cost;
+    int strong_count;
+    deformed_strong<kQuad>(fa, vc, v, lds, lane, H, strong_cost, strong_count);
+    return deformed_combine(center_cost, strong_cost, strong_count);
 }
 
 // WEAK pixels are sparse and clustered: the ones of each colour are compacted into a list and the update kernels run on
@@ -823,8 +849,16 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
     __shared__ WeakLdsT<kQuad> lds;
     // texel-quad mode: hypotheses 9..14 walk a compacted table of open (lane, hypothesis) pairs (see below)
     constexpr bool kCompact = kQuad && APD_K910_COMPACT_REFINE != 0;
-    __shared__ uint16_t refine_items[kCompact ? 5 * 64 : 1];
-    __shared__ float refine_cost[kCompact ? 5 : 1][64];
+    // Two phases, one LDS region.  Propagation (APD_K910_REMAP): prop_cost[h][pixel] -- the centre cost of (pixel, hypothesis h) on the way
+    // in, its NCCNew cost on the way out -- and prop_live[pixel], the hypotheses whose sub-patches are to be scored.  Refinement
+    // (kCompact): the table of open (lane, hypothesis) pairs and their costs.
+    constexpr bool kRemap = APD_K910_REMAP != 0;
+    constexpr int kPropWords = kRemap ? 8 * 64 + 64 : 0, kRefineWords = kCompact ? 5 * 64 + 5 * 64 / 2 : 0;
+    __shared__ uint32_t phase_lds[(kPropWords > kRefineWords ? kPropWords : kRefineWords) > 0 ? (kPropWords > kRefineWords ? kPropWords : kRefineWords) : 1];
+    float (*const prop_cost)[64] = reinterpret_cast<float (*)[64]>(phase_lds);
+    uint32_t *const prop_live = phase_lds + 8 * 64;
+    float (*const refine_cost)[64] = reinterpret_cast<float (*)[64]>(phase_lds);
+    uint16_t *const refine_items = reinterpret_cast<uint16_t *>(phase_lds + 5 * 64);
     // the wave's window of the current source view for the centre patches (texel-quad mode)
     __shared__ uint32_t centre_window[kQuad ? window_dwords(true, kK910WinH) : 1];
     const int lane = threadIdx.x;
@@ -889,21 +923,93 @@ __global__ __launch_bounds__(64, APD_K910_WAVES) void k910_update_weak(FrameArgs
         if constexpr (kQuad && APD_K910_WINDOW != 0) {
             w = weak_stage_window(fa, vc, centre_window, px, py, plane_now);
         }
+        if constexpr (!kRemap) {
 #pragma unroll 1
-        for (int h = 0; h < 9; ++h) {
-            if (h < 8 && !(flags & (1u << h))) {
-                continue;
+            for (int h = 0; h < 9; ++h) {
+                if (h < 8 && !(flags & (1u << h))) {
+                    continue;
+                }
+                float4 pl = plane_now;
+                if (h < 8) {  // the neighbour's position is already in LDS (weak_prepare_neighbours): one global load instead of two dependent ones
+                    const int packed = lds.nb[h][lane];
+                    pl = fa.planes[(int)(short)(packed & 0xFFFF) + (packed >> 16) * W];
+                }
+                APD_WEAK_COUNT(0, 1);
+                APD_WEAK_COUNT_WAVE(1);
+                cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl, w);
             }
-            float4 pl = plane_now;
-            if (h < 8) {  // the neighbour's position is already in LDS (weak_prepare_neighbours): one global load instead of two dependent ones
-                const int packed = lds.nb[h][lane];
-                pl = fa.planes[(int)(short)(packed & 0xFFFF) + (packed >> 16) * W];
+        } else {
+            // Lane = pixel for the centre patches (their 36 samples lie around the pixel: the wave's window serves them) and for the own-plane
+            // hypothesis; lane = (pixel, hypothesis) for the sub-patches of the eight neighbour hypotheses.  A sub-patch sits where its ANCHOR
+            // is, a median of 27 px from the pixel in a direction of its own (tools/nb_cluster.py), so with lane = pixel the 64 lanes of a
+            // sub-patch tap read 64 unrelated places: one L1 tag access per lane, the bound of this kernel through round 5 (46 of 49 ms).
+            // With eight consecutive lanes on the eight hypotheses of ONE pixel and slot, the eight read the same anchor's neighbourhood
+            // under eight nearly equal planes -- texels a few bytes apart, which the L1 serves with one tag access per aligned 16 bytes
+            // (tools/tcp_patterns.hip) -- and a wave-level tap touches eight places instead of sixty-four.  Same operands, same operations,
+            // the sub-patch costs of a (pixel, hypothesis) pair summed by one lane in slot order: same bits.
+            unsigned live = 0;   // neighbour hypotheses whose centre projects into the view: their sub-patches are scored below
+#pragma unroll 1
+            for (int h = 0; h < 9; ++h) {
+                if (h < 8 && !(flags & (1u << h))) {
+                    continue;
+                }
+                float4 pl = plane_now;
+                if (h < 8) {
+                    const int packed = lds.nb[h][lane];
+                    pl = fa.planes[(int)(short)(packed & 0xFFFF) + (packed >> 16) * W];
+                }
+                APD_WEAK_COUNT(0, 1);
+                APD_WEAK_COUNT_WAVE(1);
+                float qx, qy, qz;
+                plane_q(pl, qx, qy, qz);
+                const Homography H = make_homography(fa, vc, qx, qy, qz);
+                float cx, cy;
+                correspond(H, (float)px, (float)py, cx, cy);
+                if (cx >= vc.wf || cx < 0.0f || cy >= vc.hf || cy < 0.0f) {
+                    cost_array[h][v] = 2.0f;
+                    continue;
+                }
+                const float center_cost = deformed_centre<kQuad>(fa, vc, rp, H, px, py, w);
+                if (h == 8) {
+                    float strong_cost;
+                    int strong_count;
+                    deformed_strong<kQuad>(fa, vc, v, lds, lane, H, strong_cost, strong_count);
+                    cost_array[8][v] = deformed_combine(center_cost, strong_cost, strong_count);
+                } else {
+                    prop_cost[h][lane] = center_cost;
+                    live |= 1u << h;
+                }
             }
-            APD_WEAK_COUNT(0, 1);
-            APD_WEAK_COUNT_WAVE(1);
-            cost_array[h][v] = ncc_deformed<kQuad>(fa, vc, v, rp, lds, lane, px, py, pl, w);
+            prop_live[lane] = live;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int hyp = lane & 7;
+#pragma unroll 1
+            for (int g = 0; g < 8; ++g) {
+                const int owner = g * 8 + (lane >> 3);
+                const bool active = ((prop_live[owner] >> hyp) & 1u) != 0;
+                if (active) {
+                    const int packed = lds.nb[hyp][owner];
+                    const float4 pl = fa.planes[(int)(short)(packed & 0xFFFF) + (packed >> 16) * W];
+                    float qx, qy, qz;
+                    plane_q(pl, qx, qy, qz);
+                    const Homography H = make_homography(fa, vc, qx, qy, qz);
+                    float strong_cost;
+                    int strong_count;
+                    deformed_strong<kQuad>(fa, vc, v, lds, owner, H, strong_cost, strong_count);
+                    prop_cost[hyp][owner] = deformed_combine(prop_cost[hyp][owner], strong_cost, strong_count);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                if (live & (1u << h)) {
+                    cost_array[h][v] = prop_cost[h][lane];
+                }
+            }
         }
-        if constexpr (kQuad) {  // the window is rewritten for the next view
+        if constexpr (kQuad || kRemap) {  // the window / the cost table is rewritten for the next view
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }

@@ -126,6 +126,10 @@
 #define APD_K910_SUBPATCH_TILED 0  // 1 (A/B runs, with --opt tiled_copy=2): the 3 x 3 stride-5 sub-patch taps gather from the 7 x 8 pair tiles instead
                                    // of the row-major pairs.  Measured in round 5 (profiles/r05/ab_k910_tiled.txt), see DESIGN.md section 6
 #endif
+#ifndef APD_K910_REMAP
+#define APD_K910_REMAP 1  // propagation phase: the sub-patches of the eight neighbour hypotheses with lane = (pixel, hypothesis) instead of lane = pixel
+                          // (apd_kernels_weak.hip: k910_update_weak); 0: rounds 1-5
+#endif
 #ifndef APD_K910_COMPACT_REFINE
 #define APD_K910_COMPACT_REFINE 1
 #endif

@@ -137,6 +137,25 @@ def main():
                 allin = (inside | ~v).reshape(g * nwg, 512).all(-1).mean()
                 line += " %dx%d (%.0f KB): %.3f of the anchors, %.3f of the waves complete |" % (cw, ch, cw * ch / 1024.0, inside.sum() / v.sum(), allin)
             print(line)
+        # The lane = (pixel, hypothesis) mapping of round 6 (k910_update_weak, APD_K910_REMAP): a wave-level sub-patch tap is issued for the eight
+        # pixels of a group x their eight hypotheses at ONE slot index.  Lanes with the same (anchor of the slot, anchor of the hypothesis) pair
+        # read the same addresses (one L1 tag access for all of them).  How many distinct pairs per 64 lanes -- in K3's slot order (sorted by
+        # plane-fit weight per pixel) and with every pixel walking its anchors in the order of their angle around it?
+        code = np.where(valid, ay.astype(np.int64) * 65536 + ax, -1 - np.arange(8)[None, None, :])     # [waves, 64, 8] anchor id (invalid: unique)
+        ang = np.where(valid, np.arctan2(ay - py, ax - px), 10.0)
+        order = np.argsort(ang, axis=-1, kind="stable")
+        for name, c in (("K3 slot order", code), ("angle order", np.take_along_axis(code, order, -1))):
+            g = c.reshape(nw, 8, 8, 8)                      # [wave, group, pixel in group, slot]
+            pick = np.random.RandomState(2).choice(nw, min(nw, 3000), replace=False)
+            g = g[pick]
+            pairs = g[:, :, :, :, None] * (1 << 40) + g[:, :, :, None, :]     # [wave, group, pixel, slot k, hyp h]
+            # one wave-level tap = fixed (group, k): 8 pixels x 8 hyps = 64 lanes
+            lanes = pairs.transpose(0, 1, 3, 2, 4).reshape(len(pick) * 8 * 8, 64)
+            distinct = np.array([len(np.unique(r)) for r in lanes[np.random.RandomState(3).choice(len(lanes), 20000, replace=False)]])
+            places = g.transpose(0, 1, 3, 2).reshape(len(pick) * 8 * 8, 8)
+            dplaces = np.array([len(np.unique(r)) for r in places[np.random.RandomState(4).choice(len(places), 20000, replace=False)]])
+            print("  lane = (pixel, hypothesis), %-13s: distinct (anchor, plane) pairs per wave-level tap %.1f of 64; distinct anchors per tap %.2f of 8" % (
+                name, distinct.mean(), dplaces.mean()))
         # distinct anchors per wave: how much do lanes share?
         code = np.where(valid, ay * 65536 + ax, -1).reshape(nw, 512)
         distinct = np.array([len(np.unique(c[c >= 0])) for c in code[np.random.RandomState(1).choice(nw, min(nw, 4000), replace=False)]])
