@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, kQuad ? APD_K14W_WAVES : APD_K1415W_WAVES_F32)
                     const int U = __builtin_popcountll(um);
                     bool regular = false;
                     if constexpr (kPairs) {
-                        regular = ((n * U + 63) >> 6) + (fa.geom_consistency ? 1 : 2) <= n &&
+                        regular = ((n * U + 63) >> 6) + (fa.geom_consistency ? 1 : APD_K14_PAIRS_MIN_SAVE) <= n &&
                                   __builtin_amdgcn_ballot_w64(use && chunk_bits != ((1u << n) - 1u)) == 0;
                     }
                     if (kPairs && regular) {
@@ -563,7 +563,12 @@ __global__ __launch_bounds__(256, kQuad ? APD_K15W_WAVES : APD_K1415W_WAVES_F32)
 hipError_t launch_k14_windowed(const FrameArgs &fa, hipStream_t s)
 {
     const dim3 grid((fa.W + kFwTile - 1) / kFwTile, (fa.H + kFwTile - 1) / kFwTile);
-    const bool pairs = APD_K14_COMPACT && fa.num_src >= APD_K14_PAIRS_FROM_N;
+    // the (sample, lane)-pair variant pays from fewer views on in geometric passes (a saved wave-level NCC also saves its geometric term,
+    // and the walk is taken when it saves ONE): 8-bit input, K14 ms at 6200 x 4130 without / with it -- N = 8: 256.8 / 216.7 geometric,
+    // 240.0 / 238.7 photometric; N = 6: 194.4 / 176.0, 182.0 / 185.9; N = 4: 121.8 / 112.6, 122.8 / 126.2; N = 2: 41.3 / 40.2, 65.4 / 67.7
+    // (profiles/r06/ab_k14_pairs_by_pass_kind.txt).  Float images: 3100 x 2065, N = 8: 78.2 / 77.5, 66.3 / 68.7 -- unchanged rule.
+    const int pairs_from = !fa.use_quads ? APD_K14_PAIRS_FROM_N : (fa.geom_consistency ? APD_K14_PAIRS_FROM_N_GEOM : APD_K14_PAIRS_FROM_N_PHOTO);
+    const bool pairs = APD_K14_COMPACT && fa.num_src >= pairs_from;
     if (fa.use_quads) {
         if (pairs) {
             hipLaunchKernelGGL((k14w_depth_to_weak<true, true>), grid, dim3(256), 0, s, fa);

@@ -82,7 +82,16 @@
 #define APD_K14_COMPACT 1  // K14 may walk the (sample, lane) pairs of a chunk 64 at a time instead of one sample per wave-level NCC (0: never)
 #endif
 #ifndef APD_K14_PAIRS_FROM_N
-#define APD_K14_PAIRS_FROM_N 10  // ... in launches with at least this many source views
+#define APD_K14_PAIRS_FROM_N 10  // ... in launches with at least this many source views (float images)
+#endif
+#ifndef APD_K14_PAIRS_FROM_N_PHOTO
+#define APD_K14_PAIRS_FROM_N_PHOTO 8   // ... 8-bit input, photometric passes
+#endif
+#ifndef APD_K14_PAIRS_FROM_N_GEOM
+#define APD_K14_PAIRS_FROM_N_GEOM 2    // ... 8-bit input, passes with the geometric term
+#endif
+#ifndef APD_K14_PAIRS_MIN_SAVE
+#define APD_K14_PAIRS_MIN_SAVE 2  // photometric passes: a chunk walks its (sample, lane) pairs when that saves at least this many wave-level NCCs (geometric: one)
 #endif
 #ifndef APD_K14_CHUNK
 #define APD_K14_CHUNK 8  // depth samples per staged window = length of the register vector of cost sums: 4, 8 or 16 (K14 ms at 6200x4130, 10 views,
