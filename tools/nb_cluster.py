@@ -156,6 +156,23 @@ def main():
             dplaces = np.array([len(np.unique(r)) for r in places[np.random.RandomState(4).choice(len(places), 20000, replace=False)]])
             print("  lane = (pixel, hypothesis), %-13s: distinct (anchor, plane) pairs per wave-level tap %.1f of 64; distinct anchors per tap %.2f of 8" % (
                 name, distinct.mean(), dplaces.mean()))
+        if "--global-pairs" in sys.argv:
+            # how many DISTINCT (anchor of the slot, anchor of the hypothesis) pairs does a whole launch hold?  c(anchor, plane of anchor', view) does not
+            # depend on the WEAK pixel that asks for it (the two-kernel form of the propagation phase)
+            ids = np.where(valid, ay.astype(np.int64) * 65536 + ax, -1).reshape(-1, 8)          # [pixels, 8]
+            strong = valid.reshape(-1, 8)
+            pair = ids[:, :, None] * (1 << 32) + ids[:, None, :]                                 # [pixels, slot k, hyp h]
+            ok = strong[:, :, None] & strong[:, None, :]
+            flat = pair[ok]
+            uniq = np.unique(flat)
+            print("  whole launch (colour %d): %d (slot, hypothesis) pairs over %d WEAK pixels, %d distinct (anchor, anchor') pairs = %.3f; distinct anchors %d (%.1f pairs each)" % (
+                colour, flat.size, ids.shape[0], uniq.size, uniq.size / flat.size, np.unique(ids[strong]).size, uniq.size / max(np.unique(ids[strong]).size, 1)))
+            for tile_waves in (1, 4, 16, 64, 256):
+                n = (ids.shape[0] // (64 * tile_waves)) * 64 * tile_waves
+                blk = np.where(ok[:n], pair[:n], -1).reshape(-1, 64 * tile_waves * 64)
+                pick = np.random.RandomState(5).choice(blk.shape[0], min(blk.shape[0], 300), replace=False)
+                ratio = np.mean([(np.unique(b[b >= 0]).size) / max((b >= 0).sum(), 1) for b in blk[pick]])
+                print("    inside %4d consecutive waves of the list: distinct / all = %.3f" % (tile_waves, ratio))
         # distinct anchors per wave: how much do lanes share?
         code = np.where(valid, ay * 65536 + ax, -1).reshape(nw, 512)
         distinct = np.array([len(np.unique(c[c >= 0])) for c in code[np.random.RandomState(1).choice(nw, min(nw, 4000), replace=False)]])
