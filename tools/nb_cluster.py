@@ -167,6 +167,10 @@ def main():
             uniq = np.unique(flat)
             print("  whole launch (colour %d): %d (slot, hypothesis) pairs over %d WEAK pixels, %d distinct (anchor, anchor') pairs = %.3f; distinct anchors %d (%.1f pairs each)" % (
                 colour, flat.size, ids.shape[0], uniq.size, uniq.size / flat.size, np.unique(ids[strong]).size, uniq.size / max(np.unique(ids[strong]).size, 1)))
+            per_anchor = np.unique(uniq >> 32, return_counts=True)[1]
+            print("    distinct partners per anchor: median %d, p90 %d, p99 %d, p99.9 %d, max %d; share of pairs whose anchor has > 128 partners %.4f, > 256: %.4f" % (
+                np.median(per_anchor), np.percentile(per_anchor, 90), np.percentile(per_anchor, 99), np.percentile(per_anchor, 99.9), per_anchor.max(),
+                per_anchor[per_anchor > 128].sum() / per_anchor.sum(), per_anchor[per_anchor > 256].sum() / per_anchor.sum()))
             for tile_waves in (1, 4, 16, 64, 256):
                 n = (ids.shape[0] // (64 * tile_waves)) * 64 * tile_waves
                 blk = np.where(ok[:n], pair[:n], -1).reshape(-1, 64 * tile_waves * 64)
