@@ -94,7 +94,7 @@ def check_build_id(L):
     have, want = build_id(L), expected_build_id()
     if have != want:
         raise ApdError("stale HIP library: %s was built from sources with digest %s, the tree's csrc/ + flags give %s; "
-                       "run __graft_entry__.build()" % (LIB_PATH, have, want))
+                       "run __graft_entry__.build() (a lab build with APD_EXTRA_FLAGS: set APD_ALLOW_STALE_LIBRARY=1)" % (LIB_PATH, have, want))
 
 
 def lib():

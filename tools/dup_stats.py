@@ -11,6 +11,8 @@ footprints (32 x 4 px, the 64 same-colour pixels one wave64 owns) of the per-wav
 need if every lane looped over its own distinct hypotheses only.
 
 Usage: python tools/dup_stats.py [W H N iters [apd]]"""
+import os as _os
+_os.environ.setdefault("APD_ALLOW_STALE_LIBRARY", "1")   # a lab build (-DAPD_LAB_WIN_STATS): not the digest of the tree's flags
 import os
 import sys
 

@@ -1,4 +1,5 @@
 # s_waitcnt lgkmcnt(0) at the head of the LDS-window body (APD_WIN_DRAIN_SMEM): headline + whole passes, both arms on one box, A B A B
+export APD_ALLOW_STALE_LIBRARY=1   # lab builds with ad-hoc flags
 O=gpurun_out/lab; mkdir -p $O
 for arm in 1 0 1 0; do
   APD_EXTRA_FLAGS="-DAPD_WIN_DRAIN_SMEM=$arm" python apd-mvs_amd/build.py --force > /tmp/build.log 2>&1 || { echo BUILD FAILED; tail -3 /tmp/build.log; }

@@ -1,5 +1,6 @@
 # K9/K10's sub-patch taps from the 7 x 8 pair tiles (lab build) against the row-major pairs, both with the tiled copy resident
 # (--opt tiled_copy=2): launch time + L1 tag accesses / L1->L2 requests per launch.  Output: gpurun_out/lab/ab_k910_tiled.txt
+export APD_ALLOW_STALE_LIBRARY=1   # lab builds with ad-hoc flags
 O=gpurun_out/lab; mkdir -p $O; export TMPDIR=/tmp
 WL="--workload eth3d_pipes_fullres_10src_apd --steps 3 --warmup 1 --opt tiled_copy=2"
 for arm in rowmajor tiled; do

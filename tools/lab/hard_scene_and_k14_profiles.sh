@@ -1,3 +1,4 @@
+export APD_ALLOW_STALE_LIBRARY=1   # lab builds with ad-hoc flags
 O=gpurun_out/lab; mkdir -p $O
 export TMPDIR=/tmp
 (time python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize_parity.py -m gpu -x -q -k "hard") > $O/pytest_hard.log 2>&1; tail -5 $O/pytest_hard.log

@@ -1,5 +1,7 @@
 """Lane-level against wave-level work of the weak sweep K9/K10 (library built with -DAPD_LAB_WIN_STATS).
 Usage: python tools/weak_stats.py [W H N iters]"""
+import os as _os
+_os.environ.setdefault("APD_ALLOW_STALE_LIBRARY", "1")   # a lab build (-DAPD_LAB_WIN_STATS): not the digest of the tree's flags
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,5 +1,7 @@
 """Window hit statistics of the K6/K7 LDS-window kernel, per iteration (library built with -DAPD_LAB_WIN_STATS).
 Usage: python tools/win_stats.py [--hard] [W H N iters]      --hard: the synth.HARD scene (occlusions, gain, lost overlap)"""
+import os as _os
+_os.environ.setdefault("APD_ALLOW_STALE_LIBRARY", "1")   # a lab build (-DAPD_LAB_WIN_STATS): not the digest of the tree's flags
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
